@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""W4A16 GEMM benchmark on MI355X (BASELINE.json: "W4A16 GEMM TOPS vs M, K=N=4096, g=128").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step = one W4A16 GEMM launch (through the C ABI) at M=512, K=N=4096, group 128 on synthetic data already
+resident in HBM; consecutive steps cycle through enough distinct weight sets to exceed the 256 MiB Infinity
+Cache, so small-M numbers are HBM numbers, not cache numbers.  Rank 0 prints ONE JSON line:
+
+  value / ms_per_step  K steps replayed back to back (one hipGraph), bracketed by barrier + synchronize, max over
+                       ranks; includes the launch boundary between consecutive kernels
+  roofline             the GEMM kernel's OWN duration (hipEvent pair bound to each dispatch, the same clock
+                       rocprofv3 --kernel-trace reports) against the HBM or MFMA peak
+  sweep                the same two measurements for every M of the BASELINE sweep (1, 8, 64, 512)
+  cpu_baseline         the reference's CPU path (dequantize_gemm + torch.matmul, restated in oracle/cpu_path.py)
+                       timed on the host cores on a bounded sample, N=1 only
+
+The path does not shard (one dense per-layer GEMM): --gpus N runs N independent replicas.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, spec (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA (MI355X_MICROARCH.md; sparse marketing figure NOT used)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--M", type=int, default=512, help="token count of the headline step")
+    ap.add_argument("--K", type=int, default=4096)
+    ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--G", type=int, default=128)
+    ap.add_argument("--sweep", default="1,8,64,512", help="comma-separated M values reported in 'sweep'")
+    ap.add_argument("--sets", type=int, default=0, help="distinct weight sets cycled through (0 = enough for > 320 MiB)")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 skinny, 2 tiled")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the W4A16 GEMM has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from quick_amd import _lib, packing
+    from quick_amd.build import build
+    build()
+    lib = _lib.load()
+
+    K, N, G = args.K, args.N, args.G
+    Ms = sorted({int(m) for m in args.sweep.split(",") if m} | {args.M})
+    set_bytes = K * N // 2 + (K // G) * 2 * N * 2 + (K // G) * (N // 4) * 4
+    n_sets = args.sets or max(2, -(-(320 << 20) // set_bytes))
+
+    # ---- synthetic data: set 0 from logical tensors (shared with the CPU baseline), the rest raw bits
+    import oracle
+    x_np, iw, s, z = oracle.make_synthetic(max(Ms), K, N, G, seed=0)
+    x_full = torch.from_numpy(x_np).to(dev)
+    sets = [tuple(t.contiguous() for t in packing.pack_mi355x(torch.from_numpy(iw).to(dev), torch.from_numpy(s).to(dev),
+                                                              torch.from_numpy(z.astype(np.int32)).to(dev)))]
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    for _ in range(n_sets - 1):
+        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 4, N // 2), dtype=torch.int32, device=dev, generator=gen)
+        sc = torch.zeros((K // G, 2 * N), dtype=torch.float16, device=dev)
+        sc[:, :N] = (torch.rand((K // G, N), device=dev, generator=gen) * 0.02 + 0.005).half()
+        qz = torch.zeros((K // G, N // 4), dtype=torch.int32, device=dev)
+        qz[:, :N // 8] = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // G, N // 8), dtype=torch.int32, device=dev, generator=gen)
+        sets.append((qw, sc, qz))
+    arr = lambda i: (ctypes.c_void_p * n_sets)(*[st[i].data_ptr() for st in sets])
+    qw_arr, sc_arr, qz_arr = arr(0), arr(1), arr(2)
+    stream = torch.cuda.current_stream()
+
+    def measure(M, steps, warmup):
+        x = x_full[:M].contiguous()
+        y = torch.empty((M, N), dtype=torch.float16, device=dev)
+        ws_bytes = lib.quick_w4a16_workspace_bytes_ex(M, K, N, G, args.kernel, 0)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+
+        def launch(i):
+            qw, sc, qz = sets[i % n_sets]
+            rc = lib.quick_w4a16_gemm_f16_ex(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, y.data_ptr(),
+                                             ws.data_ptr(), ws_bytes, M, K, N, G, args.kernel, 0,
+                                             torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise RuntimeError(_lib.last_error())
+
+        for i in range(warmup):
+            launch(i)
+        torch.cuda.synchronize()
+        # K steps as ONE hipGraph: back-to-back on the GPU, no host launch cost in the timed region
+        mode = "hipgraph"
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                for i in range(steps):
+                    launch(warmup + i)
+            graph.replay()                       # untimed first replay (graph upload)
+        except Exception as e:                   # pragma: no cover
+            log(f"graph capture failed ({e}); timing eager launches")
+            graph, mode = None, "eager"
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(steps):
+                launch(warmup + i)
+        e1.record()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        ms_step = e0.elapsed_time(e1) / steps
+        if dist is not None:
+            t = torch.tensor([ms_step], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms_step = float(t.item())
+
+        # the kernel's own duration: event pair bound to each dispatch, cycling the same weight sets
+        kus = (ctypes.c_float * steps)()
+        rc = lib.quick_w4a16_gemm_profile(x.data_ptr(), qw_arr, sc_arr, qz_arr, n_sets, y.data_ptr(), ws.data_ptr(), ws_bytes,
+                                          M, K, N, G, args.kernel, 0, steps, kus, stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(_lib.last_error())
+        k_us = float(np.mean(np.asarray(kus[:])[min(5, steps - 1):]))
+        # same, cache-resident (one weight set): what a launch sees when the layer was just touched
+        rc = lib.quick_w4a16_gemm_profile(x.data_ptr(), qw_arr, sc_arr, qz_arr, 1, y.data_ptr(), ws.data_ptr(), ws_bytes,
+                                          M, K, N, G, args.kernel, 0, steps, kus, stream.cuda_stream)
+        k_us_hot = float(np.mean(np.asarray(kus[:])[min(5, steps - 1):])) if rc == 0 else None
+
+        flops, nbytes = oracle.algorithmic_flops(M, K, N), oracle.algorithmic_bytes(M, K, N, G)
+        ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if flops / nbytes < ridge:
+            roof = {"bound": "hbm", "achieved": nbytes / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        else:
+            roof = {"bound": "mfma", "achieved": flops / (k_us * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof.update({"kernel_us": k_us, "kernel_us_cache_resident": k_us_hot, "algorithmic_bytes": nbytes, "flops": flops})
+        return {"M": M, "ms_per_step": ms_step, "tops": flops / (ms_step * 1e-3) / 1e12, "tops_kernel_only": flops / (k_us * 1e-6) / 1e12,
+                "launch": mode, "roofline": roof}, y
+
+    results = {}
+    y_head = None
+    for M in Ms:
+        steps = args.steps
+        res, y = measure(M, steps, args.warmup)
+        results[M] = res
+        if M == args.M:
+            y_head = y.clone()
+        if rank == 0:
+            r = res["roofline"]
+            log(f"M={M:4d}  step {res['ms_per_step'] * 1e3:8.2f} us  kernel {r['kernel_us']:8.2f} us (cache-resident "
+                f"{r['kernel_us_cache_resident']:.2f})  {res['tops']:8.2f} TOPS  roofline[{r['bound']}] {r['achieved']:.1f} {r['unit']} = {r['frac'] * 100:.1f}%")
+
+    head = results[args.M]
+    out = {
+        "metric": "w4a16_gemm_tops", "value": head["tops"] * world, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"W4A16 GEMM M={args.M} K={K} N={N} group_size={G} (BASELINE.json configs[1])", "M": args.M, "K": K, "N": N,
+                   "group_size": G, "weight_sets_cycled": n_sets, "weight_set_bytes": set_bytes, "launch": head["launch"],
+                   "parallelism": "replicas only" if world > 1 else "single GPU"},
+        "roofline": head["roofline"],
+        "sweep": [results[m] for m in Ms],
+    }
+
+    # ---- the reference's CPU path on the host cores, bounded sample, rank 0 / N=1 only
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        from oracle import cpu_path
+        qw_g, qz_g = cpu_path.pack_gemm_format(iw, z)
+        qw_t, qz_t, s_t = torch.from_numpy(qw_g), torch.from_numpy(qz_g), torch.from_numpy(s)
+        x_t = torch.from_numpy(x_np[:args.M])
+        y_cpu = cpu_path.forward(x_t, qw_t, qz_t, s_t, G)          # untimed first call (page-in, thread pool)
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t0 < args.cpu_seconds and reps < 1000):
+            y_cpu = cpu_path.forward(x_t, qw_t, qz_t, s_t, G)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        out["cpu_baseline"] = {
+            "value": oracle.algorithmic_flops(args.M, K, N) / dt / 1e12, "unit": "TFLOP/s", "cores": torch.get_num_threads(),
+            "kind": "port", "ms_per_call": dt * 1e3,
+            "sample": f"{reps} calls of the reference CPU path (dequantize_gemm + torch.matmul, dequant redone per call) at M={args.M} "
+                      f"K={K} N={N} g={G}, {reps * dt:.1f} s on {torch.get_num_threads()} torch threads",
+        }
+        # the GPU result of the headline step's set 0 against the CPU baseline's output (same inputs)
+        qw, sc, qz = sets[0]
+        from quick_amd import gemm_forward
+        y_gpu = gemm_forward(x_full[:args.M].contiguous(), qw, sc, qz, kernel_id=args.kernel).float().cpu()
+        out["parity_rel_err_vs_cpu_baseline"] = float((y_gpu - y_cpu.float()).abs().max() / y_cpu.float().abs().max())
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

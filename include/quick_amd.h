@@ -1,0 +1,120 @@
+/*
+ * quick_amd.h -- C ABI of libquick_amd.so: the MI355X (gfx950) W4A16 GEMM behind the
+ * SqueezeBits/QUICK operator `quick_kernels.gemm_forward_cuda_quick`.
+ *
+ * Plain pointers and sizes only: no torch types, no C++ in the signatures.  All pointers are
+ * DEVICE pointers unless stated otherwise; `hip_stream` is a hipStream_t passed as void*
+ * (NULL = the null stream).  Every entry point is asynchronous with respect to the host and
+ * returns a status code; the text of the last error on the calling thread is available through
+ * quick_amd_last_error().
+ *
+ * Reference interfaces replaced (paths relative to the reference repository root):
+ *   quick_w4a16_gemm_f16          <- torch::Tensor gemm_forward_cuda_quick(Tensor, Tensor, Tensor,
+ *                                    Tensor, int)           csrc/gemm_cuda_quick.h:3-8,
+ *                                    host function          csrc/gemm_cuda_quick.cu:1456-1517,
+ *                                    exported by            csrc/pybind.cpp:5-8
+ *   quick_w4a16_workspace_bytes   <- the `torch::empty({split_k_iters, M, N})` scratch
+ *                                                            csrc/gemm_cuda_quick.cu:1468
+ *   quick_repack_cuda_to_mi355x   <- the offline interleave of WQLinear_QUICK.from_linear
+ *   quick_repack_mi355x_to_cuda      quick/awq/modules/linear/quick.py:88-150 (format bridge:
+ *                                    the reference's packed order <-> the MFMA-fragment order)
+ */
+#ifndef QUICK_AMD_H
+#define QUICK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QUICK_AMD_ABI_VERSION 1
+
+/* status codes */
+#define QUICK_OK 0
+#define QUICK_ERR_INVALID_ARGUMENT 1 /* shape rule violated: the reference throws std::invalid_argument
+                                        (csrc/gemm_cuda_quick.cu:1479-1484) -> Python ValueError */
+#define QUICK_ERR_WORKSPACE 2        /* workspace missing or too small */
+#define QUICK_ERR_LAUNCH 3           /* HIP launch error */
+#define QUICK_ERR_UNSUPPORTED 4      /* valid for the reference but outside this library's envelope */
+
+/* kernel selection for quick_w4a16_gemm_f16_ex (tests / bench); 0 = library heuristic */
+#define QUICK_KERNEL_AUTO 0
+#define QUICK_KERNEL_SKINNY 1 /* M-tiles straight from L2 to VGPRs, k split over the waves of a workgroup */
+#define QUICK_KERNEL_TILED 2  /* activations staged through LDS, MFMA-bound regime */
+
+int quick_amd_abi_version(void);
+const char* quick_amd_last_error(void);
+
+/*
+ * y[M, N] (fp16, row-major) = x[M, K] (fp16, row-major, contiguous) @ dequant(qweight, scales, qzeros)
+ *
+ *   qweight  int32 [K/4, N/2]   4-bit weights, MI355X order (DESIGN.md "Data layout")
+ *   scales   fp16  [K/G, 2N]    scales[g, n] in columns 0..N-1
+ *   qzeros   int32 [K/G, N/4]   zero point of (g, n) = nibble n%8 of dword n/8 of row g
+ *
+ * Dequantised weight = fp16((w - z) * s) exactly as the reference computes it
+ * (csrc/dequantize_quick.cuh:15-63 + sub/mul.rn.f16x2 in csrc/gemm_cuda_quick.cu:52-60);
+ * accumulation in fp32, one rounding to fp16 at the end.
+ *
+ * split_k_iters keeps the reference's argument (number of K slices, >= 1).  The reference uses it
+ * as a tuning knob for NVIDIA parts; here it is validated and otherwise treated as a hint -- the
+ * library picks its own K partitioning and always returns the fully reduced [M, N] result.
+ *
+ * Errors (mirroring csrc/gemm_cuda_quick.cu:1479-1484): N % 128 != 0 or N % 8 != 0 or
+ * G % 32 != 0 -> QUICK_ERR_INVALID_ARGUMENT.  Additional envelope of this library:
+ * K % 128 == 0 and K % G == 0 (every shape in BASELINE.json satisfies it) -> else QUICK_ERR_UNSUPPORTED.
+ *
+ * workspace: device scratch of at least quick_w4a16_workspace_bytes(...) bytes (may be NULL when
+ * that function returns 0).  It must stay valid until the work enqueued on `hip_stream` completes.
+ */
+int quick_w4a16_gemm_f16(const void* x, const void* qweight, const void* scales, const void* qzeros,
+                         void* y, void* workspace, size_t workspace_bytes,
+                         int M, int K, int N, int group_size, int split_k_iters, void* hip_stream);
+
+size_t quick_w4a16_workspace_bytes(int M, int K, int N, int group_size, int split_k_iters);
+
+/* Same as quick_w4a16_gemm_f16 with an explicit kernel choice (QUICK_KERNEL_*), an optional fp16
+ * bias[N] added in the epilogue (NULL = none; replaces the separate torch add of
+ * quick/awq/modules/linear/quick.py:165), and a forced K split across workgroups (0 = heuristic). */
+int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scales, const void* qzeros,
+                            const void* bias, void* y, void* workspace, size_t workspace_bytes,
+                            int M, int K, int N, int group_size, int kernel, int grid_split_k,
+                            void* hip_stream);
+size_t quick_w4a16_workspace_bytes_ex(int M, int K, int N, int group_size, int kernel, int grid_split_k);
+
+/*
+ * Measurement aid (bench.py): enqueue the GEMM `iters` times on `hip_stream`, cycling through `n_sets`
+ * weight sets (host arrays of device pointers) so that consecutive launches do not hit in the 256 MiB
+ * Infinity Cache, with a hipEvent pair bound to each main-kernel dispatch (hipExtLaunchKernelGGL);
+ * synchronise, and write each dispatch's own duration in microseconds to the HOST array
+ * kernel_us[iters].  Blocking; not part of the reference interface.
+ */
+int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const void* const* scales,
+                             const void* const* qzeros, int n_sets, void* y, void* workspace,
+                             size_t workspace_bytes, int M, int K, int N, int group_size, int kernel,
+                             int grid_split_k, int iters, float* kernel_us, void* hip_stream);
+
+/*
+ * Format bridge.  "cuda order" is byte-for-byte what the reference's WQLinear_QUICK.from_linear
+ * writes (quick/awq/modules/linear/quick.py:88-150) and what its checkpoints hold; "mi355x order"
+ * is what quick_w4a16_gemm_f16 consumes.  All six buffers have the reference's shapes; in and out
+ * must not alias.
+ */
+int quick_repack_cuda_to_mi355x(const void* qweight_in, const void* scales_in, const void* qzeros_in,
+                                void* qweight_out, void* scales_out, void* qzeros_out,
+                                int K, int N, int group_size, void* hip_stream);
+int quick_repack_mi355x_to_cuda(const void* qweight_in, const void* scales_in, const void* qzeros_in,
+                                void* qweight_out, void* scales_out, void* qzeros_out,
+                                int K, int N, int group_size, void* hip_stream);
+
+/* Dequantise an MI355X-order layer to a dense fp16 [K, N] row-major matrix (debug / parity aid;
+ * counterpart of the reference CPU path quick/awq/utils/packing_utils.py:82-97). */
+int quick_dequantize_mi355x_f16(const void* qweight, const void* scales, const void* qzeros,
+                                void* w_out, int K, int N, int group_size, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUICK_AMD_H */

@@ -1,0 +1,45 @@
+"""ctypes binding of libquick_amd.so (include/quick_amd.h).  Fails loudly: there is no fallback."""
+import ctypes
+import os
+
+from .build import LIB
+
+_P, _I, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+_SIGNATURES = {
+    "quick_amd_abi_version": (_I, []),
+    "quick_amd_last_error": (ctypes.c_char_p, []),
+    "quick_w4a16_gemm_f16": (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    "quick_w4a16_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "quick_w4a16_gemm_f16_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
+    "quick_w4a16_workspace_bytes_ex": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "quick_w4a16_gemm_profile": (_I, [_P, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "quick_repack_cuda_to_mi355x": (_I, [_P] * 6 + [_I, _I, _I, _P]),
+    "quick_repack_mi355x_to_cuda": (_I, [_P] * 6 + [_I, _I, _I, _P]),
+    "quick_dequantize_mi355x_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load the in-tree shared object; raise if it is missing (build it with `python -m quick_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise ImportError(
+                f"{LIB} is missing: the HIP extension has not been built. "
+                "Run `python -m quick_amd.build` (needs hipcc); there is no CPU fallback for the W4A16 GEMM.")
+        lib = ctypes.CDLL(LIB)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if lib.quick_amd_abi_version() != 1:
+            raise ImportError("libquick_amd.so ABI version mismatch; rebuild with `python -m quick_amd.build --force`")
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().quick_amd_last_error().decode()

@@ -1,0 +1,75 @@
+// Shared device helpers for the gfx950 W4A16 kernels.  CDNA4 only: 64-lane wavefronts,
+// v_mfma_f32_16x16x32_f16, packed-f16 VALU.  No other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace quick_amd {
+
+typedef _Float16 half_t;
+typedef half_t half2_t __attribute__((ext_vector_type(2)));
+typedef half_t half4_t __attribute__((ext_vector_type(4)));
+typedef half_t half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define QA_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define QA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ half2_t as_h2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
+__device__ __forceinline__ uint32_t as_u32(half2_t h) { return __builtin_bit_cast(uint32_t, h); }
+
+// (a & mask) | orv in ONE VALU op.  gfx950 VOP3 takes no literals, so hipcc splits the C expression
+// into v_and + v_or (two literal-carrying VOP2s); feeding the mask from an SGPR and the magic
+// number from a VGPR lets v_and_or_b32 encode.  The AMD counterpart of the `lop3` in the
+// reference's dequantize_s4_to_fp16x2_fused (csrc/dequantize_quick.cuh:37-51).
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t orv) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(orv));
+  return r;
+}
+
+// Per-(group, output channel) dequantisation constants held by a lane.
+struct GroupQ {
+  half2_t s2;    // (s, s)
+  half2_t nzlo;  // -(1024 + z) twice: subtracts the magic bias and the zero point exactly
+  half2_t nzhi;  // -(64 + z) twice: same for the nibbles read 16x too large
+};
+
+__device__ __forceinline__ GroupQ make_group(half_t s, uint32_t z /*0..15*/) {
+  GroupQ g;
+  g.s2 = half2_t{s, s};
+  const uint32_t zz = z | (z << 16);
+  g.nzlo = as_h2(0xE400E400u | zz);         // fp16 bits of -(1024 + z): 0xE400 | z
+  g.nzhi = as_h2(0xD400D400u | (zz << 4));  // fp16 bits of -(64 + z):   0xD400 | z << 4
+  return g;
+}
+
+// One packed dword (8 weights of one output channel, 8 consecutive k, MI355X nibble order
+// p = 4*(j%2) + j/2) -> the v_mfma_f32_16x16x32_f16 A-operand fragment of this lane.
+// Every weight is fp16((w - z) * s): (1024+w) - (1024+z) and (1024+16w)/16 - (64+z) are exact in
+// fp16, the multiply by s rounds once -- bit-identical to the reference's sub.f16x2 + mul.rn.f16x2
+// (csrc/gemm_cuda_quick.cu:52-60).  13 VALU ops: 1 shift, 4 and_or, 2 pk_add, 2 pk_fma, 4 pk_mul.
+__device__ __forceinline__ half8_t dequant8(uint32_t q, const GroupQ& g) {
+  const uint32_t magic = 0x64006400u;  // fp16 1024.0 twice
+  const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
+  const uint32_t q8 = q >> 8;
+  const half2_t h0 = (as_h2(and_or(q, 0x000f000fu, magic)) + g.nzlo) * g.s2;               // k0, k1
+  const half2_t h1 = (as_h2(and_or(q, 0x00f000f0u, magic)) * sixteenth + g.nzhi) * g.s2;   // k2, k3
+  const half2_t h2 = (as_h2(and_or(q8, 0x000f000fu, magic)) + g.nzlo) * g.s2;              // k4, k5
+  const half2_t h3 = (as_h2(and_or(q8, 0x00f000f0u, magic)) * sixteenth + g.nzhi) * g.s2;  // k6, k7
+  half8_t r;
+  r[0] = h0[0]; r[1] = h0[1]; r[2] = h1[0]; r[3] = h1[1];
+  r[4] = h2[0]; r[5] = h2[1]; r[6] = h3[0]; r[7] = h3[1];
+  return r;
+}
+
+__device__ __forceinline__ floatx4 mfma16(half8_t a, half8_t b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// wave-uniform values the compiler cannot prove uniform (anything derived from threadIdx)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+}  // namespace quick_amd

@@ -1,0 +1,118 @@
+"""Python face of libquick_amd.so: the functions the reference's ``quick_kernels`` extension exports
+(csrc/pybind.cpp:5-8), plus the format bridge.  Device pointers and the current HIP stream come from
+torch; the arithmetic is entirely in the HIP library -- there is no CPU / eager fallback.
+"""
+import torch
+
+from . import _lib
+
+KERNEL_AUTO, KERNEL_SKINNY, KERNEL_TILED = 0, 1, 2
+_OK, _INVALID, _WORKSPACE, _LAUNCH, _UNSUPPORTED = 0, 1, 2, 3, 4
+
+
+def _raise(rc):
+    msg = _lib.last_error() or f"libquick_amd error {rc}"
+    if rc == _INVALID:
+        raise ValueError(msg)          # std::invalid_argument in the reference (gemm_cuda_quick.cu:1479-1484)
+    if rc == _UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
+
+
+def _expect(t, dtype, name):
+    if t.dtype != dtype:               # data_ptr<T>() throws c10::Error -> RuntimeError in the reference
+        raise RuntimeError(f"expected scalar type {dtype} for {name} but found {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor: the W4A16 GEMM has no CPU implementation")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=KERNEL_AUTO, grid_split_k=0):
+    """y [M, N] fp16 = in_feats [M, K] @ dequant(kernel, scaling_factors, zeros) (+ bias), MI355X-order weights."""
+    _expect(in_feats, torch.float16, "in_feats")
+    _expect(kernel, torch.int32, "kernel")
+    _expect(scaling_factors, torch.float16, "scaling_factors")
+    _expect(zeros, torch.int32, "zeros")
+    if in_feats.dim() != 2:
+        raise RuntimeError("in_feats must be 2-D [M, K]")
+    lib = _lib.load()
+    M, K = in_feats.shape
+    N = kernel.shape[1] // 4 * 8                      # gemm_cuda_quick.cu:1468
+    if kernel.shape[0] * 4 != K:
+        raise ValueError(f"kernel has {kernel.shape[0] * 4} input channels, in_feats has {K}")
+    G = K // scaling_factors.shape[0]                 # gemm_cuda_quick.cu:1477
+    out = torch.empty((M, N), dtype=torch.float16, device=in_feats.device)
+    if M == 0:
+        return out
+    with torch.cuda.device(in_feats.device):          # OptionalCUDAGuard, gemm_cuda_quick.cu:1465
+        ws_bytes = lib.quick_w4a16_workspace_bytes_ex(M, K, N, G, kernel_id, grid_split_k)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=in_feats.device) if ws_bytes else None
+        rc = lib.quick_w4a16_gemm_f16_ex(
+            in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
+            bias.data_ptr() if bias is not None else None, out.data_ptr(),
+            ws.data_ptr() if ws is not None else None, ws_bytes, M, K, N, G, kernel_id, grid_split_k, _stream())
+    if rc != _OK:
+        _raise(rc)
+    return out
+
+
+def gemm_forward_cuda_quick(in_feats, kernel, scaling_factors, zeros, split_k_iters):
+    """Drop-in for ``quick_kernels.gemm_forward_cuda_quick`` (csrc/gemm_cuda_quick.h:3-8).
+
+    Same arguments, dtypes and error behaviour; ``kernel`` / ``scaling_factors`` / ``zeros`` are the
+    module buffers in MI355X order (what ``WQLinear_QUICK`` holds after ``prepare()``).  Return shape
+    follows the reference: ``[M, N]`` when ``split_k_iters > 1`` (its ``.sum(0)``), ``[1, M, N]`` otherwise
+    (gemm_cuda_quick.cu:1515-1516).  ``split_k_iters`` is a tuning hint for NVIDIA parts; this library
+    chooses its own K partitioning and always returns the fully reduced result.
+    """
+    if split_k_iters < 1:
+        raise ValueError("split_k_iters must be >= 1")
+    out = gemm_forward(in_feats, kernel, scaling_factors, zeros)
+    return out if split_k_iters > 1 else out.unsqueeze(0)
+
+
+def _repack(fn_name, qweight, scales, qzeros):
+    for t, d, nm in ((qweight, torch.int32, "qweight"), (scales, torch.float16, "scales"), (qzeros, torch.int32, "qzeros")):
+        _expect(t, d, nm)
+    lib = _lib.load()
+    K, N = qweight.shape[0] * 4, qweight.shape[1] * 2
+    G = K // scales.shape[0]
+    outs = [torch.empty_like(qweight), torch.empty_like(scales), torch.empty_like(qzeros)]
+    with torch.cuda.device(qweight.device):
+        rc = getattr(lib, fn_name)(qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
+                                   outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), K, N, G, _stream())
+    if rc != _OK:
+        if rc == _INVALID:
+            raise ValueError(f"{fn_name}: invalid shape K={K} N={N} G={G}")
+        if rc == _UNSUPPORTED:
+            raise NotImplementedError(f"{fn_name}: in_features ({K}) must be a multiple of 128 on MI355X")
+        raise RuntimeError(f"{fn_name} failed ({rc})")
+    return tuple(outs)
+
+
+def repack_cuda_to_mi355x(qweight, scales, qzeros):
+    """Reference-order packed tensors (a QUICK checkpoint) -> MI355X order, on the GPU."""
+    return _repack("quick_repack_cuda_to_mi355x", qweight, scales, qzeros)
+
+
+def repack_mi355x_to_cuda(qweight, scales, qzeros):
+    return _repack("quick_repack_mi355x_to_cuda", qweight, scales, qzeros)
+
+
+def dequantize_mi355x(qweight, scales, qzeros):
+    """Dense fp16 [K, N] = fp16((w - z) * s) from MI355X-order tensors (parity aid)."""
+    lib = _lib.load()
+    K, N = qweight.shape[0] * 4, qweight.shape[1] * 2
+    G = K // scales.shape[0]
+    out = torch.empty((K, N), dtype=torch.float16, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        rc = lib.quick_dequantize_mi355x_f16(qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), out.data_ptr(),
+                                             K, N, G, _stream())
+    if rc != _OK:
+        _raise(rc)
+    return out

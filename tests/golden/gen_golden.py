@@ -109,6 +109,7 @@ def main():
             x=x.numpy(),
             ref_qweight=ql.qweight.numpy(), ref_qscales=ql.scales.numpy(), ref_qzeros=ql.qzeros.numpy(),
             ref_wdeq=wdeq.numpy(), ref_y=y.numpy(),
+            ref_gemm_qweight=gl.qweight.numpy(), ref_gemm_qzeros=gl.qzeros.numpy(), ref_gemm_scales=gl.scales.numpy(),
         )
         print("wrote", name, tuple(ql.qweight.shape), tuple(ql.scales.shape), tuple(ql.qzeros.shape))
 

@@ -1,0 +1,236 @@
+"""Parity of the HIP W4A16 path (through the C ABI) against the CPU oracle.  Needs an MI355X.
+
+Tolerance: the north star asks for <= 1e-2 relative error against CPU dequantize + matmul; the HIP path
+accumulates in fp32 with one final rounding, so the tests hold it to 2e-3 (only summation order differs)
+and to bit-exactness wherever the result is order-independent (dequantised weights, one-hot probes,
+power-of-two scaling).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import golden_files, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-3
+SKINNY, TILED = 1, 2
+
+
+def _dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _pack_dev(iw, s, z, device):
+    return [_dev(a, device) for a in oracle.pack_mi355x(iw, s, z)]
+
+
+@pytest.fixture(scope="module")
+def qa(device):
+    import quick_amd
+    from quick_amd import _lib
+    _lib.load()          # fail loudly if the HIP extension is not built
+    return quick_amd
+
+
+# ------------------------------------------------------------------------------------------------
+# golden fixtures produced by the reference's own Python
+# ------------------------------------------------------------------------------------------------
+GOLD = [p for p in golden_files("exact_") if "k64" not in p] + golden_files("quant_")
+
+
+@pytest.mark.parametrize("kernel_id,ksplit", [(0, 0), (SKINNY, 1), (SKINNY, 2), (TILED, 1), (TILED, 2)])
+@pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_fixture_forward(qa, device, path, kernel_id, ksplit):
+    g = load_golden(path)
+    # reference-format checkpoint -> GPU -> HIP repack -> HIP GEMM
+    qw, qs, qz = qa.repack_cuda_to_mi355x(_dev(g["ref_qweight"], device), _dev(g["ref_qscales"], device), _dev(g["ref_qzeros"], device))
+    y = qa.gemm_forward(_dev(g["x"], device), qw, qs, qz, kernel_id=kernel_id, grid_split_k=ksplit)
+    assert y.dtype == torch.float16 and tuple(y.shape) == g["ref_y"].shape
+    assert rel_err(y.cpu().numpy(), g["ref_y"]) <= TOL
+
+
+@pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_dequant_bit_exact_and_repack_roundtrip(qa, device, path):
+    g = load_golden(path)
+    ref = [_dev(g[k], device) for k in ("ref_qweight", "ref_qscales", "ref_qzeros")]
+    mi = qa.repack_cuda_to_mi355x(*ref)
+    want = oracle.pack_mi355x(*oracle.unpack_cuda_order(g["ref_qweight"], g["ref_qscales"], g["ref_qzeros"]))
+    for a, b in zip(mi, want):
+        assert np.array_equal(a.cpu().numpy().view(np.uint8), b.view(np.uint8))
+    back = qa.repack_mi355x_to_cuda(*mi)
+    for a, b in zip(back, ref):
+        assert torch.equal(a, b)
+    wdeq = qa.dequantize_mi355x(*mi)
+    assert np.array_equal(wdeq.cpu().numpy().view(np.uint16), g["ref_wdeq"].view(np.uint16))
+
+
+@pytest.mark.parametrize("path", GOLD[:3], ids=lambda p: os.path.basename(p)[:-4])
+def test_module_forward_from_reference_checkpoint(qa, device, path):
+    g = load_golden(path)
+    K, N, G = int(g["K"]), int(g["N"]), int(g["G"])
+    m = qa.WQLinear_QUICK(4, G, K, N, True, "cpu")
+    sd = {"qweight": torch.from_numpy(g["ref_qweight"]), "scales": torch.from_numpy(g["ref_qscales"]),
+          "qzeros": torch.from_numpy(g["ref_qzeros"]), "bias": torch.linspace(-1, 1, N).half()}
+    m.load_state_dict(sd)
+    m = m.to(device)
+    assert not m.is_prepared
+    x = _dev(g["x"], device)
+    y = m(x.reshape(1, *x.shape))                       # 3-D input, like hidden states
+    assert m.is_prepared and tuple(y.shape) == (1, x.shape[0], N)
+    want = (g["ref_y"].astype(np.float32) + sd["bias"].numpy().astype(np.float32))
+    assert rel_err(y[0].cpu().numpy(), want) <= TOL
+    sd2 = m.state_dict()                                # and it still saves the reference's format
+    assert np.array_equal(sd2["qweight"].cpu().numpy(), g["ref_qweight"])
+    assert np.array_equal(sd2["qzeros"].cpu().numpy(), g["ref_qzeros"])
+    assert np.array_equal(sd2["scales"].cpu().numpy().view(np.uint16), g["ref_qscales"].view(np.uint16))
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded synthetic sweeps against the oracle
+# ------------------------------------------------------------------------------------------------
+SHAPES = [  # (M, K, N, G)
+    (1, 128, 128, 128), (1, 512, 256, 128), (2, 512, 256, 32), (7, 1024, 384, 64), (8, 1024, 128, 128),
+    (16, 2048, 256, 128), (17, 512, 256, 128), (31, 1024, 384, 128), (33, 512, 128, 64), (64, 1024, 256, 128),
+    (65, 512, 256, 128), (100, 640, 384, 32), (128, 1024, 256, 128), (129, 256, 128, 128), (200, 512, 640, 128),
+    (300, 384, 256, 128), (3, 1024, 256, 1024), (40, 512, 256, 256),
+]
+
+
+@pytest.mark.parametrize("kernel_id", [0, SKINNY, TILED])
+@pytest.mark.parametrize("M,K,N,G", SHAPES)
+def test_synthetic_sweep(qa, device, M, K, N, G, kernel_id):
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M * 7 + K + N + G)
+    want = oracle.w4a16_forward(x, iw, s, z, G)
+    y = qa.gemm_forward(_dev(x, device), *_pack_dev(iw, s, z, device), kernel_id=kernel_id)
+    assert rel_err(y.cpu().numpy(), want) <= TOL
+
+
+@pytest.mark.parametrize("ksplit", [2, 3, 8])
+@pytest.mark.parametrize("kernel_id", [SKINNY, TILED])
+def test_grid_split_k_and_bias(qa, device, kernel_id, ksplit):
+    M, K, N, G = 24, 2048, 256, 128
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=99)
+    bias = np.linspace(-2, 2, N).astype(np.float16)
+    want = oracle.w4a16_forward(x, iw, s, z, G).astype(np.float32) + bias.astype(np.float32)
+    y = qa.gemm_forward(_dev(x, device), *_pack_dev(iw, s, z, device), bias=_dev(bias, device), kernel_id=kernel_id,
+                        grid_split_k=ksplit)
+    assert rel_err(y.cpu().numpy(), want) <= TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json sizes: K = N = 4096, G = 128, M in {1, 8, 64, 512}
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full(qa, device):
+    K = N = 4096
+    G = 128
+    x, iw, s, z = oracle.make_synthetic(512, K, N, G, seed=0)
+    wdeq = oracle.dequantize(iw, s, z, G)
+    return dict(K=K, N=N, G=G, x=x, wdeq=wdeq, packed=_pack_dev(iw, s, z, device))
+
+
+@pytest.mark.parametrize("M", [1, 8, 64, 512])
+def test_baseline_shapes_against_oracle(qa, device, full, M):
+    x = full["x"][:M]
+    want = oracle.gemm_fp32acc(x, full["wdeq"])
+    y = qa.gemm_forward(_dev(x, device), *full["packed"])
+    err = rel_err(y.cpu().numpy(), want)
+    assert err <= TOL, err
+
+
+@pytest.mark.parametrize("M", [1, 8, 64, 512])
+def test_baseline_one_hot_rows_reproduce_dequantised_weights_bit_exactly(qa, device, full, M):
+    # x = e_k  =>  y = W_deq[k, :] with nothing to round: exercises unpack order, zero point, scale, MFMA
+    # operand layout and the epilogue at full size, independent of summation order.
+    K = full["K"]
+    ks = (np.arange(M) * 2654435761 % K).astype(np.int64)
+    x = np.zeros((M, K), dtype=np.float16)
+    x[np.arange(M), ks] = 1.0
+    y = qa.gemm_forward(_dev(x, device), *full["packed"]).cpu().numpy()
+    assert np.array_equal(y, full["wdeq"][ks])        # float compare: exact values, -0 == +0
+
+
+@pytest.mark.parametrize("M", [1, 64, 512])
+def test_baseline_power_of_two_scaling_is_exact(qa, device, full, M):
+    x = _dev(full["x"][:M], device)
+    y1 = qa.gemm_forward(x, *full["packed"])
+    y2 = qa.gemm_forward(x * 2, *full["packed"])
+    assert torch.equal(y2, y1 * 2)
+    assert torch.equal(qa.gemm_forward(torch.zeros_like(x), *full["packed"]), torch.zeros_like(y1))
+
+
+def test_baseline_rows_are_independent_of_batch(qa, device, full):
+    # the M=1 (skinny) and M=512 (tiled) kernels must agree on the same row up to summation order
+    x = _dev(full["x"], device)
+    y512 = qa.gemm_forward(x, *full["packed"])
+    for r in (0, 255, 511):
+        y1 = qa.gemm_forward(x[r:r + 1].contiguous(), *full["packed"])
+        assert rel_err(y1.cpu().numpy(), y512[r:r + 1].cpu().numpy()) <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# model shapes of the e2e configs, small M
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,N", [(4096, 12288), (4096, 11008), (11008, 4096), (14336, 4096), (4096, 1024), (8192, 1024)])
+@pytest.mark.parametrize("M", [1, 16, 64])
+def test_model_shapes(qa, device, K, N, M):
+    if N % 128 != 0:
+        pytest.skip("N not a multiple of 128")
+    G = 128
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=K + N + M)
+    want = oracle.w4a16_forward(x, iw, s, z, G)
+    y = qa.gemm_forward(_dev(x, device), *_pack_dev(iw, s, z, device))
+    assert rel_err(y.cpu().numpy(), want) <= TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# operator interface and error behaviour (csrc/gemm_cuda_quick.cu:1456-1517)
+# ------------------------------------------------------------------------------------------------
+def test_reference_operator_signature_and_errors(qa, device):
+    import quick_kernels
+    M, K, N, G = 5, 256, 128, 128
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=3)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device)
+    want = oracle.w4a16_forward(x, iw, s, z, G)
+    y8 = quick_kernels.gemm_forward_cuda_quick(xd, *packed, 8)
+    y1 = quick_kernels.gemm_forward_cuda_quick(xd, *packed, 1)
+    assert tuple(y8.shape) == (M, N) and tuple(y1.shape) == (1, M, N)        # gemm_cuda_quick.cu:1515-1516
+    assert rel_err(y8.cpu().numpy(), want) <= TOL and torch.equal(y1[0], y8)
+    with pytest.raises(RuntimeError):                                          # data_ptr<at::Half>() on a float tensor
+        quick_kernels.gemm_forward_cuda_quick(xd.float(), *packed, 8)
+    with pytest.raises(RuntimeError):
+        quick_kernels.gemm_forward_cuda_quick(xd, packed[0].float(), packed[1], packed[2], 8)
+    bad_n = [torch.zeros(K // 4, 96 // 2, dtype=torch.int32, device=device), torch.zeros(K // G, 192, dtype=torch.float16, device=device),
+             torch.zeros(K // G, 24, dtype=torch.int32, device=device)]
+    with pytest.raises(ValueError, match="cta_N"):                             # std::invalid_argument, line 1479
+        quick_kernels.gemm_forward_cuda_quick(xd, *bad_n, 8)
+    bad_g = [packed[0], torch.zeros(K // 16, 2 * N, dtype=torch.float16, device=device), torch.zeros(K // 16, N // 4, dtype=torch.int32, device=device)]
+    with pytest.raises(ValueError, match="multiple of 32"):                    # line 1483
+        quick_kernels.gemm_forward_cuda_quick(xd, *bad_g, 8)
+    assert tuple(qa.gemm_forward(xd[:0], *packed).shape) == (0, N)            # empty batch
+
+
+def test_runs_on_current_stream_and_is_graph_capturable(qa, device):
+    M, K, N, G = 4, 512, 256, 128
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=8)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device)
+    want = oracle.w4a16_forward(x, iw, s, z, G)
+    side = torch.cuda.Stream(device)
+    with torch.cuda.stream(side):
+        y = qa.gemm_forward(xd, *packed)
+    side.synchronize()
+    assert rel_err(y.cpu().numpy(), want) <= TOL
+    g = torch.cuda.CUDAGraph()
+    static_x = xd.clone()
+    with torch.cuda.graph(g):
+        static_y = qa.gemm_forward(static_x, *packed)
+    static_x.copy_(xd * 2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert rel_err(static_y.cpu().numpy(), want.astype(np.float32) * 2) <= TOL

@@ -1,0 +1,144 @@
+"""WQLinear_QUICK host logic and the C-ABI surface, no GPU needed."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import ROOT, golden_files, load_golden
+from quick_amd import WQLinear_QUICK, _lib, fuse_qkv_quick, packing
+from quick_amd.build import LIB
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _linear(w):
+    lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=False)
+    lin.weight.data = w.clone()
+    return lin.half()
+
+
+def _from_golden(g, **kw):
+    return WQLinear_QUICK.from_linear(_linear(_t(g["weight"])), 4, int(g["G"]), False, _t(g["scales_nk"]), _t(g["zeros_nk"]), **kw)
+
+
+def test_buffers_have_reference_shapes_and_names():
+    m = WQLinear_QUICK(4, 128, 4096, 11008, True, "cpu")
+    sd = m.state_dict()
+    assert list(sd) == ["qweight", "qzeros", "scales", "bias"]
+    assert sd["qweight"].shape == (1024, 5504) and sd["qweight"].dtype == torch.int32
+    assert sd["qzeros"].shape == (32, 2752) and sd["qzeros"].dtype == torch.int32
+    assert sd["scales"].shape == (32, 22016) and sd["scales"].dtype == torch.float16
+    assert sd["bias"].shape == (11008,) and sd["bias"].dtype == torch.float16
+    assert (m.k_split_1, m.k_split_2) == (2, 8)
+    with pytest.raises(NotImplementedError):
+        WQLinear_QUICK(8, 128, 256, 256, False, "cpu")
+    assert WQLinear_QUICK(4, -1, 256, 128, False, "cpu").group_size == 256
+    assert "w_bit=4" in m.extra_repr()
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files("exact_") if "k64" not in p] + golden_files("quant_"),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_from_linear_state_dict_is_reference_format(path):
+    g = load_golden(path)
+    m = _from_golden(g)
+    assert m.is_prepared                                    # in memory: MI355X order
+    want = oracle.pack_mi355x(*oracle.unpack_cuda_order(g["ref_qweight"], g["ref_qscales"], g["ref_qzeros"]))
+    for name, w in zip(("qweight", "scales", "qzeros"), want):
+        assert np.array_equal(getattr(m, name).numpy().view(np.uint8), w.view(np.uint8))
+    sd = m.state_dict()                                     # on disk: the reference's order, bit for bit
+    assert np.array_equal(sd["qweight"].numpy(), g["ref_qweight"])
+    assert np.array_equal(sd["scales"].numpy().view(np.uint16), g["ref_qscales"].view(np.uint16))
+    assert np.array_equal(sd["qzeros"].numpy(), g["ref_qzeros"])
+
+    # a fresh module loading that checkpoint is in reference order until prepared
+    m2 = WQLinear_QUICK.from_linear(_linear(_t(g["weight"])), 4, int(g["G"]), init_only=True)
+    assert not m2.is_prepared
+    m2.load_state_dict(sd)
+    assert not m2.is_prepared
+    m2.prepare()
+    assert m2.is_prepared
+    for name in ("qweight", "scales", "qzeros"):
+        assert torch.equal(getattr(m2, name), getattr(m, name))
+    # load_state_dict copies in place: the module must notice it holds reference order again
+    m2.load_state_dict(sd)
+    assert not m2.is_prepared
+    # moving / casting keeps the layout flag
+    m3 = _from_golden(g).to("cpu")
+    assert m3.is_prepared
+    # attribute assignment (what fuse_qkv_quick and accelerate do) resets it
+    m3.qweight = sd["qweight"].clone()
+    assert not m3.is_prepared
+
+
+def test_from_linear_k64_stays_in_checkpoint_format():
+    g = load_golden([p for p in golden_files("exact_") if "k64" in p][0])
+    m = _from_golden(g)
+    assert not m.is_prepared
+    assert np.array_equal(m.qweight.numpy(), g["ref_qweight"])
+    with pytest.raises(ValueError):
+        m.prepare()
+
+
+def test_fuse_qkv_unequal_widths_cpu():
+    rng = np.random.default_rng(11)
+    K, G = 256, 128
+    mods, logical = [], []
+    for N in (256, 128, 128):
+        iw = rng.integers(0, 16, (K, N), dtype=np.uint8)
+        z = rng.integers(0, 16, (K // G, N), dtype=np.uint8)
+        s = rng.uniform(0.005, 0.025, (K // G, N)).astype(np.float16)
+        m = WQLinear_QUICK(4, G, K, N, False, "cpu")
+        m._set_packed(*[_t(a) for a in oracle.pack_mi355x(iw, s, z)], prepared=True)
+        mods.append(m)
+        logical.append((iw, s, z))
+    fused = fuse_qkv_quick(None, *mods)
+    assert fused.out_features == 512 and not fused.is_prepared
+    full = oracle.pack_cuda_order(*[np.concatenate([l[i] for l in logical], axis=1) for i in range(3)])
+    for name, w in zip(("qweight", "scales", "qzeros"), full):
+        assert np.array_equal(getattr(fused, name).numpy().view(np.uint8), w.view(np.uint8))
+    fused.prepare()
+    iw2, s2, z2 = oracle.unpack_mi355x(fused.qweight.numpy(), fused.scales.numpy(), fused.qzeros.numpy())
+    assert np.array_equal(iw2, np.concatenate([l[0] for l in logical], axis=1))
+
+
+def test_forward_on_cpu_fails_loudly():
+    g = load_golden(golden_files("exact_k128n128")[0])
+    m = _from_golden(g)
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(_t(g["x"]))
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    assert os.path.exists(LIB), "build the library first: python -m quick_amd.build"
+    header = open(os.path.join(ROOT, "include", "quick_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(quick_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = ctypes.CDLL(LIB)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().quick_amd_abi_version() == 1
+    # argument validation runs before any GPU work
+    rc = _lib.load().quick_w4a16_gemm_f16(None, None, None, None, None, None, 0, 1, 256, 100, 128, 8, None)
+    assert rc == 1 and "cta_N" in _lib.last_error()
+    rc = _lib.load().quick_w4a16_gemm_f16(None, None, None, None, None, None, 0, 1, 256, 128, 48, 8, None)
+    assert rc == 1 and "multiple of 32" in _lib.last_error()
+    rc = _lib.load().quick_w4a16_gemm_f16(None, None, None, None, None, None, 0, 1, 192, 128, 64, 8, None)
+    assert rc == 4
+    assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 4096, 128, 8) == 0
+    assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 1024, 128, 8) == 1 * 1024 * 4
+
+
+def test_quick_kernels_shim_exports_reference_symbol():
+    import quick_kernels
+    assert callable(quick_kernels.gemm_forward_cuda_quick)
+    x = torch.zeros(1, 128, dtype=torch.float32)
+    with pytest.raises(RuntimeError, match="Half|float16"):
+        quick_kernels.gemm_forward_cuda_quick(x, torch.zeros(32, 64, dtype=torch.int32), torch.zeros(1, 256, dtype=torch.float16),
+                                              torch.zeros(1, 32, dtype=torch.int32), 8)

@@ -101,3 +101,19 @@ def test_algorithmic_counts_match_survey():
     assert oracle.algorithmic_bytes(64, 4096, 4096, 128) == 9_764_864
     assert oracle.algorithmic_bytes(512, 4096, 4096, 128) == 17_104_896
     assert oracle.algorithmic_flops(512, 4096, 4096) == 17_179_869_184
+
+
+@pytest.mark.parametrize("path", EXACT, ids=[os.path.basename(p)[:-4] for p in EXACT])
+def test_cpu_reference_path_restatement(path):
+    """oracle/cpu_path.py (the timed CPU baseline) against the reference's own GEMM-format pack and outputs."""
+    import torch
+    from oracle import cpu_path
+    g = load_golden(path)
+    iw, s, z, G = _logical(g)
+    qw, qz = cpu_path.pack_gemm_format(iw, z)
+    assert np.array_equal(qw, g["ref_gemm_qweight"]) and np.array_equal(qz, g["ref_gemm_qzeros"])
+    assert np.array_equal(s.view(np.uint16), g["ref_gemm_scales"].view(np.uint16))
+    w = cpu_path.dequantize_gemm(torch.from_numpy(qw), torch.from_numpy(qz), torch.from_numpy(s), G)
+    assert np.array_equal(w.numpy().view(np.uint16), g["ref_wdeq"].view(np.uint16))
+    y = cpu_path.forward(torch.from_numpy(g["x"]), torch.from_numpy(qw), torch.from_numpy(qz), torch.from_numpy(s), G)
+    assert rel_err(y.numpy(), g["ref_y"]) <= 2e-3      # same ops; host BLAS blocking may reorder the sums
