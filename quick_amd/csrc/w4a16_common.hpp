@@ -65,6 +65,59 @@ __device__ __forceinline__ half8_t dequant8(uint32_t q, const GroupQ& g) {
   return r;
 }
 
+// Raw group constants as they come out of memory; make_group() is applied at the point of use so that a
+// prefetch of the next k-tile's constants carries no dependent ALU work (which would make the compiler
+// wait for the whole in-order load queue right after issuing it).  Both are plain dword loads: the
+// scale dword holds the scales of channels (n & ~1, n | 1), the zero dword the nibbles of 8 channels.
+struct GroupRaw {
+  uint32_t s2;  // two fp16 scales, this lane's one selected by LaneSel::sperm
+  uint32_t zq;  // eight zero points, this lane's one selected by LaneSel::zshift
+};
+
+// lane constants that pick this lane's channel out of a GroupRaw
+struct LaneSel {
+  uint32_t sperm;   // v_perm_b32 selector replicating the low (even n) or high (odd n) half
+  uint32_t zshift;  // 4 * (n % 8)
+};
+__device__ __forceinline__ LaneSel lane_sel(int n) {
+  return LaneSel{(n & 1) ? 0x03020302u : 0x01000100u, 4u * (uint32_t)(n & 7)};
+}
+
+// group index of k-step t of 128-k tile kt.  GM: 0 -> G == 128, 1 -> G % 128 == 0 (tpg = G / 128),
+// 2 -> G == 64, 3 -> G == 32, 4 -> any other multiple of 32 (runtime division).
+template <int GM>
+__device__ __forceinline__ int group_index(int kt, int t, int tpg, int G) {
+  if constexpr (GM == 0) return kt;
+  else if constexpr (GM == 1) return kt / tpg;
+  else if constexpr (GM == 2) return kt * 2 + (t >> 1);
+  else if constexpr (GM == 3) return kt * 4 + t;
+  else return (kt * 128 + 32 * t) / G;
+}
+// distinct groups touched by one 128-k tile
+template <int GM>
+constexpr int groups_per_tile() { return GM <= 1 ? 1 : (GM == 2 ? 2 : 4); }
+template <int GM>
+__device__ __forceinline__ int group_slot(int t) { return GM <= 1 ? 0 : (GM == 2 ? (t >> 1) : t); }
+
+// scales[g, n] (fp16, row pitch 2N) and the zero-point dword of (g, n) (row pitch N/4 dwords).
+__device__ __forceinline__ GroupRaw load_group_raw(const half_t* __restrict__ S, const uint32_t* __restrict__ QZ,
+                                                   int g, int n, int N) {
+  GroupRaw r;
+  r.s2 = *(const uint32_t*)(S + (size_t)g * (2 * N) + (n & ~1));
+  r.zq = QZ[(size_t)g * (N >> 2) + (n >> 3)];
+  return r;
+}
+// 5 VALU: v_perm (scale pair), v_bfe (zero point), v_lshl_or (replicate), 2 v_or (bias constants)
+__device__ __forceinline__ GroupQ make_group(const GroupRaw& r, const LaneSel& ls) {
+  GroupQ g;
+  g.s2 = as_h2(__builtin_amdgcn_perm(r.s2, r.s2, ls.sperm));
+  const uint32_t z = __builtin_amdgcn_ubfe(r.zq, ls.zshift, 4u);
+  const uint32_t zz = z | (z << 16);
+  g.nzlo = as_h2(0xE400E400u | zz);
+  g.nzhi = as_h2(0xD400D400u | (zz << 4));
+  return g;
+}
+
 __device__ __forceinline__ floatx4 mfma16(half8_t a, half8_t b, floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }

@@ -9,8 +9,10 @@
 //     deliver the A fragments of 4 consecutive k-steps of v_mfma_f32_16x16x32_f16: dequantised
 //     weights go HBM -> VGPR -> matrix core, never through LDS (the QUICK idea, re-derived for the
 //     64-lane MFMA operand order instead of mma.sync/ldmatrix);
-//   * activations: straight L2 -> VGPR fragment loads when M is small (skinny kernel), staged
-//     through LDS in fragment order by global_load_lds when M is large (tiled kernel).
+//   * activations: skinny kernel (M <= 64) -- one 16-channel tile per workgroup, K split over the
+//     workgroup's waves, x either broadcast from an LDS copy (tiny M) or loaded as fragments straight
+//     from L2; tiled kernel (large M) -- 64 x 128 workgroup tile, x staged in LDS *in fragment order*
+//     by global_load_lds, 8 waves = 4 along N x 2 along K.
 #include "w4a16_common.hpp"
 #include "../../include/quick_amd.h"
 
@@ -24,110 +26,172 @@
 
 namespace quick_amd {
 
-// ------------------------------------------------------------------------------------------------
-// group constants
-// ------------------------------------------------------------------------------------------------
-// scales[g, n] (fp16, row pitch 2N) and the zero-point nibble of (g, n) (row pitch N/4 dwords).
-__device__ __forceinline__ GroupQ load_group(const half_t* __restrict__ S, const uint32_t* __restrict__ QZ,
-                                             int g, int n, int N) {
-  const half_t s = S[(size_t)g * (2 * N) + n];
-  const uint32_t zq = QZ[(size_t)g * (N >> 2) + (n >> 3)];
-  return make_group(s, (zq >> (4 * (n & 7))) & 15u);
-}
+struct GemmArgs {
+  const half_t* X;
+  const u32x4* QW;
+  const half_t* S;
+  const uint32_t* QZ;
+  const half_t* bias;
+  half_t* Y;
+  float* Yacc;  // fp32 accumulator when the grid splits K (ksplit > 1), else unused
+  int M, K, N, G;
+  int tpg;     // G / 128 (group mode 1)
+  int ksplit;  // K slices across workgroups
+  int kt_per_split;
+};
 
 // ------------------------------------------------------------------------------------------------
-// skinny kernel: one 16-channel tile per workgroup, K split over the waves of the workgroup
-// (and optionally over blockIdx.z), up to MT token tiles of 16 kept in registers.
+// skinny kernel: one 16-channel tile per workgroup, K split over the waves of the workgroup (and over
+// blockIdx.z when N is small), up to MT token tiles of 16 kept in registers.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int WAVES, bool G128, int U>
-__device__ __forceinline__ void skinny_body(int kt, const u32x4* __restrict__ wp, const half_t* const (&xp)[MT],
-                                            const half_t* __restrict__ S, const uint32_t* __restrict__ QZ,
-                                            int n, int N, int G, floatx4 (&acc)[MT]) {
+// Every wave walks its k-tiles in chunks of U.  A chunk is LOADED (weights 16 B/lane/tile straight from
+// HBM, raw group constants, and -- unless x sits in LDS -- the B fragments from L2) one chunk ahead of
+// being COMPUTED, into the other of two register sets; the sched_barriers keep hipcc from sinking the
+// loads next to their uses, which would serialise one HBM round trip per tile.
+//
+// XLDS: the workgroup first copies x[rows, kbegin:kend] into LDS with coalesced 16-byte loads (row pitch
+// padded by 16 B so the token rows of a fragment read spread over the bank groups) and every B fragment
+// is a ds_read_b128 -- for M == 1 a 4-address broadcast -- instead of a 64-lane global load fetching
+// 64 B per token row, 15/16 of them wasted when M == 1.
+template <int MT, int GM, int U, bool XLDS>
+struct SkinnyChunk {
   u32x4 w[U];
+  GroupRaw raw[U][groups_per_tile<GM>()];
+  half8_t xf[XLDS ? 1 : U][XLDS ? 1 : 4][XLDS ? 1 : MT];
+};
+
+template <int MT, int GM, int U, bool XLDS>
+__device__ __forceinline__ void skinny_load(SkinnyChunk<MT, GM, U, XLDS>& c, int kt, int kt_end,
+                                            const u32x4* __restrict__ wp, const half_t* const (&xp)[MT],
+                                            const GemmArgs& a, int n) {
+  constexpr int NG = groups_per_tile<GM>();
 #pragma unroll
-  for (int u = 0; u < U; ++u) w[u] = wp[(size_t)(kt + u) * 64];
-  GroupQ grp[U][G128 ? 1 : 4];
+  for (int u = 0; u < U; ++u) c.w[u] = wp[(size_t)min(kt + u, kt_end - 1) * 64];  // past the end: replay, never used
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+      c.raw[u][i] = load_group_raw(a.S, a.QZ, group_index<GM>(min(kt + u, kt_end - 1), i * (4 / NG), a.tpg, a.G), n, a.N);
+  if constexpr (!XLDS) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) c.xf[u][t][mt] = *(const half8_t*)(xp[mt] + min(kt + u, kt_end - 1) * 128 + 32 * t);
+  }
+}
+
+template <int MT, int GM, int U, bool XLDS>
+__device__ __forceinline__ void skinny_compute(const SkinnyChunk<MT, GM, U, XLDS>& c, int kt, int kt_end, const char* xl,
+                                               const LaneSel& ls, floatx4 (&acc)[MT]) {
+  constexpr int NG = groups_per_tile<GM>();
 #pragma unroll
   for (int u = 0; u < U; ++u) {
+    if (kt + u < kt_end) {  // wave-uniform
+      GroupQ grp[NG];
 #pragma unroll
-    for (int t = 0; t < (G128 ? 1 : 4); ++t) grp[u][t] = load_group(S, QZ, ((kt + u) * 128 + 32 * t) / G, n, N);
-  }
-  half8_t xf[U][4][MT];
+      for (int i = 0; i < NG; ++i) grp[i] = make_group(c.raw[u][i], ls);
 #pragma unroll
-  for (int u = 0; u < U; ++u)
+      for (int t = 0; t < 4; ++t) {
+        const half8_t af = dequant8(c.w[u][t], grp[group_slot<GM>(t)]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xf[u][t][mt] = *(const half8_t*)(xp[mt] + (kt + u) * 128 + 32 * t);
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const half8_t a = dequant8(w[u][t], grp[u][G128 ? 0 : t]);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(a, xf[u][t][mt], acc[mt]);
+        for (int mt = 0; mt < MT; ++mt) {
+          half8_t bf;
+          if constexpr (XLDS) bf = *(const half8_t*)(xl + ((kt + u) * 128 + 32 * t) * 2);
+          else bf = c.xf[u][t][mt];
+          acc[mt] = mfma16(af, bf, acc[mt]);
+        }
+      }
     }
+  }
 }
 
-template <int MT, int WAVES, bool G128>
-__global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(
-    const half_t* __restrict__ X, const u32x4* __restrict__ QW, const half_t* __restrict__ S,
-    const uint32_t* __restrict__ QZ, const half_t* __restrict__ bias, half_t* __restrict__ Y,
-    float* __restrict__ Yacc, int M, int K, int N, int G, int ksplit) {
+template <int MT, int WAVES, int GM, bool XLDS>
+__global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
   static_assert(WAVES >= MT, "reduction assigns one token tile per wave");
-  __shared__ floatx4 red[WAVES][MT][64];
+  static_assert(!XLDS || MT == 1, "the LDS copy of x is for a single token tile");
+  constexpr int U = XLDS ? 4 : (MT == 1 ? 2 : 1);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  floatx4* red = (floatx4*)smem;  // [WAVES][MT][64]
+  char* xlds = smem + WAVES * MT * 64 * sizeof(floatx4);
 
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
   const int n16 = lane & 15, q = lane >> 4;
   const int nt = blockIdx.x, mb = blockIdx.y, ks = blockIdx.z;
-  const int KT = K >> 7;
-  const int wg_begin = (int)((long)KT * ks / ksplit), wg_end = (int)((long)KT * (ks + 1) / ksplit);
+  const int KT = a.K >> 7;
+  const int wg_begin = ks * a.kt_per_split, wg_end = min(KT, wg_begin + a.kt_per_split);
   const int cnt = wg_end - wg_begin;
   const int kt_begin = wg_begin + cnt * wave / WAVES, kt_end = wg_begin + cnt * (wave + 1) / WAVES;
   const int n = nt * 16 + n16;
+  const LaneSel ls = lane_sel(n);
 
-  const u32x4* wp = QW + (size_t)nt * KT * 64 + lane;
+  const u32x4* wp = a.QW + (size_t)nt * KT * 64 + lane;
   const half_t* xp[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int row = min((mb * MT + mt) * 16 + n16, M - 1);  // rows >= M replay row M-1; never stored
-    xp[mt] = X + (size_t)row * K + q * 8;
+    const int row = min((mb * MT + mt) * 16 + n16, a.M - 1);  // rows >= M replay row M-1; never stored
+    xp[mt] = a.X + (size_t)row * a.K + q * 8;
   }
 
   floatx4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int U = (MT == 1) ? 4 : (MT == 2 ? 2 : 1);
-  int kt = kt_begin;
-  for (; kt + U <= kt_end; kt += U) skinny_body<MT, WAVES, G128, U>(kt, wp, xp, S, QZ, n, N, G, acc);
-  for (; kt < kt_end; ++kt) skinny_body<MT, WAVES, G128, 1>(kt, wp, xp, S, QZ, n, N, G, acc);
+  SkinnyChunk<MT, GM, U, XLDS> cA, cB;
+  if (kt_begin < kt_end) skinny_load<MT, GM, U, XLDS>(cA, kt_begin, kt_end, wp, xp, a, n);  // HBM requests go out first
+  __builtin_amdgcn_sched_barrier(0);
+
+  const char* xl = nullptr;
+  if constexpr (XLDS) {
+    // copy x[mb*16 .. , wg_begin*128 .. wg_end*128) -> LDS [rows][pitch]
+    const int rows = min(16, a.M - mb * 16);
+    const int kc = cnt * 16;  // 16-byte chunks per row
+    const int pitch = cnt * 256 + 16;
+    for (int i = threadIdx.x; i < rows * kc; i += WAVES * 64) {
+      const int r = i / kc, c = i - r * kc;
+      const u32x4 v = *(const u32x4*)(a.X + (size_t)(mb * 16 + r) * a.K + wg_begin * 128 + c * 8);
+      *(u32x4*)(xlds + r * pitch + c * 16) = v;
+    }
+    xl = xlds + min(n16, rows - 1) * pitch + q * 16 - wg_begin * 256;
+    __syncthreads();
+  }
+
+  for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
+    if (kt + U < kt_end) skinny_load<MT, GM, U, XLDS>(cB, kt + U, kt_end, wp, xp, a, n);
+    __builtin_amdgcn_sched_barrier(0);
+    skinny_compute<MT, GM, U, XLDS>(cA, kt, kt_end, xl, ls, acc);
+    if (kt + U >= kt_end) break;
+    if (kt + 2 * U < kt_end) skinny_load<MT, GM, U, XLDS>(cA, kt + 2 * U, kt_end, wp, xp, a, n);
+    __builtin_amdgcn_sched_barrier(0);
+    skinny_compute<MT, GM, U, XLDS>(cB, kt + U, kt_end, xl, ls, acc);
+  }
 
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) red[wave][mt][lane] = acc[mt];
+  for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
   __syncthreads();
   if (wave < MT) {
     const int mt = wave;
-    floatx4 sum = red[0][mt][lane];
+    floatx4 sum = red[mt * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < WAVES; ++w) sum += red[w][mt][lane];
+    for (int w = 1; w < WAVES; ++w) sum += red[(w * MT + mt) * 64 + lane];
     const int m = (mb * MT + mt) * 16 + n16;
     const int nc = nt * 16 + 4 * q;  // lane holds channels nc..nc+3 of token m
-    if (m < M) {
-      if (ksplit == 1) {
-        if (bias) {
-          const half4_t b = *(const half4_t*)(bias + nc);
+    if (m < a.M) {
+      if (a.ksplit == 1) {
+        if (a.bias) {
+          const half4_t b = *(const half4_t*)(a.bias + nc);
 #pragma unroll
           for (int r = 0; r < 4; ++r) sum[r] += (float)b[r];
         }
         half4_t o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (half_t)sum[r];
-        *(half4_t*)(Y + (size_t)m * N + nc) = o;
+        *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(Yacc + (size_t)m * N + nc + r, sum[r]);
+        for (int r = 0; r < 4; ++r) atomicAdd(a.Yacc + (size_t)m * a.N + nc + r, sum[r]);
       }
     }
   }
@@ -152,43 +216,117 @@ __global__ __launch_bounds__(256) void w4a16_finalize_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// tiled kernel: workgroup tile (BMT*16 tokens) x (4*TN*16 channels), 4 waves side by side along N.
-// The token tile of one 128-k step is staged in LDS *in B-fragment order* by global_load_lds
-// (lane l of fragment (t, mt) sources x[mt*16 + l%16][32t + 8*(l/16) ..+7]), so every ds_read_b128
-// is lane-linear and conflict free; weights never touch LDS.
+// tiled kernel: workgroup tile (BMT*16 tokens) x (4*TN*16 channels); 8 waves = 4 along N x 2 along K.
+// One stage = 256 k (two 128-k weight tiles): wave (wn, wk) owns channel tiles wn*TN..+TN-1 and the
+// wk-th weight tile of every stage, so no weight is dequantised twice and every LDS fragment is read
+// by 4 waves only.  The token tile of a stage is written to LDS *in B-fragment order* by
+// global_load_lds (lane l of fragment (kt, t, mt) sources x[mt*16 + l%16][kt*128 + 32t + 8*(l/16) ..+7]),
+// which makes every ds_read_b128 lane-linear and conflict free.  The two K halves are summed through
+// LDS in the epilogue.
 // ------------------------------------------------------------------------------------------------
-template <int BMT, int TN, bool G128>
-__global__ __launch_bounds__(256) void w4a16_tiled_kernel(
-    const half_t* __restrict__ X, const u32x4* __restrict__ QW, const half_t* __restrict__ S,
-    const uint32_t* __restrict__ QZ, const half_t* __restrict__ bias, half_t* __restrict__ Y,
-    float* __restrict__ Yacc, int M, int K, int N, int G, int ksplit) {
-  constexpr int FRAGS = 4 * BMT;  // 1 KiB fragments per 128-k step
-  __shared__ __attribute__((aligned(16))) char smem[2][FRAGS * 1024];
+// per-wave state of the tiled kernel that does not change over the K loop
+template <int BMT, int TN>
+struct TiledCtx {
+  const u32x4* wp[TN];   // this lane's 16 bytes of weight tile (channel tile j, k-tile 0)
+  int ncol[TN];          // this lane's output channel in channel tile j
+  const half_t* xsrc[BMT];  // global source of the fragments this wave stages (k-tile 0 of a stage)
+  int xkt[BMT];          // which of the stage's two k-tiles fragment i belongs to
+  int kt_lo, kt_hi, wave, wk;
+};
+
+template <int BMT, int TN>
+__device__ __forceinline__ void tiled_stage(const TiledCtx<BMT, TN>& c, char* smem_buf, int s) {
+#pragma unroll
+  for (int i = 0; i < BMT; ++i) {
+    const int kt = min(c.kt_lo + 2 * s + c.xkt[i], c.kt_hi - 1);  // odd tile count: replay the last tile (unused)
+    __builtin_amdgcn_global_load_lds(QA_GLOBAL_PTR(c.xsrc[i] + kt * 128), QA_LDS_PTR(smem_buf + (c.wave * BMT + i) * 1024),
+                                     16, 0, 0);
+  }
+}
+
+// weights + raw group constants of this wave's k-tile of stage s (no dependent ALU: see GroupRaw)
+template <int BMT, int TN, int GM>
+__device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN>& c, const GemmArgs& a, int s, u32x4 (&w)[TN],
+                                             uint32_t (&gs)[TN][groups_per_tile<GM>()],
+                                             uint32_t (&gz)[TN][groups_per_tile<GM>()]) {
+  constexpr int NG = groups_per_tile<GM>();
+  const int kt = min(c.kt_lo + 2 * s + c.wk, c.kt_hi - 1);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    w[j] = c.wp[j][(size_t)kt * 64];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int g = group_index<GM>(kt, i * (4 / NG), a.tpg, a.G);
+      const GroupRaw r = load_group_raw(a.S, a.QZ, g, c.ncol[j], a.N);
+      gs[j][i] = r.s2;
+      gz[j][i] = r.zq;
+    }
+  }
+}
+
+template <int BMT, int TN, int GM>
+__device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN>& c, const char* sb, int s, const u32x4 (&w)[TN],
+                                              const uint32_t (&gs)[TN][groups_per_tile<GM>()],
+                                              const uint32_t (&gz)[TN][groups_per_tile<GM>()],
+                                              floatx4 (&acc)[TN][BMT]) {
+  constexpr int NG = groups_per_tile<GM>();
+  if (c.kt_lo + 2 * s + c.wk >= c.kt_hi) return;  // wave-uniform: last stage of an odd tile count has no second half
+  GroupQ grp[TN][NG];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < NG; ++i) grp[j][i] = make_group(GroupRaw{gs[j][i], gz[j][i]}, lane_sel(c.ncol[j]));
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    half8_t bf[BMT];
+#pragma unroll
+    for (int mt = 0; mt < BMT; ++mt) bf[mt] = *(const half8_t*)(sb + (t * BMT + mt) * 1024);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const half8_t af = dequant8(w[j][t], grp[j][group_slot<GM>(t)]);
+#pragma unroll
+      for (int mt = 0; mt < BMT; ++mt) acc[j][mt] = mfma16(af, bf[mt], acc[j][mt]);
+    }
+  }
+}
+
+template <int BMT, int TN, int GM>
+__global__ __launch_bounds__(512) void w4a16_tiled_kernel(const GemmArgs a) {
+  constexpr int NG = groups_per_tile<GM>();
+  constexpr int FRAGS = 8 * BMT;             // 1 KiB fragments per stage
+  constexpr int STAGE_BYTES = FRAGS * 1024;  // 32 KiB at BMT = 4
+  static_assert(2 * STAGE_BYTES <= 65536, "static LDS");
+  static_assert(4 * TN * BMT * 1024 <= 2 * STAGE_BYTES, "epilogue exchange must fit in the stage buffers");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
+  const int wn = wave & 3, wk = wave >> 2;
   const int n16 = lane & 15, q = lane >> 4;
-  const int NB = N / (64 * TN);
+  const int NB = a.N / (64 * TN);
   const int nb = blockIdx.x % NB, mb = blockIdx.x / NB, ks = blockIdx.y;
-  const int KT = K >> 7;
-  const int kt_begin = (int)((long)KT * ks / ksplit), kt_end = (int)((long)KT * (ks + 1) / ksplit);
+  const int KT = a.K >> 7;
+  TiledCtx<BMT, TN> c;
+  c.kt_lo = ks * a.kt_per_split;
+  c.kt_hi = min(KT, c.kt_lo + a.kt_per_split);
+  c.wave = wave;
+  c.wk = wk;
+  const int nstage = (c.kt_hi - c.kt_lo + 1) >> 1;
   const int m0 = mb * BMT * 16;
-  const int nt0 = (nb * 4 + wave) * TN;  // first 16-channel tile of this wave
+  const int nt0 = (nb * 4 + wn) * TN;  // first 16-channel tile of this wave
 
-  const u32x4* wp[TN];
-  int ncol[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    wp[j] = QW + (size_t)(nt0 + j) * KT * 64 + lane;
-    ncol[j] = (nt0 + j) * 16 + n16;
+    c.wp[j] = a.QW + (size_t)(nt0 + j) * KT * 64 + lane;
+    c.ncol[j] = (nt0 + j) * 16 + n16;
   }
-  // fragments this wave stages: f = wave, wave + 4, ... ; f = t * BMT + mt
-  const half_t* xsrc[BMT];
+  // fragments this wave stages: f = wave*BMT + i  ->  (k-tile f / (4 BMT), k-step (f / BMT) % 4, token tile f % BMT)
 #pragma unroll
   for (int i = 0; i < BMT; ++i) {
-    const int f = wave + 4 * i, t = f / BMT, mt = f % BMT;
-    const int row = min(m0 + mt * 16 + n16, M - 1);
-    xsrc[i] = X + (size_t)row * K + 32 * t + 8 * q;
+    const int f = wave * BMT + i, t = (f / BMT) & 3, mt = f % BMT;
+    c.xkt[i] = f / (4 * BMT);
+    const int row = min(m0 + mt * 16 + n16, a.M - 1);
+    c.xsrc[i] = a.X + (size_t)row * a.K + 32 * t + 8 * q;
   }
 
   floatx4 acc[TN][BMT];
@@ -197,81 +335,68 @@ __global__ __launch_bounds__(256) void w4a16_tiled_kernel(
 #pragma unroll
     for (int mt = 0; mt < BMT; ++mt) acc[j][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  auto stage = [&](int buf, int kt) {
-#pragma unroll
-    for (int i = 0; i < BMT; ++i)
-      __builtin_amdgcn_global_load_lds(QA_GLOBAL_PTR(xsrc[i] + kt * 128), QA_LDS_PTR(smem[buf] + (wave + 4 * i) * 1024),
-                                       16, 0, 0);
-  };
+  // two register sets (A: even stages, B: odd stages) and two LDS buffers, ping-ponged by a 2x unrolled loop
+  u32x4 wA[TN], wB[TN];
+  uint32_t gsA[TN][NG], gsB[TN][NG];
+  uint32_t gzA[TN][NG], gzB[TN][NG];
+  char* const buf0 = smem;
+  char* const buf1 = smem + STAGE_BYTES;
+  const int rd = wk * (4 * BMT * 1024) + lane * 16;  // this wave reads its k-tile's half of a stage
 
-  u32x4 wcur[TN], wnext[TN];
-  GroupQ gcur[TN][G128 ? 1 : 4], gnext[TN][G128 ? 1 : 4];
-  auto load_w = [&](int kt, u32x4 (&w)[TN], GroupQ (&g)[TN][G128 ? 1 : 4]) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      w[j] = wp[j][(size_t)kt * 64];
-#pragma unroll
-      for (int t = 0; t < (G128 ? 1 : 4); ++t) g[j][t] = load_group(S, QZ, (kt * 128 + 32 * t) / G, ncol[j], N);
-    }
-  };
-
-  if (kt_begin < kt_end) {
-    stage(0, kt_begin);
-    load_w(kt_begin, wcur, gcur);
+  if (nstage > 0) {
+    tiled_load_w<BMT, TN, GM>(c, a, 0, wA, gsA, gzA);
+    tiled_stage<BMT, TN>(c, buf0, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  int buf = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const bool more = kt + 1 < kt_end;
-    if (more) {
-      stage(buf ^ 1, kt + 1);
-      load_w(kt + 1, wnext, gnext);
+  for (int s = 0; s < nstage; s += 2) {
+    if (s + 1 < nstage) {
+      tiled_load_w<BMT, TN, GM>(c, a, s + 1, wB, gsB, gzB);
+      tiled_stage<BMT, TN>(c, buf1, s + 1);
     }
-    const char* sb = smem[buf] + lane * 16;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      half8_t bf[BMT];
-#pragma unroll
-      for (int mt = 0; mt < BMT; ++mt) bf[mt] = *(const half8_t*)(sb + (t * BMT + mt) * 1024);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const half8_t a = dequant8(wcur[j][t], gcur[j][G128 ? 0 : t]);
-#pragma unroll
-        for (int mt = 0; mt < BMT; ++mt) acc[j][mt] = mfma16(a, bf[mt], acc[j][mt]);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile landed in LDS (and in wnext)
+    tiled_compute<BMT, TN, GM>(c, buf0 + rd, s, wA, gsA, gzA, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed in LDS (and in the other register set)
     __syncthreads();
-    if (more) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        wcur[j] = wnext[j];
-#pragma unroll
-        for (int t = 0; t < (G128 ? 1 : 4); ++t) gcur[j][t] = gnext[j][t];
-      }
+    if (s + 1 >= nstage) break;
+    if (s + 2 < nstage) {
+      tiled_load_w<BMT, TN, GM>(c, a, s + 2, wA, gsA, gzA);
+      tiled_stage<BMT, TN>(c, buf0, s + 2);
     }
-    buf ^= 1;
+    tiled_compute<BMT, TN, GM>(c, buf1 + rd, s + 1, wB, gsB, gzB, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
 
+  // sum the two K halves through LDS (the stage buffers are free after the last barrier)
+  floatx4* ex = (floatx4*)smem;  // [wn][j][mt][lane]
+  if (wk == 1) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int nc = (nt0 + j) * 16 + 4 * q;
-    half4_t b = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-    if (bias && ksplit == 1) b = *(const half4_t*)(bias + nc);
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int mt = 0; mt < BMT; ++mt) {
-      const int m = m0 + mt * 16 + n16;
-      if (m < M) {
-        if (ksplit == 1) {
-          half4_t o;
+      for (int mt = 0; mt < BMT; ++mt) ex[((wn * TN + j) * BMT + mt) * 64 + lane] = acc[j][mt];
+  }
+  __syncthreads();
+  if (wk == 0) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[j][mt][r] + (float)b[r]);
-          *(half4_t*)(Y + (size_t)m * N + nc) = o;
-        } else {
+    for (int j = 0; j < TN; ++j) {
+      const int nc = (nt0 + j) * 16 + 4 * q;
+      half4_t b = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+      if (a.bias && a.ksplit == 1) b = *(const half4_t*)(a.bias + nc);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(Yacc + (size_t)m * N + nc + r, acc[j][mt][r]);
+      for (int mt = 0; mt < BMT; ++mt) {
+        const floatx4 v = acc[j][mt] + ex[((wn * TN + j) * BMT + mt) * 64 + lane];
+        const int m = m0 + mt * 16 + n16;
+        if (m < a.M) {
+          if (a.ksplit == 1) {
+            half4_t o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[r] + (float)b[r]);
+            *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(a.Yacc + (size_t)m * a.N + nc + r, v[r]);
+          }
         }
       }
     }
@@ -291,10 +416,10 @@ __global__ __launch_bounds__(64) void w4a16_dequant_kernel(const u32x4* __restri
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int k0 = kt * 128 + 32 * t + 8 * q;
-    const GroupQ g = load_group(S, QZ, k0 / G, n, N);
-    const half8_t a = dequant8(w[t], g);
+    const GroupQ g = make_group(load_group_raw(S, QZ, k0 / G, n, N), lane_sel(n));
+    const half8_t af = dequant8(w[t], g);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) W[(size_t)(k0 + j) * N + n] = a[j];
+    for (int j = 0; j < 8; ++j) W[(size_t)(k0 + j) * N + n] = af[j];
   }
 }
 
@@ -313,9 +438,17 @@ static int fail(int code, const char* fmt, ...) {
 struct Plan {
   int kernel;  // QUICK_KERNEL_SKINNY / QUICK_KERNEL_TILED
   int mt;      // skinny: token tiles per workgroup; tiled: BMT
-  int tn;      // tiled: channel tiles per wave
   int waves;   // skinny: waves per workgroup
+  bool xlds;   // skinny: x through an LDS copy
   int ksplit;  // K slices across workgroups (fp32 atomics + finalize when > 1)
+  int kt_per_split;
+};
+
+// Where the main kernel goes: the stream, plus an optional event pair bound to that one dispatch
+// (hipExtLaunchKernelGGL) so that a profiler-free caller can read the kernel's own duration.
+struct Launch {
+  hipStream_t st;
+  hipEvent_t start, stop;
 };
 
 static int check_shapes(int M, int K, int N, int G) {
@@ -329,61 +462,89 @@ static int check_shapes(int M, int K, int N, int G) {
   return QUICK_OK;
 }
 
+static constexpr int kSkinnyXldsBytes = 64 * 1024;  // LDS budget of the x copy
+
+// `kernel`: low 4 bits = family (QUICK_KERNEL_*), bits 4-7 = token tiles (0 = auto), bits 8-11 = skinny waves / 4
+// (0 = auto), bit 12 = skinny: forbid the LDS copy of x.  Upper bits are for tests and tuning only.
 static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   Plan p{};
   const int KT = K / 128;
-  if (kernel == QUICK_KERNEL_AUTO) kernel = (M <= 16) ? QUICK_KERNEL_SKINNY : QUICK_KERNEL_TILED;
-  p.kernel = kernel;
-  if (kernel == QUICK_KERNEL_SKINNY) {
-    p.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
-    p.waves = 8;
+  const int family = kernel & 15, mt_req = (kernel >> 4) & 15, waves_req = ((kernel >> 8) & 15) * 4;
+  const bool no_xlds = (kernel >> 12) & 1;
+  p.kernel = family == QUICK_KERNEL_AUTO ? (M <= 64 ? QUICK_KERNEL_SKINNY : QUICK_KERNEL_TILED) : family;
+  int ks = 1;
+  if (p.kernel == QUICK_KERNEL_SKINNY) {
+    p.mt = mt_req ? mt_req : (M <= 16 ? 1 : (M <= 32 ? 2 : 4));
+    if (p.mt != 1 && p.mt != 2) p.mt = 4;
+    p.waves = (waves_req == 4 || waves_req == 8 || waves_req == 16) ? waves_req : 8;
     const int mblocks = (M + p.mt * 16 - 1) / (p.mt * 16);
-    int ks = 1;
     // fill the 256 CUs when N is small: every workgroup should still own >= 8 k-tiles
     while ((N / 16) * mblocks * ks < 256 && KT / (ks * 2) >= 8) ks *= 2;
-    p.ksplit = grid_split_k > 0 ? grid_split_k : ks;
   } else {
-    p.mt = (M <= 32) ? 2 : (M <= 64 ? 4 : 8);
-    p.tn = 2;
-    p.ksplit = grid_split_k > 0 ? grid_split_k : 1;
+    p.mt = mt_req == 2 ? 2 : 4;
+    const int tiles = (N / 128) * ((M + p.mt * 16 - 1) / (p.mt * 16));
+    while (tiles * ks < 192 && KT / (ks * 2) >= 8) ks *= 2;
   }
-  p.ksplit = std::max(1, std::min(p.ksplit, KT));
+  p.ksplit = std::max(1, std::min(grid_split_k > 0 ? grid_split_k : ks, KT));
+  p.kt_per_split = (KT + p.ksplit - 1) / p.ksplit;
+  if (p.kernel == QUICK_KERNEL_TILED && (p.kt_per_split & 1) && p.ksplit > 1) ++p.kt_per_split;  // whole stages
+  p.ksplit = (KT + p.kt_per_split - 1) / p.kt_per_split;
+  if (p.kernel == QUICK_KERNEL_SKINNY) {
+    const int rows = std::min(M, 16);
+    p.xlds = !no_xlds && p.mt == 1 && (size_t)rows * (p.kt_per_split * 256 + 16) <= (size_t)kSkinnyXldsBytes;
+  }
   return p;
 }
 
-// Where the main kernel goes: the stream, plus an optional event pair bound to that one dispatch
-// (hipExtLaunchKernelGGL) so that a profiler-free caller can read the kernel's own duration.
-struct Launch {
-  hipStream_t st;
-  hipEvent_t start, stop;
-};
+static int group_mode(int G) { return G == 128 ? 0 : (G % 128 == 0 ? 1 : (G == 64 ? 2 : (G == 32 ? 3 : 4))); }
 
-template <int MT, int WAVES>
-static void launch_skinny(const Plan& p, const void* x, const void* qw, const void* s, const void* qz, const void* bias,
-                          void* y, float* yacc, int M, int K, int N, int G, const Launch& L) {
-  dim3 grid(N / 16, (M + MT * 16 - 1) / (MT * 16), p.ksplit), block(WAVES * 64);
-  if (G % 128 == 0)
-    hipExtLaunchKernelGGL((w4a16_skinny_kernel<MT, WAVES, true>), grid, block, 0, L.st, L.start, L.stop, 0,
-                          (const half_t*)x, (const u32x4*)qw, (const half_t*)s, (const uint32_t*)qz, (const half_t*)bias,
-                          (half_t*)y, yacc, M, K, N, G, p.ksplit);
-  else
-    hipExtLaunchKernelGGL((w4a16_skinny_kernel<MT, WAVES, false>), grid, block, 0, L.st, L.start, L.stop, 0,
-                          (const half_t*)x, (const u32x4*)qw, (const half_t*)s, (const uint32_t*)qz, (const half_t*)bias,
-                          (half_t*)y, yacc, M, K, N, G, p.ksplit);
+template <int MT, int WAVES, bool XLDS>
+static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) {
+  dim3 grid(a.N / 16, (a.M + MT * 16 - 1) / (MT * 16), p.ksplit), block(WAVES * 64);
+  size_t lds = (size_t)WAVES * MT * 1024;
+  if (XLDS) lds += (size_t)std::min(a.M, 16) * (p.kt_per_split * 256 + 16);
+#define QA_SKINNY(GMV)                                                                                              \
+  hipExtLaunchKernelGGL((w4a16_skinny_kernel<MT, WAVES, GMV, XLDS>), grid, block, (unsigned)lds, L.st, L.start, L.stop, \
+                        0, a)
+  switch (group_mode(a.G)) {
+    case 0: QA_SKINNY(0); break;
+    case 1: QA_SKINNY(1); break;
+    case 2: QA_SKINNY(2); break;
+    case 3: QA_SKINNY(3); break;
+    default: QA_SKINNY(4); break;
+  }
+#undef QA_SKINNY
 }
 
-template <int BMT, int TN>
-static void launch_tiled(const Plan& p, const void* x, const void* qw, const void* s, const void* qz, const void* bias,
-                         void* y, float* yacc, int M, int K, int N, int G, const Launch& L) {
-  dim3 grid((N / (64 * TN)) * ((M + BMT * 16 - 1) / (BMT * 16)), p.ksplit), block(256);
-  if (G % 128 == 0)
-    hipExtLaunchKernelGGL((w4a16_tiled_kernel<BMT, TN, true>), grid, block, 0, L.st, L.start, L.stop, 0,
-                          (const half_t*)x, (const u32x4*)qw, (const half_t*)s, (const uint32_t*)qz, (const half_t*)bias,
-                          (half_t*)y, yacc, M, K, N, G, p.ksplit);
-  else
-    hipExtLaunchKernelGGL((w4a16_tiled_kernel<BMT, TN, false>), grid, block, 0, L.st, L.start, L.stop, 0,
-                          (const half_t*)x, (const u32x4*)qw, (const half_t*)s, (const uint32_t*)qz, (const half_t*)bias,
-                          (half_t*)y, yacc, M, K, N, G, p.ksplit);
+template <int MT>
+static void launch_skinny(const Plan& p, const GemmArgs& a, const Launch& L) {
+  if constexpr (MT == 1) {
+    if (p.xlds) {
+      if (p.waves == 4) launch_skinny_gm<1, 4, true>(p, a, L);
+      else if (p.waves == 16) launch_skinny_gm<1, 16, true>(p, a, L);
+      else launch_skinny_gm<1, 8, true>(p, a, L);
+      return;
+    }
+  }
+  if (p.waves == 4) launch_skinny_gm<MT, 4, false>(p, a, L);
+  else if (p.waves == 16) launch_skinny_gm<MT, 16, false>(p, a, L);
+  else launch_skinny_gm<MT, 8, false>(p, a, L);
+}
+
+template <int BMT>
+static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
+  constexpr int TN = 2;
+  dim3 grid((a.N / (64 * TN)) * ((a.M + BMT * 16 - 1) / (BMT * 16)), p.ksplit), block(512);
+#define QA_TILED(GMV) \
+  hipExtLaunchKernelGGL((w4a16_tiled_kernel<BMT, TN, GMV>), grid, block, 0, L.st, L.start, L.stop, 0, a)
+  switch (group_mode(a.G)) {
+    case 0: QA_TILED(0); break;
+    case 1: QA_TILED(1); break;
+    case 2: QA_TILED(2); break;
+    case 3: QA_TILED(3); break;
+    default: QA_TILED(4); break;
+  }
+#undef QA_TILED
 }
 
 static int run_gemm(const void* x, const void* qweight, const void* scales, const void* qzeros, const void* bias, void* y,
@@ -391,34 +552,30 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
                     const Launch& L) {
   if (int rc = check_shapes(M, K, N, G)) return rc;
   if (!x || !qweight || !scales || !qzeros || !y) return fail(QUICK_ERR_INVALID_ARGUMENT, "null tensor pointer");
-  if (kernel < QUICK_KERNEL_AUTO || kernel > QUICK_KERNEL_TILED)
-    return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
-  hipStream_t st = L.st;
+  if ((kernel & 15) > QUICK_KERNEL_TILED || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
   const Plan p = make_plan(M, K, N, kernel, grid_split_k);
-  float* yacc = nullptr;
+  GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)bias,
+             (half_t*)y, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split};
   if (p.ksplit > 1) {
     const size_t need = (size_t)M * N * sizeof(float);
     if (!workspace || workspace_bytes < need)
       return fail(QUICK_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
-    yacc = (float*)workspace;
-    if (hipMemsetAsync(yacc, 0, need, st) != hipSuccess) return fail(QUICK_ERR_LAUNCH, "hipMemsetAsync failed");
+    a.Yacc = (float*)workspace;
+    if (hipMemsetAsync(a.Yacc, 0, need, L.st) != hipSuccess) return fail(QUICK_ERR_LAUNCH, "hipMemsetAsync failed");
   }
   if (p.kernel == QUICK_KERNEL_SKINNY) {
     switch (p.mt) {
-      case 1: launch_skinny<1, 8>(p, x, qweight, scales, qzeros, bias, y, yacc, M, K, N, G, L); break;
-      case 2: launch_skinny<2, 8>(p, x, qweight, scales, qzeros, bias, y, yacc, M, K, N, G, L); break;
-      default: launch_skinny<4, 8>(p, x, qweight, scales, qzeros, bias, y, yacc, M, K, N, G, L); break;
+      case 1: launch_skinny<1>(p, a, L); break;
+      case 2: launch_skinny<2>(p, a, L); break;
+      default: launch_skinny<4>(p, a, L); break;
     }
   } else {
-    switch (p.mt) {
-      case 2: launch_tiled<2, 2>(p, x, qweight, scales, qzeros, bias, y, yacc, M, K, N, G, L); break;
-      case 4: launch_tiled<4, 2>(p, x, qweight, scales, qzeros, bias, y, yacc, M, K, N, G, L); break;
-      default: launch_tiled<8, 2>(p, x, qweight, scales, qzeros, bias, y, yacc, M, K, N, G, L); break;
-    }
+    if (p.mt == 2) launch_tiled<2>(p, a, L);
+    else launch_tiled<4>(p, a, L);
   }
   if (p.ksplit > 1) {
     const size_t n4 = ((size_t)M * N + 3) / 4;
-    hipLaunchKernelGGL(w4a16_finalize_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, yacc,
+    hipLaunchKernelGGL(w4a16_finalize_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, L.st, a.Yacc,
                        (const half_t*)bias, (half_t*)y, M, N);
   }
   const hipError_t e = hipGetLastError();

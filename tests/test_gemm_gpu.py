@@ -155,9 +155,14 @@ def test_baseline_one_hot_rows_reproduce_dequantised_weights_bit_exactly(qa, dev
 
 
 @pytest.mark.parametrize("M", [1, 64, 512])
-def test_baseline_power_of_two_scaling_is_exact(qa, device, full, M):
-    x = _dev(full["x"][:M], device)
+def test_baseline_power_of_two_scaling_is_exact_and_deterministic(qa, device, full, M):
+    # fp16 subnormals are kept out of x: doubling turns some of them into normals, and the matrix core does
+    # not treat the two classes alike, so y(2x) == 2 y(x) would otherwise fail by an ulp in a handful of outputs
+    xs = full["x"][:M].copy()
+    xs[np.abs(xs) < 2.0 ** -13] = 2.0 ** -13
+    x = _dev(xs, device)
     y1 = qa.gemm_forward(x, *full["packed"])
+    assert torch.equal(qa.gemm_forward(x, *full["packed"]), y1)          # run-to-run identical (no races)
     y2 = qa.gemm_forward(x * 2, *full["packed"])
     assert torch.equal(y2, y1 * 2)
     assert torch.equal(qa.gemm_forward(torch.zeros_like(x), *full["packed"]), torch.zeros_like(y1))
