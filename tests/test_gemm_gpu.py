@@ -164,7 +164,9 @@ def test_baseline_power_of_two_scaling_is_exact_and_deterministic(qa, device, fu
     y1 = qa.gemm_forward(x, *full["packed"])
     assert torch.equal(qa.gemm_forward(x, *full["packed"]), y1)          # run-to-run identical (no races)
     y2 = qa.gemm_forward(x * 2, *full["packed"])
-    assert torch.equal(y2, y1 * 2)
+    normal = y1.abs() >= 2.0 ** -13          # a subnormal fp16 output has fewer bits than its double: not comparable
+    assert torch.equal(y2[normal], (y1 * 2)[normal])
+    assert ((y2 - y1 * 2).abs() <= 2.0 ** -23)[~normal].all()
     assert torch.equal(qa.gemm_forward(torch.zeros_like(x), *full["packed"]), torch.zeros_like(y1))
 
 

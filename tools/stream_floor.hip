@@ -48,6 +48,24 @@ __global__ void k_stream_red(const u32x4* __restrict__ w, unsigned* __restrict__
   }
 }
 
+// streaming kernel that also records each wave's first/last wall-clock tick (s_memrealtime)
+template <int L>
+__global__ void k_stream_ts(const u32x4* __restrict__ w, unsigned* __restrict__ out, unsigned long long* __restrict__ ts) {
+  const unsigned long long t0 = wall_clock64();
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const u32x4* p = w + (size_t)wave * L * 64 + lane;
+  u32x4 v[L];
+#pragma unroll
+  for (int i = 0; i < L; ++i) v[i] = p[i * 64];
+  unsigned acc = 0;
+#pragma unroll
+  for (int i = 0; i < L; ++i) acc ^= v[i][0] ^ v[i][1] ^ v[i][2] ^ v[i][3];
+  if (acc == 0x12345678u) out[wave] = acc;
+  const unsigned long long t1 = wall_clock64();
+  if (lane == 0) { ts[2 * wave] = t0; ts[2 * wave + 1] = t1 + (acc == 0x12345678u); }
+}
+
 template <typename F>
 static void timeit(const char* name, F launch, int iters = 60) {
   std::vector<hipEvent_t> ev(2 * iters);
@@ -87,5 +105,25 @@ int main() {
   RUN(1, 256, 0) RUN(2, 256, 0) RUN(4, 256, 0) RUN(8, 256, 0) RUN(16, 256, 0)
   RUN(2, 512, 0) RUN(4, 512, 0) RUN(8, 512, 0) RUN(4, 1024, 0) RUN(2, 1024, 0)
   RUN(4, 512, 1) RUN(2, 1024, 1) RUN(4, 256, 1) RUN(8, 256, 1)
+  // in-kernel wall-clock span of the streaming kernel (first wave start -> last wave end)
+  {
+    int rate_khz = 0; hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, 0);
+    const int L = 4, BLOCK = 512, waves = (int)(bytes / (1024 * L)), grid = waves / (BLOCK / 64);
+    unsigned long long* ts; hipMalloc(&ts, waves * 16);
+    std::vector<unsigned long long> h(2 * waves);
+    for (int hot = 0; hot < 2; ++hot) {
+      double acc = 0; int n = 0;
+      for (int i = 0; i < 30; ++i) {
+        const u32x4* p = (const u32x4*)(w + (hot ? 0 : (size_t)(i % nsets) * bytes));
+        hipLaunchKernelGGL((k_stream_ts<L>), dim3(grid), dim3(BLOCK), 0, st, p, out, ts);
+        hipStreamSynchronize(st);
+        hipMemcpy(h.data(), ts, waves * 16, hipMemcpyDeviceToHost);
+        unsigned long long lo = ~0ull, hi = 0, latest_start = 0;
+        for (int k = 0; k < waves; ++k) { lo = std::min(lo, h[2 * k]); hi = std::max(hi, h[2 * k + 1]); latest_start = std::max(latest_start, h[2 * k]); }
+        if (i >= 5) { acc += (double)(hi - lo) / rate_khz * 1000.0; ++n; if (i == 5) printf("   (last wave started %.2f us after the first)\n", (double)(latest_start - lo) / rate_khz * 1000.0); }
+      }
+      printf("in-kernel span stream L=4 block=512 %s: %.2f us (wall clock %d kHz)\n", hot ? "hot" : "cold", acc / n, rate_khz);
+    }
+  }
   return 0;
 }
