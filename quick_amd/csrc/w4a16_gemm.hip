@@ -227,21 +227,29 @@ __global__ __launch_bounds__(256) void w4a16_finalize_kernel(const float* __rest
 // per-wave state of the tiled kernel that does not change over the K loop
 template <int BMT, int TN>
 struct TiledCtx {
-  const u32x4* wp[TN];   // this lane's 16 bytes of weight tile (channel tile j, k-tile 0)
-  int ncol[TN];          // this lane's output channel in channel tile j
+  const u32x4* wp[TN];      // this lane's 16 bytes of weight tile (channel tile j, k-tile 0)
+  int ncol[TN];             // this lane's output channel in channel tile j
   const half_t* xsrc[BMT];  // global source of the fragments this wave stages (k-tile 0 of a stage)
-  int xkt[BMT];          // which of the stage's two k-tiles fragment i belongs to
+  int xkt[BMT];             // which of the stage's two k-tiles fragment i belongs to
   int kt_lo, kt_hi, wave, wk;
 };
 
+// x fragments of stage s: global -> registers (ordinary loads: hipcc counts them, so they can stay in flight
+// across barriers and several stages; global_load_lds cannot -- the compiler drains it at every barrier and at
+// the first use of any other load)
 template <int BMT, int TN>
-__device__ __forceinline__ void tiled_stage(const TiledCtx<BMT, TN>& c, char* smem_buf, int s) {
+__device__ __forceinline__ void tiled_load_x(const TiledCtx<BMT, TN>& c, int s, u32x4 (&xr)[BMT]) {
 #pragma unroll
   for (int i = 0; i < BMT; ++i) {
     const int kt = min(c.kt_lo + 2 * s + c.xkt[i], c.kt_hi - 1);  // odd tile count: replay the last tile (unused)
-    __builtin_amdgcn_global_load_lds(QA_GLOBAL_PTR(c.xsrc[i] + kt * 128), QA_LDS_PTR(smem_buf + (c.wave * BMT + i) * 1024),
-                                     16, 0, 0);
+    xr[i] = *(const u32x4*)(c.xsrc[i] + kt * 128);
   }
+}
+// registers -> LDS in B-fragment order: fragment f = wave*BMT + i is 1 KiB, lane l at byte 16 l
+template <int BMT, int TN>
+__device__ __forceinline__ void tiled_store_x(const TiledCtx<BMT, TN>& c, char* buf, int lane, const u32x4 (&xr)[BMT]) {
+#pragma unroll
+  for (int i = 0; i < BMT; ++i) *(u32x4*)(buf + (c.wave * BMT + i) * 1024 + lane * 16) = xr[i];
 }
 
 // weights + raw group constants of this wave's k-tile of stage s (no dependent ALU: see GroupRaw)
@@ -290,9 +298,14 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN>& c, const 
   }
 }
 
+// Software pipeline, D = 3 stages deep: while stage s is computed from LDS buffer s%2, the x fragments of stage
+// s+1 (loaded two iterations ago) are written to the other buffer and the loads of stage s+3 are issued.
+// Register slots: x in flight D-1 = 2, weights D+1 = 4; the loop is unrolled by 4 so every slot index is static.
 template <int BMT, int TN, int GM>
 __global__ __launch_bounds__(512) void w4a16_tiled_kernel(const GemmArgs a) {
   constexpr int NG = groups_per_tile<GM>();
+  constexpr int D = 3, XS = D - 1, WS = D + 1, UNR = 4;
+  static_assert(UNR % XS == 0 && UNR % WS == 0 && UNR % 2 == 0, "static slot indices");
   constexpr int FRAGS = 8 * BMT;             // 1 KiB fragments per stage
   constexpr int STAGE_BYTES = FRAGS * 1024;  // 32 KiB at BMT = 4
   static_assert(2 * STAGE_BYTES <= 65536, "static LDS");
@@ -335,38 +348,41 @@ __global__ __launch_bounds__(512) void w4a16_tiled_kernel(const GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < BMT; ++mt) acc[j][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  // two register sets (A: even stages, B: odd stages) and two LDS buffers, ping-ponged by a 2x unrolled loop
-  u32x4 wA[TN], wB[TN];
-  uint32_t gsA[TN][NG], gsB[TN][NG];
-  uint32_t gzA[TN][NG], gzB[TN][NG];
-  char* const buf0 = smem;
-  char* const buf1 = smem + STAGE_BYTES;
+  u32x4 xr[XS][BMT];
+  u32x4 w[WS][TN];
+  uint32_t gs[WS][TN][NG], gz[WS][TN][NG];
   const int rd = wk * (4 * BMT * 1024) + lane * 16;  // this wave reads its k-tile's half of a stage
 
+  // prologue: stage 0 straight into LDS, stages 1 .. D-1 in flight.  Loads past the last stage are NOT guarded:
+  // they replay the last tile (clamped index) and are never consumed -- a guard would merge "issued" and "not
+  // issued" paths and force hipcc to drain the whole load queue (vmcnt(0)) at every consumer.
   if (nstage > 0) {
-    tiled_load_w<BMT, TN, GM>(c, a, 0, wA, gsA, gzA);
-    tiled_stage<BMT, TN>(c, buf0, 0);
+    tiled_load_w<BMT, TN, GM>(c, a, 0, w[0], gs[0], gz[0]);
+    tiled_load_x<BMT, TN>(c, 0, xr[0]);
+    tiled_store_x<BMT, TN>(c, smem, lane, xr[0]);
+#pragma unroll
+    for (int d = 1; d < D; ++d) {
+      tiled_load_w<BMT, TN, GM>(c, a, d, w[d % WS], gs[d % WS], gz[d % WS]);
+      tiled_load_x<BMT, TN>(c, d, xr[d % XS]);
+    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int s = 0; s < nstage; s += 2) {
-    if (s + 1 < nstage) {
-      tiled_load_w<BMT, TN, GM>(c, a, s + 1, wB, gsB, gzB);
-      tiled_stage<BMT, TN>(c, buf1, s + 1);
+  for (int s0 = 0; s0 < nstage; s0 += UNR) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int s = s0 + u;
+      if (s >= nstage) goto k_loop_done;
+      char* const cur = smem + (u & 1) * STAGE_BYTES;
+      char* const nxt = smem + ((u + 1) & 1) * STAGE_BYTES;
+      tiled_store_x<BMT, TN>(c, nxt, lane, xr[(u + 1) % XS]);  // stage s+1 (a replay of the last one at the very end)
+      tiled_load_w<BMT, TN, GM>(c, a, s + D, w[(u + D) % WS], gs[(u + D) % WS], gz[(u + D) % WS]);
+      tiled_load_x<BMT, TN>(c, s + D, xr[(u + D) % XS]);
+      tiled_compute<BMT, TN, GM>(c, cur + rd, s, w[u % WS], gs[u % WS], gz[u % WS], acc);
+      __syncthreads();
     }
-    tiled_compute<BMT, TN, GM>(c, buf0 + rd, s, wA, gsA, gzA, acc);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed in LDS (and in the other register set)
-    __syncthreads();
-    if (s + 1 >= nstage) break;
-    if (s + 2 < nstage) {
-      tiled_load_w<BMT, TN, GM>(c, a, s + 2, wA, gsA, gzA);
-      tiled_stage<BMT, TN>(c, buf0, s + 2);
-    }
-    tiled_compute<BMT, TN, GM>(c, buf1 + rd, s + 1, wB, gsB, gzB, acc);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
+k_loop_done:
 
   // sum the two K halves through LDS (the stage buffers are free after the last barrier)
   floatx4* ex = (floatx4*)smem;  // [wn][j][mt][lane]
