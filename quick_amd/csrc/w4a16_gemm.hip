@@ -272,7 +272,9 @@ __device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN>& c, const G
   }
 }
 
-template <int BMT, int TN, int GM>
+// ABL (ablation bits, timing experiments only -- results are wrong when set): 1 = no global loads in the K loop,
+// 2 = no LDS traffic in the K loop, 4 = no dequantisation, 8 = no barrier.
+template <int BMT, int TN, int GM, int ABL = 0>
 __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN>& c, const char* sb, int s, const u32x4 (&w)[TN],
                                               const uint32_t (&gs)[TN][groups_per_tile<GM>()],
                                               const uint32_t (&gz)[TN][groups_per_tile<GM>()],
@@ -288,10 +290,15 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN>& c, const 
   for (int t = 0; t < 4; ++t) {
     half8_t bf[BMT];
 #pragma unroll
-    for (int mt = 0; mt < BMT; ++mt) bf[mt] = *(const half8_t*)(sb + (t * BMT + mt) * 1024);
+    for (int mt = 0; mt < BMT; ++mt) {
+      if constexpr (ABL & 2) bf[mt] = __builtin_bit_cast(half8_t, w[0]);
+      else bf[mt] = *(const half8_t*)(sb + (t * BMT + mt) * 1024);
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const half8_t af = dequant8(w[j][t], grp[j][group_slot<GM>(t)]);
+      half8_t af;
+      if constexpr (ABL & 4) af = __builtin_bit_cast(half8_t, w[j]);
+      else af = dequant8(w[j][t], grp[j][group_slot<GM>(t)]);
 #pragma unroll
       for (int mt = 0; mt < BMT; ++mt) acc[j][mt] = mfma16(af, bf[mt], acc[j][mt]);
     }
@@ -301,7 +308,7 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN>& c, const 
 // Software pipeline, D = 3 stages deep: while stage s is computed from LDS buffer s%2, the x fragments of stage
 // s+1 (loaded two iterations ago) are written to the other buffer and the loads of stage s+3 are issued.
 // Register slots: x in flight D-1 = 2, weights D+1 = 4; the loop is unrolled by 4 so every slot index is static.
-template <int BMT, int TN, int GM>
+template <int BMT, int TN, int GM, int ABL = 0>
 __global__ __launch_bounds__(512) void w4a16_tiled_kernel(const GemmArgs a) {
   constexpr int NG = groups_per_tile<GM>();
   constexpr int D = 3, XS = D - 1, WS = D + 1, UNR = 4;
@@ -375,11 +382,13 @@ __global__ __launch_bounds__(512) void w4a16_tiled_kernel(const GemmArgs a) {
       if (s >= nstage) goto k_loop_done;
       char* const cur = smem + (u & 1) * STAGE_BYTES;
       char* const nxt = smem + ((u + 1) & 1) * STAGE_BYTES;
-      tiled_store_x<BMT, TN>(c, nxt, lane, xr[(u + 1) % XS]);  // stage s+1 (a replay of the last one at the very end)
-      tiled_load_w<BMT, TN, GM>(c, a, s + D, w[(u + D) % WS], gs[(u + D) % WS], gz[(u + D) % WS]);
-      tiled_load_x<BMT, TN>(c, s + D, xr[(u + D) % XS]);
-      tiled_compute<BMT, TN, GM>(c, cur + rd, s, w[u % WS], gs[u % WS], gz[u % WS], acc);
-      __syncthreads();
+      if constexpr (!(ABL & 2)) tiled_store_x<BMT, TN>(c, nxt, lane, xr[(u + 1) % XS]);  // stage s+1 (a replay of the last one at the very end)
+      if constexpr (!(ABL & 1)) {
+        tiled_load_w<BMT, TN, GM>(c, a, s + D, w[(u + D) % WS], gs[(u + D) % WS], gz[(u + D) % WS]);
+        tiled_load_x<BMT, TN>(c, s + D, xr[(u + D) % XS]);
+      }
+      tiled_compute<BMT, TN, GM, ABL>(c, cur + rd, s, w[u % WS], gs[u % WS], gz[u % WS], acc);
+      if constexpr (!(ABL & 8)) __syncthreads();
     }
   }
 k_loop_done:
@@ -458,6 +467,7 @@ struct Plan {
   bool xlds;   // skinny: x through an LDS copy
   int ksplit;  // K slices across workgroups (fp32 atomics + finalize when > 1)
   int kt_per_split;
+  int ablate;  // kernel bits 16-19: ablation variant of the tiled kernel (timing experiments only)
 };
 
 // Where the main kernel goes: the stream, plus an optional event pair bound to that one dispatch
@@ -487,6 +497,7 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   const int KT = K / 128;
   const int family = kernel & 15, mt_req = (kernel >> 4) & 15, waves_req = ((kernel >> 8) & 15) * 4;
   const bool no_xlds = (kernel >> 12) & 1;
+  p.ablate = (kernel >> 16) & 15;
   p.kernel = family == QUICK_KERNEL_AUTO ? (M <= 64 ? QUICK_KERNEL_SKINNY : QUICK_KERNEL_TILED) : family;
   int ks = 1;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
@@ -553,6 +564,20 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
   dim3 grid((a.N / (64 * TN)) * ((a.M + BMT * 16 - 1) / (BMT * 16)), p.ksplit), block(512);
 #define QA_TILED(GMV) \
   hipExtLaunchKernelGGL((w4a16_tiled_kernel<BMT, TN, GMV>), grid, block, 0, L.st, L.start, L.stop, 0, a)
+#define QA_TILED_ABL(ABLV) \
+  hipExtLaunchKernelGGL((w4a16_tiled_kernel<BMT, TN, 0, ABLV>), grid, block, 0, L.st, L.start, L.stop, 0, a)
+  if (BMT == 4 && p.ablate && a.G == 128) {  // timing experiments (tools/): results are wrong on purpose
+    switch (p.ablate) {
+      case 1: QA_TILED_ABL(1); return;
+      case 2: QA_TILED_ABL(2); return;
+      case 3: QA_TILED_ABL(3); return;
+      case 4: QA_TILED_ABL(4); return;
+      case 7: QA_TILED_ABL(7); return;
+      case 8: QA_TILED_ABL(8); return;
+      case 15: QA_TILED_ABL(15); return;
+      default: break;
+    }
+  }
   switch (group_mode(a.G)) {
     case 0: QA_TILED(0); break;
     case 1: QA_TILED(1); break;
