@@ -225,40 +225,41 @@ __global__ __launch_bounds__(256) void w4a16_finalize_kernel(const float* __rest
 // LDS in the epilogue.
 // ------------------------------------------------------------------------------------------------
 // per-wave state of the tiled kernel that does not change over the K loop
-template <int BMT, int TN>
+template <int BMT, int TN, int WK>
 struct TiledCtx {
+  static constexpr int XPW = (4 * WK * BMT) / (4 * WK);  // x fragments staged per wave per stage (= BMT)
   const u32x4* wp[TN];      // this lane's 16 bytes of weight tile (channel tile j, k-tile 0)
   int ncol[TN];             // this lane's output channel in channel tile j
   const half_t* xsrc[BMT];  // global source of the fragments this wave stages (k-tile 0 of a stage)
-  int xkt[BMT];             // which of the stage's two k-tiles fragment i belongs to
+  int xkt[BMT];             // which of the stage's WK k-tiles fragment i belongs to
   int kt_lo, kt_hi, wave, wk;
 };
 
 // x fragments of stage s: global -> registers (ordinary loads: hipcc counts them, so they can stay in flight
-// across barriers and several stages; global_load_lds cannot -- the compiler drains it at every barrier and at
-// the first use of any other load)
-template <int BMT, int TN>
-__device__ __forceinline__ void tiled_load_x(const TiledCtx<BMT, TN>& c, int s, u32x4 (&xr)[BMT]) {
+// across barriers; global_load_lds cannot -- the compiler drains it at every barrier and at the first use of any
+// other load)
+template <int BMT, int TN, int WK>
+__device__ __forceinline__ void tiled_load_x(const TiledCtx<BMT, TN, WK>& c, int s, u32x4 (&xr)[BMT]) {
 #pragma unroll
   for (int i = 0; i < BMT; ++i) {
-    const int kt = min(c.kt_lo + 2 * s + c.xkt[i], c.kt_hi - 1);  // odd tile count: replay the last tile (unused)
+    const int kt = min(c.kt_lo + WK * s + c.xkt[i], c.kt_hi - 1);  // past the end: replay the last tile (unused)
     xr[i] = *(const u32x4*)(c.xsrc[i] + kt * 128);
   }
 }
 // registers -> LDS in B-fragment order: fragment f = wave*BMT + i is 1 KiB, lane l at byte 16 l
-template <int BMT, int TN>
-__device__ __forceinline__ void tiled_store_x(const TiledCtx<BMT, TN>& c, char* buf, int lane, const u32x4 (&xr)[BMT]) {
+template <int BMT, int TN, int WK>
+__device__ __forceinline__ void tiled_store_x(const TiledCtx<BMT, TN, WK>& c, char* buf, int lane, const u32x4 (&xr)[BMT]) {
 #pragma unroll
   for (int i = 0; i < BMT; ++i) *(u32x4*)(buf + (c.wave * BMT + i) * 1024 + lane * 16) = xr[i];
 }
 
 // weights + raw group constants of this wave's k-tile of stage s (no dependent ALU: see GroupRaw)
-template <int BMT, int TN, int GM>
-__device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN>& c, const GemmArgs& a, int s, u32x4 (&w)[TN],
+template <int BMT, int TN, int WK, int GM>
+__device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN, WK>& c, const GemmArgs& a, int s, u32x4 (&w)[TN],
                                              uint32_t (&gs)[TN][groups_per_tile<GM>()],
                                              uint32_t (&gz)[TN][groups_per_tile<GM>()]) {
   constexpr int NG = groups_per_tile<GM>();
-  const int kt = min(c.kt_lo + 2 * s + c.wk, c.kt_hi - 1);
+  const int kt = min(c.kt_lo + WK * s + c.wk, c.kt_hi - 1);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     w[j] = c.wp[j][(size_t)kt * 64];
@@ -274,13 +275,13 @@ __device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN>& c, const G
 
 // ABL (ablation bits, timing experiments only -- results are wrong when set): 1 = no global loads in the K loop,
 // 2 = no LDS traffic in the K loop, 4 = no dequantisation, 8 = no barrier.
-template <int BMT, int TN, int GM, int ABL = 0>
-__device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN>& c, const char* sb, int s, const u32x4 (&w)[TN],
+template <int BMT, int TN, int WK, int GM, int ABL = 0>
+__device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK>& c, const char* sb, int s, const u32x4 (&w)[TN],
                                               const uint32_t (&gs)[TN][groups_per_tile<GM>()],
                                               const uint32_t (&gz)[TN][groups_per_tile<GM>()],
                                               floatx4 (&acc)[TN][BMT]) {
   constexpr int NG = groups_per_tile<GM>();
-  if (c.kt_lo + 2 * s + c.wk >= c.kt_hi) return;  // wave-uniform: last stage of an odd tile count has no second half
+  if (c.kt_lo + WK * s + c.wk >= c.kt_hi) return;  // wave-uniform: a ragged last stage has no tile for this wave
   GroupQ grp[TN][NG];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
@@ -305,19 +306,25 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN>& c, const 
   }
 }
 
-// Software pipeline, D = 3 stages deep: while stage s is computed from LDS buffer s%2, the x fragments of stage
-// s+1 (loaded two iterations ago) are written to the other buffer and the loads of stage s+3 are issued.
-// Register slots: x in flight D-1 = 2, weights D+1 = 4; the loop is unrolled by 4 so every slot index is static.
-template <int BMT, int TN, int GM, int ABL = 0>
-__global__ __launch_bounds__(512) void w4a16_tiled_kernel(const GemmArgs a) {
+// Tiled kernel.  Workgroup tile (BMT*16 tokens) x (4*TN*16 channels); 4*WK waves = 4 along N x WK along K.
+// One stage = WK*128 k: wave (wn, wk) owns channel tiles wn*TN..+TN-1 and the wk-th 128-k weight tile of every
+// stage, so no weight is dequantised twice inside a workgroup and every LDS fragment is read by 4 waves only.  The
+// token tile of a stage lives in LDS *in B-fragment order* (lane l of fragment (kt, t, mt) holds
+// x[mt*16 + l%16][kt*128 + 32t + 8*(l/16) ..+7]), so every ds_read_b128 / ds_write_b128 is lane-linear and
+// conflict free.  The WK partial sums are added through LDS in the epilogue.
+//
+// Software pipeline (2 LDS buffers, 2 weight register sets, 1 x register set; loop unrolled by 2 so that every
+// slot index is static):  iteration s  =  { x(s+1): regs -> LDS[other] ; issue x(s+2) loads ; compute stage s from
+// LDS[cur] with weights[s%2] ; issue weights(s+2) into the set just freed ; barrier }.
+// Loads past the last stage are NOT guarded: they replay the last tile (clamped index) and are never consumed -- a
+// guard would merge "issued" and "not issued" paths and make hipcc drain the whole load queue at every consumer.
+template <int BMT, int TN, int WK, int GM, int ABL = 0>
+__global__ __launch_bounds__(256 * WK) void w4a16_tiled_kernel(const GemmArgs a) {
   constexpr int NG = groups_per_tile<GM>();
-  constexpr int D = 3, XS = D - 1, WS = D + 1, UNR = 4;
-  static_assert(UNR % XS == 0 && UNR % WS == 0 && UNR % 2 == 0, "static slot indices");
-  constexpr int FRAGS = 8 * BMT;             // 1 KiB fragments per stage
-  constexpr int STAGE_BYTES = FRAGS * 1024;  // 32 KiB at BMT = 4
-  static_assert(2 * STAGE_BYTES <= 65536, "static LDS");
-  static_assert(4 * TN * BMT * 1024 <= 2 * STAGE_BYTES, "epilogue exchange must fit in the stage buffers");
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  constexpr int FRAGS = 4 * WK * BMT;        // 1 KiB fragments per stage
+  constexpr int STAGE_BYTES = FRAGS * 1024;  // 32 KiB at BMT = 4, WK = 2
+  static_assert((WK - 1) * 4 * TN * BMT * 1024 <= 2 * STAGE_BYTES, "epilogue exchange must fit in the stage buffers");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE_BYTES
 
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
@@ -326,12 +333,12 @@ __global__ __launch_bounds__(512) void w4a16_tiled_kernel(const GemmArgs a) {
   const int NB = a.N / (64 * TN);
   const int nb = blockIdx.x % NB, mb = blockIdx.x / NB, ks = blockIdx.y;
   const int KT = a.K >> 7;
-  TiledCtx<BMT, TN> c;
+  TiledCtx<BMT, TN, WK> c;
   c.kt_lo = ks * a.kt_per_split;
   c.kt_hi = min(KT, c.kt_lo + a.kt_per_split);
   c.wave = wave;
   c.wk = wk;
-  const int nstage = (c.kt_hi - c.kt_lo + 1) >> 1;
+  const int nstage = (c.kt_hi - c.kt_lo + WK - 1) / WK;
   const int m0 = mb * BMT * 16;
   const int nt0 = (nb * 4 + wn) * TN;  // first 16-channel tile of this wave
 
@@ -355,51 +362,43 @@ __global__ __launch_bounds__(512) void w4a16_tiled_kernel(const GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < BMT; ++mt) acc[j][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 xr[XS][BMT];
-  u32x4 w[WS][TN];
-  uint32_t gs[WS][TN][NG], gz[WS][TN][NG];
-  const int rd = wk * (4 * BMT * 1024) + lane * 16;  // this wave reads its k-tile's half of a stage
+  u32x4 xr[BMT];
+  u32x4 w[2][TN];
+  uint32_t gs[2][TN][NG], gz[2][TN][NG];
+  const int rd = wk * (4 * BMT * 1024) + lane * 16;  // this wave reads its k-tile's part of a stage
 
-  // prologue: stage 0 straight into LDS, stages 1 .. D-1 in flight.  Loads past the last stage are NOT guarded:
-  // they replay the last tile (clamped index) and are never consumed -- a guard would merge "issued" and "not
-  // issued" paths and force hipcc to drain the whole load queue (vmcnt(0)) at every consumer.
   if (nstage > 0) {
-    tiled_load_w<BMT, TN, GM>(c, a, 0, w[0], gs[0], gz[0]);
-    tiled_load_x<BMT, TN>(c, 0, xr[0]);
-    tiled_store_x<BMT, TN>(c, smem, lane, xr[0]);
-#pragma unroll
-    for (int d = 1; d < D; ++d) {
-      tiled_load_w<BMT, TN, GM>(c, a, d, w[d % WS], gs[d % WS], gz[d % WS]);
-      tiled_load_x<BMT, TN>(c, d, xr[d % XS]);
-    }
+    tiled_load_w<BMT, TN, WK, GM>(c, a, 0, w[0], gs[0], gz[0]);
+    tiled_load_x<BMT, TN, WK>(c, 0, xr);
+    tiled_load_w<BMT, TN, WK, GM>(c, a, 1, w[1], gs[1], gz[1]);
+    tiled_store_x<BMT, TN, WK>(c, smem, lane, xr);
+    tiled_load_x<BMT, TN, WK>(c, 1, xr);
   }
   __syncthreads();
 
-  for (int s0 = 0; s0 < nstage; s0 += UNR) {
+  for (int s0 = 0; s0 < nstage; s0 += 2) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
+    for (int u = 0; u < 2; ++u) {
       const int s = s0 + u;
       if (s >= nstage) goto k_loop_done;
-      char* const cur = smem + (u & 1) * STAGE_BYTES;
-      char* const nxt = smem + ((u + 1) & 1) * STAGE_BYTES;
-      if constexpr (!(ABL & 2)) tiled_store_x<BMT, TN>(c, nxt, lane, xr[(u + 1) % XS]);  // stage s+1 (a replay of the last one at the very end)
-      if constexpr (!(ABL & 1)) {
-        tiled_load_w<BMT, TN, GM>(c, a, s + D, w[(u + D) % WS], gs[(u + D) % WS], gz[(u + D) % WS]);
-        tiled_load_x<BMT, TN>(c, s + D, xr[(u + D) % XS]);
-      }
-      tiled_compute<BMT, TN, GM, ABL>(c, cur + rd, s, w[u % WS], gs[u % WS], gz[u % WS], acc);
+      char* const cur = smem + u * STAGE_BYTES;
+      char* const nxt = smem + (u ^ 1) * STAGE_BYTES;
+      if constexpr (!(ABL & 2)) tiled_store_x<BMT, TN, WK>(c, nxt, lane, xr);  // stage s+1 (a replay at the very end)
+      if constexpr (!(ABL & 1)) tiled_load_x<BMT, TN, WK>(c, s + 2, xr);
+      tiled_compute<BMT, TN, WK, GM, ABL>(c, cur + rd, s, w[u], gs[u], gz[u], acc);
+      if constexpr (!(ABL & 1)) tiled_load_w<BMT, TN, WK, GM>(c, a, s + 2, w[u], gs[u], gz[u]);
       if constexpr (!(ABL & 8)) __syncthreads();
     }
   }
 k_loop_done:
 
-  // sum the two K halves through LDS (the stage buffers are free after the last barrier)
-  floatx4* ex = (floatx4*)smem;  // [wn][j][mt][lane]
-  if (wk == 1) {
+  // add the WK partial sums through LDS (the stage buffers are free after the last barrier)
+  floatx4* ex = (floatx4*)smem;  // [wk-1][wn][j][mt][lane]
+  if (wk > 0) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int mt = 0; mt < BMT; ++mt) ex[((wn * TN + j) * BMT + mt) * 64 + lane] = acc[j][mt];
+      for (int mt = 0; mt < BMT; ++mt) ex[((((wk - 1) * 4 + wn) * TN + j) * BMT + mt) * 64 + lane] = acc[j][mt];
   }
   __syncthreads();
   if (wk == 0) {
@@ -410,7 +409,9 @@ k_loop_done:
       if (a.bias && a.ksplit == 1) b = *(const half4_t*)(a.bias + nc);
 #pragma unroll
       for (int mt = 0; mt < BMT; ++mt) {
-        const floatx4 v = acc[j][mt] + ex[((wn * TN + j) * BMT + mt) * 64 + lane];
+        floatx4 v = acc[j][mt];
+#pragma unroll
+        for (int k = 1; k < WK; ++k) v += ex[((((k - 1) * 4 + wn) * TN + j) * BMT + mt) * 64 + lane];
         const int m = m0 + mt * 16 + n16;
         if (m < a.M) {
           if (a.ksplit == 1) {
@@ -509,12 +510,13 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
     while ((N / 16) * mblocks * ks < 256 && KT / (ks * 2) >= 8) ks *= 2;
   } else {
     p.mt = mt_req == 2 ? 2 : 4;
+    p.waves = waves_req == 8 ? 8 : 16;
     const int tiles = (N / 128) * ((M + p.mt * 16 - 1) / (p.mt * 16));
     while (tiles * ks < 192 && KT / (ks * 2) >= 8) ks *= 2;
   }
   p.ksplit = std::max(1, std::min(grid_split_k > 0 ? grid_split_k : ks, KT));
   p.kt_per_split = (KT + p.ksplit - 1) / p.ksplit;
-  if (p.kernel == QUICK_KERNEL_TILED && (p.kt_per_split & 1) && p.ksplit > 1) ++p.kt_per_split;  // whole stages
+  if (p.kernel == QUICK_KERNEL_TILED && p.ksplit > 1) p.kt_per_split = (p.kt_per_split + 3) & ~3;  // whole stages
   p.ksplit = (KT + p.kt_per_split - 1) / p.kt_per_split;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
     const int rows = std::min(M, 16);
@@ -558,34 +560,40 @@ static void launch_skinny(const Plan& p, const GemmArgs& a, const Launch& L) {
   else launch_skinny_gm<MT, 8, false>(p, a, L);
 }
 
-template <int BMT>
+template <int BMT, int WK>
 static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
   constexpr int TN = 2;
-  dim3 grid((a.N / (64 * TN)) * ((a.M + BMT * 16 - 1) / (BMT * 16)), p.ksplit), block(512);
-#define QA_TILED(GMV) \
-  hipExtLaunchKernelGGL((w4a16_tiled_kernel<BMT, TN, GMV>), grid, block, 0, L.st, L.start, L.stop, 0, a)
-#define QA_TILED_ABL(ABLV) \
-  hipExtLaunchKernelGGL((w4a16_tiled_kernel<BMT, TN, 0, ABLV>), grid, block, 0, L.st, L.start, L.stop, 0, a)
+  dim3 grid((a.N / (64 * TN)) * ((a.M + BMT * 16 - 1) / (BMT * 16)), p.ksplit), block(256 * WK);
+  const unsigned lds = 2 * 4 * WK * BMT * 1024;
+#define QA_TILED_K(GMV, ABLV)                                                                                      \
+  do {                                                                                                             \
+    auto kfn = w4a16_tiled_kernel<BMT, TN, WK, GMV, ABLV>;                                                         \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
+  } while (0)
   if (BMT == 4 && p.ablate && a.G == 128) {  // timing experiments (tools/): results are wrong on purpose
     switch (p.ablate) {
-      case 1: QA_TILED_ABL(1); return;
-      case 2: QA_TILED_ABL(2); return;
-      case 3: QA_TILED_ABL(3); return;
-      case 4: QA_TILED_ABL(4); return;
-      case 7: QA_TILED_ABL(7); return;
-      case 8: QA_TILED_ABL(8); return;
-      case 15: QA_TILED_ABL(15); return;
+      case 1: QA_TILED_K(0, 1); return;
+      case 2: QA_TILED_K(0, 2); return;
+      case 3: QA_TILED_K(0, 3); return;
+      case 4: QA_TILED_K(0, 4); return;
+      case 7: QA_TILED_K(0, 7); return;
+      case 15: QA_TILED_K(0, 15); return;
       default: break;
     }
   }
   switch (group_mode(a.G)) {
-    case 0: QA_TILED(0); break;
-    case 1: QA_TILED(1); break;
-    case 2: QA_TILED(2); break;
-    case 3: QA_TILED(3); break;
-    default: QA_TILED(4); break;
+    case 0: QA_TILED_K(0, 0); break;
+    case 1: QA_TILED_K(1, 0); break;
+    case 2: QA_TILED_K(2, 0); break;
+    case 3: QA_TILED_K(3, 0); break;
+    default: QA_TILED_K(4, 0); break;
   }
-#undef QA_TILED
+#undef QA_TILED_K
 }
 
 static int run_gemm(const void* x, const void* qweight, const void* scales, const void* qzeros, const void* bias, void* y,
@@ -611,8 +619,9 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
       default: launch_skinny<4>(p, a, L); break;
     }
   } else {
-    if (p.mt == 2) launch_tiled<2>(p, a, L);
-    else launch_tiled<4>(p, a, L);
+    if (p.mt == 2) launch_tiled<2, 2>(p, a, L);
+    else if (p.waves == 8) launch_tiled<4, 2>(p, a, L);
+    else launch_tiled<4, 4>(p, a, L);
   }
   if (p.ksplit > 1) {
     const size_t n4 = ((size_t)M * N + 3) / 4;
