@@ -96,6 +96,10 @@ int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const v
                              size_t workspace_bytes, int M, int K, int N, int group_size, int kernel,
                              int grid_split_k, int iters, float* kernel_us, void* hip_stream);
 
+/* Measurement aid: the same event-pair clock on `iters` dispatches of an EMPTY kernel with the GEMM's launch
+ * shape (256 workgroups x 512 threads): the fixed part of every "kernel duration" reading on this stack. */
+int quick_amd_dispatch_floor(int iters, float* kernel_us, void* hip_stream);
+
 /*
  * Format bridge.  "cuda order" is byte-for-byte what the reference's WQLinear_QUICK.from_linear
  * writes (quick/awq/modules/linear/quick.py:88-150) and what its checkpoints hold; "mi355x order"

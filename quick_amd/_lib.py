@@ -14,6 +14,7 @@ _SIGNATURES = {
     "quick_w4a16_gemm_f16_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     "quick_w4a16_workspace_bytes_ex": (_Z, [_I, _I, _I, _I, _I, _I]),
     "quick_w4a16_gemm_profile": (_I, [_P, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "quick_amd_dispatch_floor": (_I, [_I, _P, _P]),
     "quick_repack_cuda_to_mi355x": (_I, [_P] * 6 + [_I, _I, _I, _P]),
     "quick_repack_mi355x_to_cuda": (_I, [_P] * 6 + [_I, _I, _I, _P]),
     "quick_dequantize_mi355x_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -19,7 +19,6 @@ SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM
 FETCH_SIZE GRBM_GUI_ACTIVE
 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 TCC_REQ_sum TCC_READ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum
-TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 LIST
 cd $root
 python tools/prof_summary.py $out > $out/summary.txt 2>&1
