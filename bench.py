@@ -223,11 +223,17 @@ def main():
             return y, time.perf_counter() - t0
         x_t = torch.from_numpy(x_np[:args.M])
         cpu_call(128)                                    # page-in, thread pool
-        _, probe = cpu_call(128)
-        n_cpu = int(min(N, max(128, (args.cpu_seconds / 2 / max(probe, 1e-6)) // 1 * 128)))
-        n_cpu = max(128, (n_cpu // 128) * 128)
-        reps, total, y_cpu = 0, 0.0, None
-        while reps < 1 or (total < args.cpu_seconds / 2 and reps < 50):
+        # grow the slice geometrically while a call stays well inside the budget (host fp16 GEMM speed varies by
+        # orders of magnitude between CPUs, and not linearly in the slice width)
+        n_cpu, spent = 128, 0.0
+        y_cpu, dt1 = cpu_call(n_cpu)
+        spent += dt1
+        while n_cpu < N and dt1 * 2.5 < (args.cpu_seconds - spent):
+            n_cpu = min(N, n_cpu * 2)
+            y_cpu, dt1 = cpu_call(n_cpu)
+            spent += dt1
+        reps, total = 1, dt1
+        while total + dt1 < (args.cpu_seconds - spent) and reps < 50:
             y_cpu, dt1 = cpu_call(n_cpu)
             total += dt1
             reps += 1
