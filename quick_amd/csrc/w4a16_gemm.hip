@@ -38,6 +38,7 @@ struct GemmArgs {
   int tpg;     // G / 128 (group mode 1)
   int ksplit;  // K slices across workgroups
   int kt_per_split;
+  unsigned long long* dbg;  // ablation bit 16: per-wave phase cycle totals [workgroup][wave][8]
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -376,6 +377,16 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled_kernel(const GemmArgs a)
   }
   __syncthreads();
 
+  // ABL bit 16: s_memtime stamps between the phases of every iteration, summed per wave (perturbs the schedule a bit)
+  unsigned long long ph[5] = {0, 0, 0, 0, 0};
+  unsigned long long t_prev = 0;
+#define QA_STAMP(i)                                              \
+  if constexpr (ABL & 16) {                                      \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+    ph[i] += t_now - t_prev;                                     \
+    t_prev = t_now;                                              \
+  }
+  if constexpr (ABL & 16) t_prev = __builtin_amdgcn_s_memtime();
   for (int s0 = 0; s0 < nstage; s0 += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -384,13 +395,27 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled_kernel(const GemmArgs a)
       char* const cur = smem + u * STAGE_BYTES;
       char* const nxt = smem + (u ^ 1) * STAGE_BYTES;
       if constexpr (!(ABL & 2)) tiled_store_x<BMT, TN, WK>(c, nxt, lane, xr);  // stage s+1 (a replay at the very end)
+      QA_STAMP(0)
       if constexpr (!(ABL & 1)) tiled_load_x<BMT, TN, WK>(c, s + 2, xr);
+      QA_STAMP(1)
       tiled_compute<BMT, TN, WK, GM, ABL>(c, cur + rd, s, w[u], gs[u], gz[u], acc);
+      QA_STAMP(2)
       if constexpr (!(ABL & 1)) tiled_load_w<BMT, TN, WK, GM>(c, a, s + 2, w[u], gs[u], gz[u]);
+      QA_STAMP(3)
       if constexpr (!(ABL & 8)) __syncthreads();
+      QA_STAMP(4)
     }
   }
 k_loop_done:
+  if constexpr (ABL & 16) {
+    if (lane == 0 && a.dbg) {
+      unsigned long long* o = a.dbg + ((size_t)blockIdx.x * (4 * WK) + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) o[i] = ph[i];
+      o[5] = nstage;
+    }
+  }
+#undef QA_STAMP
 
   // add the WK partial sums through LDS (the stage buffers are free after the last barrier)
   floatx4* ex = (floatx4*)smem;  // [wk-1][wn][j][mt][lane]
@@ -503,7 +528,7 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   const int KT = K / 128;
   const int family = kernel & 15, mt_req = (kernel >> 4) & 15, waves_req = ((kernel >> 8) & 15) * 4;
   const bool no_xlds = (kernel >> 12) & 1;
-  p.ablate = (kernel >> 16) & 15;
+  p.ablate = (kernel >> 16) & 31;
   p.kernel = family == QUICK_KERNEL_AUTO ? (M <= 64 ? QUICK_KERNEL_SKINNY : QUICK_KERNEL_TILED) : family;
   int ks = 1;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
@@ -588,6 +613,7 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
       case 4: QA_TILED_K(0, 4); return;
       case 7: QA_TILED_K(0, 7); return;
       case 15: QA_TILED_K(0, 15); return;
+      case 16: QA_TILED_K(0, 16); return;
       default: break;
     }
   }
@@ -609,7 +635,8 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   if ((kernel & 15) > QUICK_KERNEL_TILED || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
   const Plan p = make_plan(M, K, N, kernel, grid_split_k);
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)bias,
-             (half_t*)y, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split};
+             (half_t*)y, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, nullptr};
+  if (p.ablate == 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
   if (p.ksplit > 1) {
     const size_t need = (size_t)M * N * sizeof(float);
     if (!workspace || workspace_bytes < need)

@@ -7,12 +7,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // each workgroup streams `per_wg` bytes (wrapping inside its XCD-local window of `window` bytes), U loads in flight per wave
 template <int U>
-__global__ __launch_bounds__(512) void k_read(const u32x4* __restrict__ buf, unsigned* __restrict__ out, size_t window_vec,
+__global__ __launch_bounds__(1024) void k_read(const u32x4* __restrict__ buf, unsigned* __restrict__ out, size_t window_vec,
                                               int iters) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // blocks with the same blockIdx % 8 share an XCD: give each XCD its own window
   const size_t base = (size_t)(blockIdx.x % 8) * window_vec;
-  size_t off = ((size_t)(blockIdx.x / 8) * 8 + wave) * 64 * U;  // in 16-byte units
+  size_t off = ((size_t)(blockIdx.x / 8) * (blockDim.x >> 6) + wave) * 64 * U;  // in 16-byte units
   unsigned acc = 0;
   for (int it = 0; it < iters; ++it) {
     u32x4 v[U];
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(512) void k_read(const u32x4* __restrict__ buf, uns
     for (int u = 0; u < U; ++u) v[u] = buf[base + (off + u * 64 + lane) % window_vec];
 #pragma unroll
     for (int u = 0; u < U; ++u) acc ^= v[u][0] ^ v[u][3];
-    off += 32 * 8 * 64 * U;  // all 32 workgroups of the XCD x 8 waves advance together
+    off += 32 * (blockDim.x >> 6) * 64 * U;  // all 32 workgroups of the XCD x their waves advance together
   }
   if (acc == 0x12345u) out[blockIdx.x] = acc;
 }
@@ -45,7 +45,7 @@ int main() {
   u32x4* buf; hipMalloc(&buf, total); hipMemset(buf, 1, total);
   unsigned* out; hipMalloc(&out, 4096);
   for (size_t w : {(size_t)512 << 10, (size_t)2 << 20, (size_t)8 << 20, (size_t)64 << 20})
-    for (int waves : {4, 8}) {
+    for (int waves : {4, 8, 16}) {
       run<1>(buf, out, w, waves); run<2>(buf, out, w, waves); run<4>(buf, out, w, waves); run<8>(buf, out, w, waves); run<16>(buf, out, w, waves);
     }
   return 0;

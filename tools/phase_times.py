@@ -1,0 +1,31 @@
+"""Diagnostic: per-phase cycle totals of the tiled kernel (ablation bit 16 = s_memtime stamps), M=512 K=N=4096."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from quick_amd import _lib
+lib = _lib.load()
+dev = torch.device("cuda:0")
+M, K, N, G = 512, 4096, 4096, 128
+x = torch.randn(M, K, device=dev).half()
+qw = torch.randint(-2**31, 2**31 - 1, (K // 4, N // 2), dtype=torch.int32, device=dev)
+sc = torch.rand(K // G, 2 * N, device=dev).half() * 0.02 + 0.005
+qz = torch.randint(-2**31, 2**31 - 1, (K // G, N // 4), dtype=torch.int32, device=dev)
+y = torch.empty(M, N, dtype=torch.float16, device=dev)
+ws = torch.zeros(4096 * 8 * 64 // 8, dtype=torch.int64, device=dev)
+kid = 2 + (16 << 16) + (int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+for _ in range(3):
+    rc = lib.quick_w4a16_gemm_f16_ex(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, y.data_ptr(), ws.data_ptr(),
+                                     ws.numel() * 8, M, K, N, G, kid, 0, None)
+    assert rc == 0, _lib.last_error()
+torch.cuda.synchronize()
+d = ws.cpu().numpy().reshape(-1, 8)[: 256 * 8].reshape(256, 8, 8).astype(np.float64)
+nst = d[0, 0, 5]
+names = ["x regs->LDS (vmcnt wait + ds_write)", "issue x loads", "compute (ds_read + dequant + mfma)", "issue w loads", "barrier"]
+tot = d[:, :, :5].sum(axis=2).mean()
+print(f"stages {nst:.0f}; mean cycles per wave in the K loop {tot:.0f} (s_memtime ticks = shader cycles)")
+for i, n in enumerate(names):
+    v = d[:, :, i]
+    print(f"  {n:40s} {v.mean() / nst:8.0f} cyc/stage  ({100 * v.mean() / tot:4.1f} %)   wave spread {v.min() / nst:.0f}..{v.max() / nst:.0f}")
+for wk in (0, 1):
+    v = d[:, 4 * wk:4 * wk + 4, :5].mean(axis=(0, 1)) / nst
+    print(f"  waves wk={wk}: " + "  ".join(f"{x:.0f}" for x in v))
