@@ -614,6 +614,11 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
       case 7: QA_TILED_K(0, 7); return;
       case 15: QA_TILED_K(0, 15); return;
       case 16: QA_TILED_K(0, 16); return;
+      case 17: QA_TILED_K(0, 17); return;
+      case 18: QA_TILED_K(0, 18); return;
+      case 20: QA_TILED_K(0, 20); return;
+      case 22: QA_TILED_K(0, 22); return;
+      case 23: QA_TILED_K(0, 23); return;
       default: break;
     }
   }
@@ -636,7 +641,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   const Plan p = make_plan(M, K, N, kernel, grid_split_k);
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)bias,
              (half_t*)y, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, nullptr};
-  if (p.ablate == 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
+  if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
   if (p.ksplit > 1) {
     const size_t need = (size_t)M * N * sizeof(float);
     if (!workspace || workspace_bytes < need)

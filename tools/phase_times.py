@@ -12,7 +12,7 @@ sc = torch.rand(K // G, 2 * N, device=dev).half() * 0.02 + 0.005
 qz = torch.randint(-2**31, 2**31 - 1, (K // G, N // 4), dtype=torch.int32, device=dev)
 y = torch.empty(M, N, dtype=torch.float16, device=dev)
 ws = torch.zeros(4096 * 8 * 64 // 8, dtype=torch.int64, device=dev)
-kid = 2 + (16 << 16) + (int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+kid = 2 + ((16 + (int(sys.argv[1]) if len(sys.argv) > 1 else 0)) << 16)
 for _ in range(3):
     rc = lib.quick_w4a16_gemm_f16_ex(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, y.data_ptr(), ws.data_ptr(),
                                      ws.numel() * 8, M, K, N, G, kid, 0, None)
