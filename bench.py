@@ -98,7 +98,7 @@ def main():
         x = x_full[:M].contiguous()
         y = torch.empty((M, N), dtype=torch.float16, device=dev)
         ws_bytes = lib.quick_w4a16_workspace_bytes_ex(M, K, N, G, args.kernel, 0)
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        ws = torch.zeros(max(ws_bytes, 1), dtype=torch.uint8, device=dev)   # zero-filled once; the library keeps it so
 
         def launch(i):
             qw, sc, qz = sets[i % n_sets]

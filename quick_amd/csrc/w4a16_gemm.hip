@@ -33,13 +33,42 @@ struct GemmArgs {
   const uint32_t* QZ;
   const half_t* bias;
   half_t* Y;
-  float* Yacc;  // fp32 accumulator when the grid splits K (ksplit > 1), else unused
+  float* slabs;        // ksplit > 1: fp32 partial tiles, [tile][slice][slab]
+  unsigned* counters;  // ksplit > 1: one arrival counter per output tile (zero on entry, zero again on exit)
   int M, K, N, G;
   int tpg;     // G / 128 (group mode 1)
   int ksplit;  // K slices across workgroups
   int kt_per_split;
   unsigned long long* dbg;  // ablation bit 16: per-wave phase cycle totals [workgroup][wave][8]
 };
+
+// ------------------------------------------------------------------------------------------------
+// K split across workgroups, reduced inside the launch ("last arriver finishes the tile").
+// Every slice stores its fp32 partial tile to its slab (plain, fully coalesced stores), then calls
+// splitk_arrive(): per-wave drain -> workgroup barrier -> ONE lane: agent-scope release, ticket from the tile's
+// counter; the workgroup that draws the last ticket resets the counter (the workspace is handed back zeroed),
+// does ONE agent-scope acquire, and -- after a second barrier -- adds the other slabs to the partial it still
+// holds in registers.  No spinning, so no co-residency requirement; correctness does not depend on which XCD or
+// CU a slice ran on (release = L2 write-back, acquire = L1 invalidate, as in cdna_hip_programming.md G16).
+// Replaces the reference's fp16 `[split_k, M, N]` scratch + torch `.sum(0)` (csrc/gemm_cuda_quick.cu:1468, 1515).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool splitk_arrive(unsigned* counter, int nslices, unsigned* lds_word) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's slab stores have been issued to L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // keep the write-back ahead of the ticket (ROCm 7.2 may drop it)
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = t == (unsigned)nslices - 1u;
+    if (last) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    *lds_word = last ? 1u : 0u;
+  }
+  __syncthreads();
+  return *lds_word != 0u;
+}
 
 // ------------------------------------------------------------------------------------------------
 // skinny kernel: one 16-channel tile per workgroup, K split over the waves of the workgroup (and over
@@ -172,58 +201,41 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
   __syncthreads();
+  floatx4 sum = floatx4{0.f, 0.f, 0.f, 0.f};
   if (wave < MT) {
-    const int mt = wave;
-    floatx4 sum = red[mt * 64 + lane];
+    sum = red[wave * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < WAVES; ++w) sum += red[(w * MT + mt) * 64 + lane];
-    const int m = (mb * MT + mt) * 16 + n16;
+    for (int w = 1; w < WAVES; ++w) sum += red[(w * MT + wave) * 64 + lane];
+  }
+  if (a.ksplit > 1) {
+    const int tile = mb * gridDim.x + nt;
+    float* slab0 = a.slabs + (size_t)tile * a.ksplit * (MT * 256);
+    if (wave < MT) *(floatx4*)(slab0 + (size_t)ks * (MT * 256) + (wave * 64 + lane) * 4) = sum;
+    if (!splitk_arrive(a.counters + tile, a.ksplit, (unsigned*)smem)) return;
+    if (wave < MT) {
+      for (int o = 0; o < a.ksplit; ++o)
+        if (o != ks) sum += *(const floatx4*)(slab0 + (size_t)o * (MT * 256) + (wave * 64 + lane) * 4);
+    }
+  }
+  if (wave < MT) {
+    const int m = (mb * MT + wave) * 16 + n16;
     const int nc = nt * 16 + 4 * q;  // lane holds channels nc..nc+3 of token m
     if (m < a.M) {
-      if (a.ksplit == 1) {
-        if (a.bias) {
-          const half4_t b = *(const half4_t*)(a.bias + nc);
+      if (a.bias) {
+        const half4_t b = *(const half4_t*)(a.bias + nc);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sum[r] += (float)b[r];
-        }
-        half4_t o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)sum[r];
-        *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(a.Yacc + (size_t)m * a.N + nc + r, sum[r]);
+        for (int r = 0; r < 4; ++r) sum[r] += (float)b[r];
       }
+      half4_t o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (half_t)sum[r];
+      *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
     }
   }
 }
 
-// fp32 accumulator (grid split-K) -> fp16 output (+ bias)
-__global__ __launch_bounds__(256) void w4a16_finalize_kernel(const float* __restrict__ Yacc,
-                                                             const half_t* __restrict__ bias,
-                                                             half_t* __restrict__ Y, int M, int N) {
-  const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i4 >= (size_t)M * N) return;
-  floatx4 v = *(const floatx4*)(Yacc + i4);
-  if (bias) {
-    const half4_t b = *(const half4_t*)(bias + (i4 % N));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
-  }
-  half4_t o;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-  *(half4_t*)(Y + i4) = o;
-}
-
 // ------------------------------------------------------------------------------------------------
-// tiled kernel: workgroup tile (BMT*16 tokens) x (4*TN*16 channels); 8 waves = 4 along N x 2 along K.
-// One stage = 256 k (two 128-k weight tiles): wave (wn, wk) owns channel tiles wn*TN..+TN-1 and the
-// wk-th weight tile of every stage, so no weight is dequantised twice and every LDS fragment is read
-// by 4 waves only.  The token tile of a stage is written to LDS *in B-fragment order* by
-// global_load_lds (lane l of fragment (kt, t, mt) sources x[mt*16 + l%16][kt*128 + 32t + 8*(l/16) ..+7]),
-// which makes every ds_read_b128 lane-linear and conflict free.  The two K halves are summed through
-// LDS in the epilogue.
+// tiled kernel
 // ------------------------------------------------------------------------------------------------
 // per-wave state of the tiled kernel that does not change over the K loop
 template <int BMT, int TN, int WK>
@@ -428,26 +440,48 @@ k_loop_done:
   __syncthreads();
   if (wk == 0) {
 #pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int mt = 0; mt < BMT; ++mt)
+#pragma unroll
+        for (int k = 1; k < WK; ++k) acc[j][mt] += ex[((((k - 1) * 4 + wn) * TN + j) * BMT + mt) * 64 + lane];
+  }
+  if (a.ksplit > 1) {
+    constexpr int SLAB = 4 * TN * BMT * 256;  // floats per partial tile
+    float* slab0 = a.slabs + (size_t)blockIdx.x * a.ksplit * SLAB;
+    if (wk == 0) {
+      float* mine = slab0 + (size_t)ks * SLAB + ((wn * TN) * BMT * 64 + lane) * 4;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int mt = 0; mt < BMT; ++mt) *(floatx4*)(mine + (j * BMT + mt) * 256) = acc[j][mt];
+    }
+    if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
+    if (wk == 0) {
+      for (int o = 0; o < a.ksplit; ++o) {
+        if (o == ks) continue;
+        const float* other = slab0 + (size_t)o * SLAB + ((wn * TN) * BMT * 64 + lane) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int mt = 0; mt < BMT; ++mt) acc[j][mt] += *(const floatx4*)(other + (j * BMT + mt) * 256);
+      }
+    }
+  }
+  if (wk == 0) {
+#pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nc = (nt0 + j) * 16 + 4 * q;
       half4_t b = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-      if (a.bias && a.ksplit == 1) b = *(const half4_t*)(a.bias + nc);
+      if (a.bias) b = *(const half4_t*)(a.bias + nc);
 #pragma unroll
       for (int mt = 0; mt < BMT; ++mt) {
-        floatx4 v = acc[j][mt];
-#pragma unroll
-        for (int k = 1; k < WK; ++k) v += ex[((((k - 1) * 4 + wn) * TN + j) * BMT + mt) * 64 + lane];
         const int m = m0 + mt * 16 + n16;
         if (m < a.M) {
-          if (a.ksplit == 1) {
-            half4_t o;
+          half4_t o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[r] + (float)b[r]);
-            *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(a.Yacc + (size_t)m * a.N + nc + r, v[r]);
-          }
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[j][mt][r] + (float)b[r]);
+          *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
         }
       }
     }
@@ -496,7 +530,9 @@ struct Plan {
   int mt;      // skinny: token tiles per workgroup; tiled: BMT
   int waves;   // skinny: waves per workgroup
   bool xlds;   // skinny: x through an LDS copy
-  int ksplit;  // K slices across workgroups (fp32 atomics + finalize when > 1)
+  int ksplit;  // K slices across workgroups, reduced in-kernel by the last arriver
+  int ntiles;  // output tiles (one arrival counter each)
+  size_t slab_floats;  // fp32 elements of one partial tile
   int kt_per_split;
   int ablate;  // kernel bits 16-19: ablation variant of the tiled kernel (timing experiments only)
 };
@@ -529,30 +565,43 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   const int family = kernel & 15, mt_req = (kernel >> 4) & 15, waves_req = ((kernel >> 8) & 15) * 4;
   const bool no_xlds = (kernel >> 12) & 1;
   p.ablate = (kernel >> 16) & 31;
-  p.kernel = family == QUICK_KERNEL_AUTO ? (M <= 64 ? QUICK_KERNEL_SKINNY : QUICK_KERNEL_TILED) : family;
+  p.kernel = family == QUICK_KERNEL_AUTO ? (M <= 16 ? QUICK_KERNEL_SKINNY : QUICK_KERNEL_TILED) : family;
   int ks = 1;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
     p.mt = mt_req ? mt_req : (M <= 16 ? 1 : (M <= 32 ? 2 : 4));
     if (p.mt != 1 && p.mt != 2) p.mt = 4;
     p.waves = (waves_req == 4 || waves_req == 8 || waves_req == 16) ? waves_req : 8;
     const int mblocks = (M + p.mt * 16 - 1) / (p.mt * 16);
+    p.ntiles = (N / 16) * mblocks;
+    p.slab_floats = (size_t)p.mt * 256;
     // fill the 256 CUs when N is small: every workgroup should still own >= 8 k-tiles
-    while ((N / 16) * mblocks * ks < 256 && KT / (ks * 2) >= 8) ks *= 2;
+    while (p.ntiles * ks < 256 && KT / (ks * 2) >= 8) ks *= 2;
+    p.ksplit = std::max(1, std::min(grid_split_k > 0 ? grid_split_k : ks, KT));
+    p.kt_per_split = (KT + p.ksplit - 1) / p.ksplit;
   } else {
-    p.mt = mt_req == 2 ? 2 : 4;
+    p.mt = mt_req ? (mt_req == 2 ? 2 : (mt_req == 8 ? 8 : 4)) : (M <= 32 ? 2 : 4);
     p.waves = waves_req == 16 ? 16 : 8;
-    const int tiles = (N / 128) * ((M + p.mt * 16 - 1) / (p.mt * 16));
-    while (tiles * ks < 192 && KT / (ks * 2) >= 8) ks *= 2;
+    const int wk = p.waves / 4;
+    p.ntiles = (N / 128) * ((M + p.mt * 16 - 1) / (p.mt * 16));
+    p.slab_floats = (size_t)4 * 2 * p.mt * 256;
+    // one workgroup per CU: split K until the 256 CUs are covered, keeping >= 2 stages per slice
+    const int nstage = (KT + wk - 1) / wk;
+    while (p.ntiles * ks * 2 <= 256 && nstage / (ks * 2) >= 2) ks *= 2;
+    p.ksplit = std::max(1, std::min(grid_split_k > 0 ? grid_split_k : ks, nstage));
+    p.kt_per_split = ((nstage + p.ksplit - 1) / p.ksplit) * wk;  // whole stages
   }
-  p.ksplit = std::max(1, std::min(grid_split_k > 0 ? grid_split_k : ks, KT));
-  p.kt_per_split = (KT + p.ksplit - 1) / p.ksplit;
-  if (p.kernel == QUICK_KERNEL_TILED && p.ksplit > 1) p.kt_per_split = (p.kt_per_split + 3) & ~3;  // whole stages
   p.ksplit = (KT + p.kt_per_split - 1) / p.kt_per_split;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
     const int rows = std::min(M, 16);
     p.xlds = !no_xlds && p.mt == 1 && (size_t)rows * (p.kt_per_split * 256 + 16) <= (size_t)kSkinnyXldsBytes;
   }
   return p;
+}
+
+// workspace: [ntiles arrival counters, padded to 256 B][ntiles * ksplit fp32 slabs]
+static size_t counters_bytes(const Plan& p) { return (((size_t)p.ntiles * 4 + 255) / 256) * 256; }
+static size_t workspace_need(const Plan& p) {
+  return p.ksplit > 1 ? counters_bytes(p) + (size_t)p.ntiles * p.ksplit * p.slab_floats * sizeof(float) : 0;
 }
 
 static int group_mode(int G) { return G == 128 ? 0 : (G % 128 == 0 ? 1 : (G == 64 ? 2 : (G == 32 ? 3 : 4))); }
@@ -640,14 +689,14 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   if ((kernel & 15) > QUICK_KERNEL_TILED || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
   const Plan p = make_plan(M, K, N, kernel, grid_split_k);
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)bias,
-             (half_t*)y, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, nullptr};
+             (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, nullptr};
   if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
   if (p.ksplit > 1) {
-    const size_t need = (size_t)M * N * sizeof(float);
+    const size_t need = workspace_need(p);
     if (!workspace || workspace_bytes < need)
       return fail(QUICK_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
-    a.Yacc = (float*)workspace;
-    if (hipMemsetAsync(a.Yacc, 0, need, L.st) != hipSuccess) return fail(QUICK_ERR_LAUNCH, "hipMemsetAsync failed");
+    a.counters = (unsigned*)workspace;  // zero on entry (caller's contract), zero again when the launch completes
+    a.slabs = (float*)((char*)workspace + counters_bytes(p));
   }
   if (p.kernel == QUICK_KERNEL_SKINNY) {
     switch (p.mt) {
@@ -657,13 +706,9 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     }
   } else {
     if (p.mt == 2) launch_tiled<2, 2>(p, a, L);
+    else if (p.mt == 8) launch_tiled<8, 2>(p, a, L);
     else if (p.waves == 8) launch_tiled<4, 2>(p, a, L);
     else launch_tiled<4, 4>(p, a, L);
-  }
-  if (p.ksplit > 1) {
-    const size_t n4 = ((size_t)M * N + 3) / 4;
-    hipLaunchKernelGGL(w4a16_finalize_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, L.st, a.Yacc,
-                       (const half_t*)bias, (half_t*)y, M, N);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(QUICK_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
@@ -682,7 +727,7 @@ const char* quick_amd_last_error(void) { return g_err; }
 size_t quick_w4a16_workspace_bytes_ex(int M, int K, int N, int group_size, int kernel, int grid_split_k) {
   if (check_shapes(M, K, N, group_size) != QUICK_OK) return 0;
   const Plan p = make_plan(M, K, N, kernel, grid_split_k);
-  return p.ksplit > 1 ? (size_t)M * N * sizeof(float) : 0;
+  return workspace_need(p);
 }
 
 size_t quick_w4a16_workspace_bytes(int M, int K, int N, int group_size, int split_k_iters) {

@@ -32,6 +32,20 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_WORKSPACES = {}
+
+
+def _workspace(device, nbytes):
+    """Zero-filled scratch for the in-kernel split-K reduction, one per (device, stream), grown on demand.  The
+    library hands it back zeroed after every launch, so it is allocated and cleared only when it has to grow."""
+    key = (device.index, _stream())
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
 def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=KERNEL_AUTO, grid_split_k=0):
     """y [M, N] fp16 = in_feats [M, K] @ dequant(kernel, scaling_factors, zeros) (+ bias), MI355X-order weights."""
     _expect(in_feats, torch.float16, "in_feats")
@@ -51,11 +65,12 @@ def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=
         return out
     with torch.cuda.device(in_feats.device):          # OptionalCUDAGuard, gemm_cuda_quick.cu:1465
         ws_bytes = lib.quick_w4a16_workspace_bytes_ex(M, K, N, G, kernel_id, grid_split_k)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=in_feats.device) if ws_bytes else None
+        ws = _workspace(in_feats.device, ws_bytes) if ws_bytes else None
         rc = lib.quick_w4a16_gemm_f16_ex(
             in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
             bias.data_ptr() if bias is not None else None, out.data_ptr(),
-            ws.data_ptr() if ws is not None else None, ws_bytes, M, K, N, G, kernel_id, grid_split_k, _stream())
+            ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, M, K, N, G, kernel_id,
+            grid_split_k, _stream())
     if rc != _OK:
         _raise(rc)
     return out

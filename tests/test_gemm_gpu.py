@@ -197,6 +197,19 @@ def test_model_shapes(qa, device, K, N, M):
 # ------------------------------------------------------------------------------------------------
 # operator interface and error behaviour (csrc/gemm_cuda_quick.cu:1456-1517)
 # ------------------------------------------------------------------------------------------------
+def test_split_k_reduction_is_stable_across_many_launches(qa, device):
+    """In-kernel split-K (last arriver reduces): the arrival counters must come back to zero after every launch and the
+    result must not depend on which slice arrives last -- hammer it, alternating shapes that share the workspace."""
+    cases = []
+    for M, K, N, G in ((64, 4096, 1024, 128), (40, 2048, 512, 128), (8, 4096, 256, 128), (130, 2048, 256, 64)):
+        x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + N)
+        cases.append((_dev(x, device), _pack_dev(iw, s, z, device), oracle.w4a16_forward(x, iw, s, z, G)))
+    for rep in range(25):
+        for xd, packed, want in cases:
+            y = qa.gemm_forward(xd, *packed)
+            assert rel_err(y.cpu().numpy(), want) <= TOL, rep
+
+
 def test_reference_operator_signature_and_errors(qa, device):
     import quick_kernels
     M, K, N, G = 5, 256, 128, 128
