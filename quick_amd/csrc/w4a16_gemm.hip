@@ -71,106 +71,106 @@ __device__ __forceinline__ bool splitk_arrive(unsigned* counter, int nslices, un
 }
 
 // ------------------------------------------------------------------------------------------------
-// skinny kernel: one 16-channel tile per workgroup, K split over the waves of the workgroup (and over
-// blockIdx.z when N is small), up to MT token tiles of 16 kept in registers.
+// skinny kernel: one workgroup owns 16 tokens x (NTW*16) channels for the whole K; its waves split K (and
+// blockIdx.z splits it further when the grid would not fill the chip).
 // ------------------------------------------------------------------------------------------------
-// Every wave walks its k-tiles in chunks of U.  A chunk is LOADED (weights 16 B/lane/tile straight from
-// HBM, raw group constants, and -- unless x sits in LDS -- the B fragments from L2) one chunk ahead of
-// being COMPUTED, into the other of two register sets; the sched_barriers keep hipcc from sinking the
-// loads next to their uses, which would serialise one HBM round trip per tile.
+// Every wave walks its k-tiles in chunks of U.  A chunk is LOADED (weights 16 B/lane/tile straight from HBM, raw
+// group constants, and -- unless x sits in LDS -- the B fragments from L2, once per k-step for all NTW channel
+// tiles) one chunk ahead of being COMPUTED, into the other of two register sets; the sched_barriers keep hipcc
+// from sinking the loads next to their uses, which would serialise one HBM round trip per tile.
+// NTW trades workgroup count against x traffic: token blocks re-read the weights (L2 hits), channel blocks re-read
+// x, so NTW ~ number of token blocks keeps both at N/16 workgroups' worth.
 //
-// XLDS: the workgroup first copies x[rows, kbegin:kend] into LDS with coalesced 16-byte loads (row pitch
-// padded by 16 B so the token rows of a fragment read spread over the bank groups) and every B fragment
-// is a ds_read_b128 -- for M == 1 a 4-address broadcast -- instead of a 64-lane global load fetching
-// 64 B per token row, 15/16 of them wasted when M == 1.
-template <int MT, int GM, int U, bool XLDS>
+// XLDS: the workgroup first copies x[rows, kbegin:kend] into LDS with coalesced 16-byte loads (row pitch padded
+// by 16 B so the token rows of a fragment read spread over the bank groups) and every B fragment is a
+// ds_read_b128 -- for M == 1 a 4-address broadcast -- instead of a 64-lane global load fetching 64 B per token
+// row, 15/16 of them wasted when M == 1.
+template <int NTW, int GM, int U, bool XLDS>
 struct SkinnyChunk {
-  u32x4 w[U];
-  GroupRaw raw[U][groups_per_tile<GM>()];
-  half8_t xf[XLDS ? 1 : U][XLDS ? 1 : 4][XLDS ? 1 : MT];
+  u32x4 w[U][NTW];
+  GroupRaw raw[U][NTW][groups_per_tile<GM>()];
+  half8_t xf[XLDS ? 1 : U][XLDS ? 1 : 4];
 };
 
-template <int MT, int GM, int U, bool XLDS>
-__device__ __forceinline__ void skinny_load(SkinnyChunk<MT, GM, U, XLDS>& c, int kt, int kt_end,
-                                            const u32x4* __restrict__ wp, const half_t* const (&xp)[MT],
+template <int NTW, int GM, int U, bool XLDS>
+__device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS>& c, int kt, int kt_end,
+                                            const u32x4* __restrict__ wp, size_t wstride, const half_t* xp,
                                             const GemmArgs& a, int n) {
   constexpr int NG = groups_per_tile<GM>();
 #pragma unroll
-  for (int u = 0; u < U; ++u) c.w[u] = wp[(size_t)min(kt + u, kt_end - 1) * 64];  // past the end: replay, never used
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) c.w[u][j] = wp[j * wstride + (size_t)min(kt + u, kt_end - 1) * 64];  // past the end: replay
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int i = 0; i < NG; ++i)
-      c.raw[u][i] = load_group_raw(a.S, a.QZ, group_index<GM>(min(kt + u, kt_end - 1), i * (4 / NG), a.tpg, a.G), n, a.N);
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int i = 0; i < NG; ++i)
+        c.raw[u][j][i] = load_group_raw(a.S, a.QZ, group_index<GM>(min(kt + u, kt_end - 1), i * (4 / NG), a.tpg, a.G),
+                                        n + 16 * j, a.N);
   if constexpr (!XLDS) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) c.xf[u][t][mt] = *(const half8_t*)(xp[mt] + min(kt + u, kt_end - 1) * 128 + 32 * t);
+      for (int t = 0; t < 4; ++t) c.xf[u][t] = *(const half8_t*)(xp + min(kt + u, kt_end - 1) * 128 + 32 * t);
   }
 }
 
-template <int MT, int GM, int U, bool XLDS>
-__device__ __forceinline__ void skinny_compute(const SkinnyChunk<MT, GM, U, XLDS>& c, int kt, int kt_end, const char* xl,
-                                               const LaneSel& ls, floatx4 (&acc)[MT]) {
+template <int NTW, int GM, int U, bool XLDS>
+__device__ __forceinline__ void skinny_compute(const SkinnyChunk<NTW, GM, U, XLDS>& c, int kt, int kt_end, const char* xl,
+                                               const LaneSel& ls, floatx4 (&acc)[NTW]) {
   constexpr int NG = groups_per_tile<GM>();
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (kt + u < kt_end) {  // wave-uniform
-      GroupQ grp[NG];
+      GroupQ grp[NTW][NG];
 #pragma unroll
-      for (int i = 0; i < NG; ++i) grp[i] = make_group(c.raw[u][i], ls);
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int i = 0; i < NG; ++i) grp[j][i] = make_group(c.raw[u][j][i], ls);  // n and n + 16 j select alike
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const half8_t af = dequant8(c.w[u][t], grp[group_slot<GM>(t)]);
+        half8_t bf;
+        if constexpr (XLDS) bf = *(const half8_t*)(xl + ((kt + u) * 128 + 32 * t) * 2);
+        else bf = c.xf[u][t];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          half8_t bf;
-          if constexpr (XLDS) bf = *(const half8_t*)(xl + ((kt + u) * 128 + 32 * t) * 2);
-          else bf = c.xf[u][t][mt];
-          acc[mt] = mfma16(af, bf, acc[mt]);
-        }
+        for (int j = 0; j < NTW; ++j) acc[j] = mfma16(dequant8(c.w[u][j][t], grp[j][group_slot<GM>(t)]), bf, acc[j]);
       }
     }
   }
 }
 
-template <int MT, int WAVES, int GM, bool XLDS>
+template <int NTW, int WAVES, int GM, bool XLDS>
 __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
-  static_assert(WAVES >= MT, "reduction assigns one token tile per wave");
-  static_assert(!XLDS || MT == 1, "the LDS copy of x is for a single token tile");
-  constexpr int U = XLDS ? 4 : (MT == 1 ? 2 : 1);
+  static_assert(WAVES >= NTW, "the final reduction assigns one channel tile per wave");
+  constexpr int U = XLDS ? (NTW == 1 ? 4 : 2) : (NTW <= 2 ? 2 : 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  floatx4* red = (floatx4*)smem;  // [WAVES][MT][64]
-  char* xlds = smem + WAVES * MT * 64 * sizeof(floatx4);
+  floatx4* red = (floatx4*)smem;  // [WAVES][NTW][64]
+  char* xlds = smem + WAVES * NTW * 64 * sizeof(floatx4);
 
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
   const int n16 = lane & 15, q = lane >> 4;
-  const int nt = blockIdx.x, mb = blockIdx.y, ks = blockIdx.z;
+  const int nb = blockIdx.x, mb = blockIdx.y, ks = blockIdx.z;
   const int KT = a.K >> 7;
   const int wg_begin = ks * a.kt_per_split, wg_end = min(KT, wg_begin + a.kt_per_split);
   const int cnt = wg_end - wg_begin;
   const int kt_begin = wg_begin + cnt * wave / WAVES, kt_end = wg_begin + cnt * (wave + 1) / WAVES;
-  const int n = nt * 16 + n16;
+  const int n = nb * (16 * NTW) + n16;  // channel of this lane in channel tile 0 (tile j: + 16 j)
   const LaneSel ls = lane_sel(n);
 
-  const u32x4* wp = a.QW + (size_t)nt * KT * 64 + lane;
-  const half_t* xp[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int row = min((mb * MT + mt) * 16 + n16, a.M - 1);  // rows >= M replay row M-1; never stored
-    xp[mt] = a.X + (size_t)row * a.K + q * 8;
-  }
+  const size_t wstride = (size_t)KT * 64;  // u32x4 elements between consecutive channel tiles
+  const u32x4* wp = a.QW + (size_t)nb * NTW * wstride + lane;
+  const int row = min(mb * 16 + n16, a.M - 1);  // rows >= M replay row M-1; never stored
+  const half_t* xp = a.X + (size_t)row * a.K + q * 8;
 
-  floatx4 acc[MT];
+  floatx4 acc[NTW];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NTW; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  SkinnyChunk<MT, GM, U, XLDS> cA, cB;
-  if (kt_begin < kt_end) skinny_load<MT, GM, U, XLDS>(cA, kt_begin, kt_end, wp, xp, a, n);  // HBM requests go out first
+  SkinnyChunk<NTW, GM, U, XLDS> cA, cB;
+  if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt_begin, kt_end, wp, wstride, xp, a, n);  // HBM requests first
   __builtin_amdgcn_sched_barrier(0);
 
   const char* xl = nullptr;
@@ -189,37 +189,37 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   }
 
   for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
-    if (kt + U < kt_end) skinny_load<MT, GM, U, XLDS>(cB, kt + U, kt_end, wp, xp, a, n);
+    if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS>(cB, kt + U, kt_end, wp, wstride, xp, a, n);
     __builtin_amdgcn_sched_barrier(0);
-    skinny_compute<MT, GM, U, XLDS>(cA, kt, kt_end, xl, ls, acc);
+    skinny_compute<NTW, GM, U, XLDS>(cA, kt, kt_end, xl, ls, acc);
     if (kt + U >= kt_end) break;
-    if (kt + 2 * U < kt_end) skinny_load<MT, GM, U, XLDS>(cA, kt + 2 * U, kt_end, wp, xp, a, n);
+    if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt + 2 * U, kt_end, wp, wstride, xp, a, n);
     __builtin_amdgcn_sched_barrier(0);
-    skinny_compute<MT, GM, U, XLDS>(cB, kt + U, kt_end, xl, ls, acc);
+    skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, xl, ls, acc);
   }
 
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
+  for (int j = 0; j < NTW; ++j) red[(wave * NTW + j) * 64 + lane] = acc[j];
   __syncthreads();
   floatx4 sum = floatx4{0.f, 0.f, 0.f, 0.f};
-  if (wave < MT) {
+  if (wave < NTW) {
     sum = red[wave * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < WAVES; ++w) sum += red[(w * MT + wave) * 64 + lane];
+    for (int w = 1; w < WAVES; ++w) sum += red[(w * NTW + wave) * 64 + lane];
   }
   if (a.ksplit > 1) {
-    const int tile = mb * gridDim.x + nt;
-    float* slab0 = a.slabs + (size_t)tile * a.ksplit * (MT * 256);
-    if (wave < MT) *(floatx4*)(slab0 + (size_t)ks * (MT * 256) + (wave * 64 + lane) * 4) = sum;
+    const int tile = mb * gridDim.x + nb;
+    float* slab0 = a.slabs + (size_t)tile * a.ksplit * (NTW * 256);
+    if (wave < NTW) *(floatx4*)(slab0 + (size_t)ks * (NTW * 256) + (wave * 64 + lane) * 4) = sum;
     if (!splitk_arrive(a.counters + tile, a.ksplit, (unsigned*)smem)) return;
-    if (wave < MT) {
+    if (wave < NTW) {
       for (int o = 0; o < a.ksplit; ++o)
-        if (o != ks) sum += *(const floatx4*)(slab0 + (size_t)o * (MT * 256) + (wave * 64 + lane) * 4);
+        if (o != ks) sum += *(const floatx4*)(slab0 + (size_t)o * (NTW * 256) + (wave * 64 + lane) * 4);
     }
   }
-  if (wave < MT) {
-    const int m = (mb * MT + wave) * 16 + n16;
-    const int nc = nt * 16 + 4 * q;  // lane holds channels nc..nc+3 of token m
+  if (wave < NTW) {
+    const int m = mb * 16 + n16;
+    const int nc = (nb * NTW + wave) * 16 + 4 * q;  // lane holds channels nc..nc+3 of token m
     if (m < a.M) {
       if (a.bias) {
         const half4_t b = *(const half4_t*)(a.bias + nc);
@@ -527,7 +527,7 @@ static int fail(int code, const char* fmt, ...) {
 
 struct Plan {
   int kernel;  // QUICK_KERNEL_SKINNY / QUICK_KERNEL_TILED
-  int mt;      // skinny: token tiles per workgroup; tiled: BMT
+  int mt;      // skinny: channel tiles (of 16) per workgroup, NTW; tiled: token tiles per workgroup, BMT
   int waves;   // skinny: waves per workgroup
   bool xlds;   // skinny: x through an LDS copy
   int ksplit;  // K slices across workgroups, reduced in-kernel by the last arriver
@@ -565,14 +565,16 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   const int family = kernel & 15, mt_req = (kernel >> 4) & 15, waves_req = ((kernel >> 8) & 15) * 4;
   const bool no_xlds = (kernel >> 12) & 1;
   p.ablate = (kernel >> 16) & 31;
-  p.kernel = family == QUICK_KERNEL_AUTO ? (M <= 16 ? QUICK_KERNEL_SKINNY : QUICK_KERNEL_TILED) : family;
+  p.kernel = family == QUICK_KERNEL_AUTO ? (M <= 64 ? QUICK_KERNEL_SKINNY : QUICK_KERNEL_TILED) : family;
   int ks = 1;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
-    p.mt = mt_req ? mt_req : (M <= 16 ? 1 : (M <= 32 ? 2 : 4));
+    const int mblocks = (M + 15) / 16;
+    // channel tiles per workgroup ~ token blocks (weights are re-read per token block, x per channel block)
+    p.mt = mt_req ? mt_req : (mblocks <= 1 ? 1 : (mblocks <= 2 ? 2 : 4));
     if (p.mt != 1 && p.mt != 2) p.mt = 4;
+    while (p.mt > 1 && (N / 16) % p.mt != 0) p.mt /= 2;
     p.waves = (waves_req == 4 || waves_req == 8 || waves_req == 16) ? waves_req : 8;
-    const int mblocks = (M + p.mt * 16 - 1) / (p.mt * 16);
-    p.ntiles = (N / 16) * mblocks;
+    p.ntiles = (N / (16 * p.mt)) * mblocks;
     p.slab_floats = (size_t)p.mt * 256;
     // fill the 256 CUs when N is small: every workgroup should still own >= 8 k-tiles
     while (p.ntiles * ks < 256 && KT / (ks * 2) >= 8) ks *= 2;
@@ -593,7 +595,7 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   p.ksplit = (KT + p.kt_per_split - 1) / p.kt_per_split;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
     const int rows = std::min(M, 16);
-    p.xlds = !no_xlds && p.mt == 1 && (size_t)rows * (p.kt_per_split * 256 + 16) <= (size_t)kSkinnyXldsBytes;
+    p.xlds = !no_xlds && M <= 16 && (size_t)rows * (p.kt_per_split * 256 + 16) <= (size_t)kSkinnyXldsBytes;
   }
   return p;
 }
@@ -606,13 +608,13 @@ static size_t workspace_need(const Plan& p) {
 
 static int group_mode(int G) { return G == 128 ? 0 : (G % 128 == 0 ? 1 : (G == 64 ? 2 : (G == 32 ? 3 : 4))); }
 
-template <int MT, int WAVES, bool XLDS>
+template <int NTW, int WAVES, bool XLDS>
 static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) {
-  dim3 grid(a.N / 16, (a.M + MT * 16 - 1) / (MT * 16), p.ksplit), block(WAVES * 64);
-  size_t lds = (size_t)WAVES * MT * 1024;
+  dim3 grid(a.N / (16 * NTW), (a.M + 15) / 16, p.ksplit), block(WAVES * 64);
+  size_t lds = (size_t)WAVES * NTW * 1024;
   if (XLDS) lds += (size_t)std::min(a.M, 16) * (p.kt_per_split * 256 + 16);
-#define QA_SKINNY(GMV)                                                                                              \
-  hipExtLaunchKernelGGL((w4a16_skinny_kernel<MT, WAVES, GMV, XLDS>), grid, block, (unsigned)lds, L.st, L.start, L.stop, \
+#define QA_SKINNY(GMV)                                                                                               \
+  hipExtLaunchKernelGGL((w4a16_skinny_kernel<NTW, WAVES, GMV, XLDS>), grid, block, (unsigned)lds, L.st, L.start, L.stop, \
                         0, a)
   switch (group_mode(a.G)) {
     case 0: QA_SKINNY(0); break;
@@ -624,19 +626,17 @@ static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) 
 #undef QA_SKINNY
 }
 
-template <int MT>
+template <int NTW>
 static void launch_skinny(const Plan& p, const GemmArgs& a, const Launch& L) {
-  if constexpr (MT == 1) {
-    if (p.xlds) {
-      if (p.waves == 4) launch_skinny_gm<1, 4, true>(p, a, L);
-      else if (p.waves == 16) launch_skinny_gm<1, 16, true>(p, a, L);
-      else launch_skinny_gm<1, 8, true>(p, a, L);
-      return;
-    }
+  if (p.xlds) {
+    if (p.waves == 4) launch_skinny_gm<NTW, 4, true>(p, a, L);
+    else if (p.waves == 16) launch_skinny_gm<NTW, 16, true>(p, a, L);
+    else launch_skinny_gm<NTW, 8, true>(p, a, L);
+  } else {
+    if (p.waves == 4) launch_skinny_gm<NTW, 4, false>(p, a, L);
+    else if (p.waves == 16) launch_skinny_gm<NTW, 16, false>(p, a, L);
+    else launch_skinny_gm<NTW, 8, false>(p, a, L);
   }
-  if (p.waves == 4) launch_skinny_gm<MT, 4, false>(p, a, L);
-  else if (p.waves == 16) launch_skinny_gm<MT, 16, false>(p, a, L);
-  else launch_skinny_gm<MT, 8, false>(p, a, L);
 }
 
 template <int BMT, int WK>
