@@ -44,26 +44,31 @@ struct GemmArgs {
 
 // ------------------------------------------------------------------------------------------------
 // K split across workgroups, reduced inside the launch ("last arriver finishes the tile").
-// Every slice stores its fp32 partial tile to its slab (plain, fully coalesced stores), then calls
-// splitk_arrive(): per-wave drain -> workgroup barrier -> ONE lane: agent-scope release, ticket from the tile's
-// counter; the workgroup that draws the last ticket resets the counter (the workspace is handed back zeroed),
-// does ONE agent-scope acquire, and -- after a second barrier -- adds the other slabs to the partial it still
-// holds in registers.  No spinning, so no co-residency requirement; correctness does not depend on which XCD or
-// CU a slice ran on (release = L2 write-back, acquire = L1 invalidate, as in cdna_hip_programming.md G16).
-// Replaces the reference's fp16 `[split_k, M, N]` scratch + torch `.sum(0)` (csrc/gemm_cuda_quick.cu:1468, 1515).
+// Every slice writes its fp32 partial tile to its slab with WRITE-THROUGH (sc1) 16-byte stores, drains them
+// (per-wave vmcnt(0)), and after a workgroup barrier ONE lane draws a ticket from the tile's agent-scope
+// counter.  The workgroup that draws the last ticket resets the counter (the workspace is handed back zeroed)
+// and adds the other slices' slabs -- read with sc1 loads, which bypass the reader's possibly stale L1 -- to the
+// partial it still holds in registers.  No fences (a release would write back the whole XCD L2: 2-7 us under
+// load), no spinning (so no co-residency requirement), and nothing depends on which XCD or CU a slice ran on
+// (cdna_hip_programming.md G16, form R1).  Replaces the reference's fp16 `[split_k, M, N]` scratch + torch
+// `.sum(0)` (csrc/gemm_cuda_quick.cu:1468, 1515).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(float* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void slab_store(__amdgpu_buffer_rsrc_t r, unsigned byte_off, floatx4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, /*sc1*/ 16);
+}
+__device__ __forceinline__ floatx4 slab_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, /*sc1*/ 16));
+}
 __device__ __forceinline__ bool splitk_arrive(unsigned* counter, int nslices, unsigned* lds_word) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's slab stores have been issued to L2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have landed
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // keep the write-back ahead of the ticket (ROCm 7.2 may drop it)
     const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = t == (unsigned)nslices - 1u;
-    if (last) {
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *lds_word = last ? 1u : 0u;
   }
   __syncthreads();
@@ -209,12 +214,13 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   }
   if (a.ksplit > 1) {
     const int tile = mb * gridDim.x + nb;
-    float* slab0 = a.slabs + (size_t)tile * a.ksplit * (NTW * 256);
-    if (wave < NTW) *(floatx4*)(slab0 + (size_t)ks * (NTW * 256) + (wave * 64 + lane) * 4) = sum;
+    constexpr unsigned SLAB_BYTES = NTW * 1024;
+    const __amdgpu_buffer_rsrc_t rs = slab_rsrc(a.slabs + (size_t)tile * a.ksplit * (NTW * 256), a.ksplit * SLAB_BYTES);
+    if (wave < NTW) slab_store(rs, ks * SLAB_BYTES + (wave * 64 + lane) * 16, sum);
     if (!splitk_arrive(a.counters + tile, a.ksplit, (unsigned*)smem)) return;
     if (wave < NTW) {
       for (int o = 0; o < a.ksplit; ++o)
-        if (o != ks) sum += *(const floatx4*)(slab0 + (size_t)o * (NTW * 256) + (wave * 64 + lane) * 4);
+        if (o != ks) sum += slab_load(rs, o * SLAB_BYTES + (wave * 64 + lane) * 16);
     }
   }
   if (wave < NTW) {
@@ -447,24 +453,24 @@ k_loop_done:
         for (int k = 1; k < WK; ++k) acc[j][mt] += ex[((((k - 1) * 4 + wn) * TN + j) * BMT + mt) * 64 + lane];
   }
   if (a.ksplit > 1) {
-    constexpr int SLAB = 4 * TN * BMT * 256;  // floats per partial tile
-    float* slab0 = a.slabs + (size_t)blockIdx.x * a.ksplit * SLAB;
+    constexpr unsigned SLAB_BYTES = 4 * TN * BMT * 1024;  // one fp32 partial tile
+    const __amdgpu_buffer_rsrc_t rs =
+        slab_rsrc(a.slabs + (size_t)blockIdx.x * a.ksplit * (SLAB_BYTES / 4), a.ksplit * SLAB_BYTES);
+    const unsigned my = ((wn * TN) * BMT * 64 + lane) * 16;
     if (wk == 0) {
-      float* mine = slab0 + (size_t)ks * SLAB + ((wn * TN) * BMT * 64 + lane) * 4;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int mt = 0; mt < BMT; ++mt) *(floatx4*)(mine + (j * BMT + mt) * 256) = acc[j][mt];
+        for (int mt = 0; mt < BMT; ++mt) slab_store(rs, ks * SLAB_BYTES + my + (j * BMT + mt) * 1024, acc[j][mt]);
     }
     if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
     if (wk == 0) {
       for (int o = 0; o < a.ksplit; ++o) {
         if (o == ks) continue;
-        const float* other = slab0 + (size_t)o * SLAB + ((wn * TN) * BMT * 64 + lane) * 4;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int mt = 0; mt < BMT; ++mt) acc[j][mt] += *(const floatx4*)(other + (j * BMT + mt) * 256);
+          for (int mt = 0; mt < BMT; ++mt) acc[j][mt] += slab_load(rs, o * SLAB_BYTES + my + (j * BMT + mt) * 1024);
       }
     }
   }
