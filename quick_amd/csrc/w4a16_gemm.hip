@@ -583,7 +583,7 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
     p.ntiles = (N / (16 * p.mt)) * mblocks;
     p.slab_floats = (size_t)p.mt * 256;
     // fill the 256 CUs when N is small: every workgroup should still own >= 8 k-tiles
-    while (p.ntiles * ks < 256 && KT / (ks * 2) >= 8) ks *= 2;
+    while (p.ntiles * ks * 2 <= 256 && KT / (ks * 2) >= 8) ks *= 2;
     p.ksplit = std::max(1, std::min(grid_split_k > 0 ? grid_split_k : ks, KT));
     p.kt_per_split = (KT + p.ksplit - 1) / p.ksplit;
   } else {
