@@ -494,6 +494,234 @@ k_loop_done:
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// tiled kernel, 32x32x16 MFMA flavour.  Same workgroup tile, wave grid, LDS double buffer and pipeline as above,
+// but the matrix instruction is v_mfma_f32_32x32x16_f16: 32 cycles per instruction instead of 16, which -- unlike
+// the 16-cycle 16x16x32 -- leaves the SIMD free to issue ~4 VALU ops per MFMA (tools/mfma_valu_overlap.hip), so
+// part of the dequantisation hides under the matrix pipe inside ONE wave.
+//   A operand (32 channels x 16 k; lane l: channel l%32, k-half l/32): built from the raw packed dwords of TWO
+//     16-channel tiles -- whose lanes are (channel%16, k-octet l/16) -- with v_permlane16_swap + v_permlane32_swap:
+//     [r0.q0 r1.q0 | r0.q1 r1.q1] feeds the first k16 step of a k32 step, [r0.q2 r1.q2 | r0.q3 r1.q3] the second.
+//     The weight layout in HBM is unchanged.
+//   B operand (16 k x 32 tokens; lane l: token l%32, k-half l/32): the LDS image of a stage is
+//     [k-tile][k16 step 0..7][32-token tile][64 lanes x 16 B]; the staging loads keep the 16-row x 64-byte shape and
+//     each lane writes its 16 bytes to the slot the 32-wide fragment wants.
+//   C/D: lane l holds token l%32 and channels (r%4) + 8*(r/4) + 4*(l/32), r = 0..15, of the 32-channel pair.
+// ------------------------------------------------------------------------------------------------
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+
+template <int BMT, int TN, int WK>
+__device__ __forceinline__ void tiled32_store_x(const TiledCtx<BMT, TN, WK>& c, char* buf, int lane, const u32x4 (&xr)[BMT]) {
+  const int r16 = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < BMT; ++i) {
+    const int f = c.wave * BMT + i;  // wave-uniform: (k-tile, k32 step t, 16-token tile a)
+    const int kt = f / (4 * BMT), t = (f / BMT) & 3, a16 = f % BMT;
+    const int frag = (kt * 8 + 2 * t + (q >> 1)) * (BMT / 2) + (a16 >> 1);
+    *(u32x4*)(buf + frag * 1024 + (16 * (a16 & 1) + r16 + 32 * (q & 1)) * 16) = xr[i];
+  }
+}
+
+template <int BMT, int TN, int WK, int GM>
+__device__ __forceinline__ void tiled32_compute(const TiledCtx<BMT, TN, WK>& c, const char* sb, int s, const u32x4 (&w)[TN],
+                                                const uint32_t (&gs)[TN][groups_per_tile<GM>()],
+                                                const uint32_t (&gz)[TN][groups_per_tile<GM>()],
+                                                floatx16 (&acc)[TN / 2][BMT / 2], int lane) {
+  constexpr int NG = groups_per_tile<GM>();
+  if (c.kt_lo + WK * s + c.wk >= c.kt_hi) return;  // wave-uniform: a ragged last stage has no tile for this wave
+  // after the lane shuffle, lanes 16-31 and 48-63 hold the second tile of a pair: pick that tile's constants there
+  const bool second = (lane >> 4) & 1;
+  GroupQ grp[TN / 2][NG];
+#pragma unroll
+  for (int p = 0; p < TN / 2; ++p)
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const GroupRaw r{second ? gs[2 * p + 1][i] : gs[2 * p][i], second ? gz[2 * p + 1][i] : gz[2 * p][i]};
+      grp[p][i] = make_group(r, lane_sel(c.ncol[2 * p]));  // n%8 and n%2 are the same for both tiles of a pair
+    }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    uint32_t araw[TN / 2][2];
+#pragma unroll
+    for (int p = 0; p < TN / 2; ++p) {
+      const u32x2v s1 = __builtin_amdgcn_permlane16_swap(w[2 * p][t], w[2 * p + 1][t], false, false);
+      const u32x2v s2 = __builtin_amdgcn_permlane32_swap(s1[0], s1[1], false, false);
+      araw[p][0] = s2[0];
+      araw[p][1] = s2[1];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      half8_t bf[BMT / 2];
+#pragma unroll
+      for (int m2 = 0; m2 < BMT / 2; ++m2) bf[m2] = *(const half8_t*)(sb + ((2 * t + kk) * (BMT / 2) + m2) * 1024);
+#pragma unroll
+      for (int p = 0; p < TN / 2; ++p) {
+        const half8_t af = dequant8(araw[p][kk], grp[p][group_slot<GM>(t)]);
+#pragma unroll
+        for (int m2 = 0; m2 < BMT / 2; ++m2)
+          acc[p][m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[m2], acc[p][m2], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int BMT, int TN, int WK, int GM>
+__global__ __launch_bounds__(256 * WK) void w4a16_tiled32_kernel(const GemmArgs a) {
+  static_assert(TN % 2 == 0 && BMT % 2 == 0, "32x32 tiles pair up 16-channel and 16-token tiles");
+  constexpr int NG = groups_per_tile<GM>();
+  constexpr int FRAGS = 4 * WK * BMT;
+  constexpr int STAGE_BYTES = FRAGS * 1024;
+  static_assert((WK - 1) * 4 * TN * BMT * 1024 <= 2 * STAGE_BYTES, "epilogue exchange must fit in the stage buffers");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE_BYTES
+
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int wn = wave & 3, wk = wave >> 2;
+  const int n16 = lane & 15, q = lane >> 4;
+  const int NB = a.N / (64 * TN);
+  const int nb = blockIdx.x % NB, mb = blockIdx.x / NB, ks = blockIdx.y;
+  const int KT = a.K >> 7;
+  TiledCtx<BMT, TN, WK> c;
+  c.kt_lo = ks * a.kt_per_split;
+  c.kt_hi = min(KT, c.kt_lo + a.kt_per_split);
+  c.wave = wave;
+  c.wk = wk;
+  const int nstage = (c.kt_hi - c.kt_lo + WK - 1) / WK;
+  const int m0 = mb * BMT * 16;
+  const int nt0 = (nb * 4 + wn) * TN;
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    c.wp[j] = a.QW + (size_t)(nt0 + j) * KT * 64 + lane;
+    c.ncol[j] = (nt0 + j) * 16 + n16;
+  }
+#pragma unroll
+  for (int i = 0; i < BMT; ++i) {
+    const int f = wave * BMT + i, t = (f / BMT) & 3, mt = f % BMT;
+    c.xkt[i] = f / (4 * BMT);
+    const int row = min(m0 + mt * 16 + n16, a.M - 1);
+    c.xsrc[i] = a.X + (size_t)row * a.K + 32 * t + 8 * q;
+  }
+
+  floatx16 acc[TN / 2][BMT / 2];
+#pragma unroll
+  for (int p = 0; p < TN / 2; ++p)
+#pragma unroll
+    for (int m2 = 0; m2 < BMT / 2; ++m2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][m2][r] = 0.f;
+
+  u32x4 xr[BMT];
+  u32x4 w[2][TN];
+  uint32_t gs[2][TN][NG], gz[2][TN][NG];
+  const int rd = wk * (4 * BMT * 1024) + lane * 16;
+
+  if (nstage > 0) {
+    tiled_load_w<BMT, TN, WK, GM>(c, a, 0, w[0], gs[0], gz[0]);
+    tiled_load_x<BMT, TN, WK>(c, 0, xr);
+    tiled_load_w<BMT, TN, WK, GM>(c, a, 1, w[1], gs[1], gz[1]);
+    tiled32_store_x<BMT, TN, WK>(c, smem, lane, xr);
+    tiled_load_x<BMT, TN, WK>(c, 1, xr);
+  }
+  __syncthreads();
+
+  for (int s0 = 0; s0 < nstage; s0 += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int s = s0 + u;
+      if (s >= nstage) goto k_loop_done;
+      char* const cur = smem + u * STAGE_BYTES;
+      char* const nxt = smem + (u ^ 1) * STAGE_BYTES;
+      tiled32_store_x<BMT, TN, WK>(c, nxt, lane, xr);
+      tiled_load_x<BMT, TN, WK>(c, s + 2, xr);
+      tiled32_compute<BMT, TN, WK, GM>(c, cur + rd, s, w[u], gs[u], gz[u], acc, lane);
+      tiled_load_w<BMT, TN, WK, GM>(c, a, s + 2, w[u], gs[u], gz[u]);
+      __syncthreads();
+    }
+  }
+k_loop_done:
+
+  // per-lane accumulator chunk (p, m2, r4): channels nt0*16 + p*32 + 8*r4 + 4*(lane/32) .. +3 of token m0 + m2*32 + lane%32
+  constexpr int CH = (TN / 2) * (BMT / 2) * 4;  // floatx4 chunks per lane
+  floatx4* ex = (floatx4*)smem;                 // [wk-1][wn][chunk][lane]
+  auto chunk = [&](int p, int m2, int r4) {
+    return floatx4{acc[p][m2][4 * r4], acc[p][m2][4 * r4 + 1], acc[p][m2][4 * r4 + 2], acc[p][m2][4 * r4 + 3]};
+  };
+  if (wk > 0) {
+#pragma unroll
+    for (int p = 0; p < TN / 2; ++p)
+#pragma unroll
+      for (int m2 = 0; m2 < BMT / 2; ++m2)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          ex[(((wk - 1) * 4 + wn) * CH + (p * (BMT / 2) + m2) * 4 + r4) * 64 + lane] = chunk(p, m2, r4);
+  }
+  __syncthreads();
+  floatx4 v[TN / 2][BMT / 2][4];
+  if (wk == 0) {
+#pragma unroll
+    for (int p = 0; p < TN / 2; ++p)
+#pragma unroll
+      for (int m2 = 0; m2 < BMT / 2; ++m2)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          v[p][m2][r4] = chunk(p, m2, r4);
+#pragma unroll
+          for (int k = 1; k < WK; ++k) v[p][m2][r4] += ex[(((k - 1) * 4 + wn) * CH + (p * (BMT / 2) + m2) * 4 + r4) * 64 + lane];
+        }
+  }
+  if (a.ksplit > 1) {
+    constexpr unsigned SLAB_BYTES = 4 * TN * BMT * 1024;
+    const __amdgpu_buffer_rsrc_t rs =
+        slab_rsrc(a.slabs + (size_t)blockIdx.x * a.ksplit * (SLAB_BYTES / 4), a.ksplit * SLAB_BYTES);
+    const unsigned my = (wn * CH * 64 + lane) * 16;
+    if (wk == 0) {
+#pragma unroll
+      for (int p = 0; p < TN / 2; ++p)
+#pragma unroll
+        for (int m2 = 0; m2 < BMT / 2; ++m2)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4)
+            slab_store(rs, ks * SLAB_BYTES + my + ((p * (BMT / 2) + m2) * 4 + r4) * 1024, v[p][m2][r4]);
+    }
+    if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
+    if (wk == 0) {
+      for (int o = 0; o < a.ksplit; ++o) {
+        if (o == ks) continue;
+#pragma unroll
+        for (int p = 0; p < TN / 2; ++p)
+#pragma unroll
+          for (int m2 = 0; m2 < BMT / 2; ++m2)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+              v[p][m2][r4] += slab_load(rs, o * SLAB_BYTES + my + ((p * (BMT / 2) + m2) * 4 + r4) * 1024);
+      }
+    }
+  }
+  if (wk == 0) {
+    const int tok = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int p = 0; p < TN / 2; ++p)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int nc = (nt0 + 2 * p) * 16 + 8 * r4 + 4 * half;
+        half4_t b = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        if (a.bias) b = *(const half4_t*)(a.bias + nc);
+#pragma unroll
+        for (int m2 = 0; m2 < BMT / 2; ++m2) {
+          const int m = m0 + m2 * 32 + tok;
+          if (m < a.M) {
+            half4_t o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[p][m2][r4][r] + (float)b[r]);
+            *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
+          }
+        }
+      }
+  }
+}
+
 // empty kernel with the GEMM's launch shape: what the dispatch-duration clock reads with no work at all
 __global__ __launch_bounds__(512) void w4a16_empty_kernel(unsigned* sink) {
   if (sink != nullptr && threadIdx.x == 0xffffffffu) sink[0] = 1;
@@ -540,7 +768,8 @@ struct Plan {
   int ntiles;  // output tiles (one arrival counter each)
   size_t slab_floats;  // fp32 elements of one partial tile
   int kt_per_split;
-  int ablate;  // kernel bits 16-19: ablation variant of the tiled kernel (timing experiments only)
+  int ablate;  // kernel bits 16-20: ablation variant of the tiled kernel (timing experiments only)
+  bool mfma32; // tiled: v_mfma_f32_32x32x16_f16 flavour (kernel bit 13 selects the 16x16x32 one)
 };
 
 // Where the main kernel goes: the stream, plus an optional event pair bound to that one dispatch
@@ -571,6 +800,7 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   const int family = kernel & 15, mt_req = (kernel >> 4) & 15, waves_req = ((kernel >> 8) & 15) * 4;
   const bool no_xlds = (kernel >> 12) & 1;
   p.ablate = (kernel >> 16) & 31;
+  p.mfma32 = !((kernel >> 13) & 1) && p.ablate == 0;
   p.kernel = family == QUICK_KERNEL_AUTO ? (M <= 64 ? QUICK_KERNEL_SKINNY : QUICK_KERNEL_TILED) : family;
   int ks = 1;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
@@ -676,6 +906,27 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
       case 23: QA_TILED_K(0, 23); return;
       default: break;
     }
+  }
+  if (p.mfma32) {
+#define QA_TILED32_K(GMV)                                                                                          \
+  do {                                                                                                             \
+    auto kfn = w4a16_tiled32_kernel<BMT, TN, WK, GMV>;                                                             \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
+  } while (0)
+    switch (group_mode(a.G)) {
+      case 0: QA_TILED32_K(0); break;
+      case 1: QA_TILED32_K(1); break;
+      case 2: QA_TILED32_K(2); break;
+      case 3: QA_TILED32_K(3); break;
+      default: QA_TILED32_K(4); break;
+    }
+#undef QA_TILED32_K
+    return;
   }
   switch (group_mode(a.G)) {
     case 0: QA_TILED_K(0, 0); break;
