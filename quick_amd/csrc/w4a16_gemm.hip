@@ -769,7 +769,7 @@ struct Plan {
   size_t slab_floats;  // fp32 elements of one partial tile
   int kt_per_split;
   int ablate;  // kernel bits 16-20: ablation variant of the tiled kernel (timing experiments only)
-  bool mfma32; // tiled: v_mfma_f32_32x32x16_f16 flavour (kernel bit 13 selects the 16x16x32 one)
+  bool mfma32; // tiled: v_mfma_f32_32x32x16_f16 flavour (kernel bit 13; measured slower than 16x16x32 in r01)
 };
 
 // Where the main kernel goes: the stream, plus an optional event pair bound to that one dispatch
@@ -800,7 +800,7 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   const int family = kernel & 15, mt_req = (kernel >> 4) & 15, waves_req = ((kernel >> 8) & 15) * 4;
   const bool no_xlds = (kernel >> 12) & 1;
   p.ablate = (kernel >> 16) & 31;
-  p.mfma32 = !((kernel >> 13) & 1) && p.ablate == 0;
+  p.mfma32 = ((kernel >> 13) & 1) && p.ablate == 0;
   p.kernel = family == QUICK_KERNEL_AUTO ? (M <= 64 ? QUICK_KERNEL_SKINNY : QUICK_KERNEL_TILED) : family;
   int ks = 1;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
