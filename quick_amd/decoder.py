@@ -1,0 +1,171 @@
+"""Synthetic Llama-like decoder stack that calls the W4A16 operator at the real layer shapes.
+
+This is the caller side of the hot path: the counterpart, for measurement only, of the
+reference's fused runtime (quick/awq/modules/fused/{model,block,attn}.py) and of examples/benchmark.py.  There are no
+checkpoints or network here, so weights are random packed tensors of the right shapes; attention, RMSNorm, RoPE and the
+KV cache are plain torch-ROCm ops (the reference uses out-of-tree awq_ext / awq_ft_ext kernels for those); every
+quantised projection goes through ``WQLinear_QUICK`` -> libquick_amd.so.
+
+Differences from the reference's layer wiring, both on the GEMM side of the boundary:
+  * q/k/v are one fused GEMM also for GQA models (the reference's QUICK_cat rejects unequal widths);
+  * gate_proj and up_proj are one GEMM of width 2*intermediate (the intent of the reference's unused QuantFusedMLP,
+    quick/awq/modules/fused/mlp.py:52-71), followed by a torch SiLU*mul.
+"""
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from .linear import WQLinear_QUICK
+
+
+@dataclass
+class DecoderConfig:
+    name: str
+    hidden: int
+    layers: int
+    heads: int
+    kv_heads: int
+    intermediate: int
+    vocab: int = 32000
+    group_size: int = 128
+    rope_theta: float = 10000.0
+
+    @property
+    def head_dim(self):
+        return self.hidden // self.heads
+
+
+CONFIGS = {
+    "llama2-7b": DecoderConfig("Llama-2-7B", 4096, 32, 32, 32, 11008),
+    "mistral-7b": DecoderConfig("Mistral-7B", 4096, 32, 32, 8, 14336),
+    "llama2-70b": DecoderConfig("Llama-2-70B", 8192, 80, 64, 8, 28672),
+    "tiny": DecoderConfig("tiny-test", 256, 2, 4, 2, 512, vocab=512),
+}
+
+
+def random_wqlinear(K, N, G, device, gen):
+    """A WQLinear_QUICK whose buffers are random bits already in MI355X order (timing only)."""
+    m = WQLinear_QUICK(4, G, K, N, False, device)
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 4, N // 2), dtype=torch.int32, device=device, generator=gen)
+    sc = torch.zeros((K // G, 2 * N), dtype=torch.float16, device=device)
+    sc[:, :N] = (torch.rand((K // G, N), device=device, generator=gen) * 0.004 + 0.001).half()
+    qz = torch.zeros((K // G, N // 4), dtype=torch.int32, device=device)
+    qz[:, :N // 8] = 0x88888888 - 2 ** 32        # zero point 8 everywhere: weights centred on 0
+    m._set_packed(qw, sc, qz, prepared=True)
+    return m
+
+
+def _rms_norm(x, w, eps=1e-5):
+    v = x.float()
+    return (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype) * w
+
+
+def _rope(x, cos, sin):
+    # x [B, H, T, D]; cos/sin [T, D] (HF rotate-half convention)
+    d = x.shape[-1] // 2
+    rot = torch.cat((-x[..., d:], x[..., :d]), dim=-1)
+    return x * cos + rot * sin
+
+
+class SyntheticDecoder:
+    def __init__(self, cfg: DecoderConfig, batch, max_len, device, seed=0):
+        self.cfg, self.B, self.max_len, self.dev = cfg, batch, max_len, device
+        g = torch.Generator(device=device).manual_seed(seed)
+        H, KV, D, I, G = cfg.hidden, cfg.kv_heads * cfg.head_dim, cfg.head_dim, cfg.intermediate, cfg.group_size
+        self.layers = []
+        for _ in range(cfg.layers):
+            self.layers.append(dict(
+                qkv=random_wqlinear(H, H + 2 * KV, G, device, g), o=random_wqlinear(H, H, G, device, g),
+                gate_up=random_wqlinear(H, 2 * I, G, device, g), down=random_wqlinear(I, H, G, device, g),
+                ln1=torch.ones(H, dtype=torch.float16, device=device), ln2=torch.ones(H, dtype=torch.float16, device=device),
+                k=torch.zeros(batch, cfg.kv_heads, max_len, D, dtype=torch.float16, device=device),
+                v=torch.zeros(batch, cfg.kv_heads, max_len, D, dtype=torch.float16, device=device)))
+        self.embed = (torch.randn(cfg.vocab, H, device=device, generator=g) * 0.02).half()
+        self.lm_head = (torch.randn(cfg.vocab, H, device=device, generator=g) * 0.02).half()
+        self.norm = torch.ones(H, dtype=torch.float16, device=device)
+        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, device=device).float() / D))
+        ang = torch.outer(torch.arange(max_len, device=device).float(), inv)
+        self.cos = torch.cat((ang.cos(), ang.cos()), -1).half()
+        self.sin = torch.cat((ang.sin(), ang.sin()), -1).half()
+
+    def weight_bytes(self):
+        return sum(l[k].qweight.numel() * 4 for l in self.layers for k in ("qkv", "o", "gate_up", "down"))
+
+    @torch.no_grad()
+    def forward(self, tokens, pos, mask):
+        """tokens [B, T] int64; pos int64 [T] (positions being written); mask additive [1, 1, T, max_len] or None for
+        causal prefill from position 0.  Returns the next-token ids [B] (argmax of the last position's logits)."""
+        cfg, B, T = self.cfg, tokens.shape[0], tokens.shape[1]
+        H, nh, nkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
+        x = self.embed[tokens]                                        # [B, T, H]
+        cos, sin = self.cos.index_select(0, pos), self.sin.index_select(0, pos)
+        for l in self.layers:
+            h = _rms_norm(x, l["ln1"])
+            qkv = l["qkv"](h)                                          # W4A16 GEMM, M = B*T
+            q, k, v = qkv.split((H, nkv * D, nkv * D), dim=-1)
+            q = _rope(q.view(B, T, nh, D).transpose(1, 2), cos, sin)
+            k = _rope(k.view(B, T, nkv, D).transpose(1, 2), cos, sin)
+            v = v.view(B, T, nkv, D).transpose(1, 2)
+            l["k"].index_copy_(2, pos, k)
+            l["v"].index_copy_(2, pos, v)
+            if mask is None:                                           # prefill from an empty cache: causal over T
+                att = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=nkv != nh)
+            else:
+                att = F.scaled_dot_product_attention(q, l["k"], l["v"], attn_mask=mask, enable_gqa=nkv != nh)
+            x = x + l["o"](att.transpose(1, 2).reshape(B, T, H))       # W4A16 GEMM
+            h = _rms_norm(x, l["ln2"])
+            gu = l["gate_up"](h)                                       # W4A16 GEMM, N = 2*intermediate
+            gate, up = gu.split(cfg.intermediate, dim=-1)
+            x = x + l["down"](F.silu(gate) * up)                       # W4A16 GEMM
+        logits = _rms_norm(x[:, -1], self.norm) @ self.lm_head.t()
+        return logits.argmax(-1)
+
+
+@torch.no_grad()
+def run_generation(model: SyntheticDecoder, ctx, n_generate, use_graph=True):
+    """examples/benchmark.py:38-67 methodology: events around every forward; prefill = iteration 0, decode = the rest.
+    Returns (prefill_seconds, [decode step seconds])."""
+    B, dev, L = model.B, model.dev, model.max_len
+    assert ctx + n_generate <= L
+    tokens = torch.randint(0, model.cfg.vocab, (B, ctx), device=dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    s, e = ev(), ev()
+    s.record()
+    nxt = model.forward(tokens, torch.arange(ctx, device=dev), None)
+    e.record()
+    torch.cuda.synchronize()
+    prefill = s.elapsed_time(e) * 1e-3
+
+    # decode: static tensors so that one step can be captured in a hipGraph and replayed
+    tok = nxt.view(B, 1).clone()
+    pos = torch.full((1,), ctx, dtype=torch.int64, device=dev)
+    mask = torch.full((1, 1, 1, L), float("-inf"), dtype=torch.float16, device=dev)
+    mask[..., :ctx] = 0
+
+    def step():
+        mask.index_fill_(3, pos, 0.0)
+        out = model.forward(tok, pos, mask)
+        tok.copy_(out.view(B, 1))
+        pos.add_(1)
+
+    graph = None
+    if use_graph:
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):      # warm-up on a side stream, as torch requires before capture
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        n_generate -= 2                     # two steps were spent on warm-up and capture
+    times = []
+    for _ in range(n_generate):
+        s.record()
+        graph.replay() if graph is not None else step()
+        e.record()
+        torch.cuda.synchronize()
+        times.append(s.elapsed_time(e) * 1e-3)
+    return prefill, times
