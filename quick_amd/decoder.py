@@ -160,7 +160,7 @@ def run_generation(model: SyntheticDecoder, ctx, n_generate, use_graph=True):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step()
-        n_generate -= 2                     # two steps were spent on warm-up and capture
+        n_generate -= 1                     # one step was executed by the warm-up (capture executes nothing)
     times = []
     for _ in range(n_generate):
         s.record()

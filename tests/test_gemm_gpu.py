@@ -268,6 +268,6 @@ def test_synthetic_decoder_graph_replay_matches_eager(qa, device):
         torch.manual_seed(0)
         model = SyntheticDecoder(CONFIGS["tiny"], batch=3, max_len=48, device=device, seed=1)
         prefill, steps = run_generation(model, ctx=16, n_generate=12, use_graph=use_graph)
-        assert prefill > 0 and len(steps) == (10 if use_graph else 12) and all(t > 0 for t in steps)
+        assert prefill > 0 and len(steps) == (11 if use_graph else 12) and all(t > 0 for t in steps)
         toks.append(model.layers[0]["k"][:, :, :28].clone())        # the KV cache written by the 12 steps
     assert torch.equal(toks[0], toks[1])
