@@ -88,6 +88,14 @@ int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scal
                             void* hip_stream);
 size_t quick_w4a16_workspace_bytes_ex(int M, int K, int N, int group_size, int kernel, int grid_split_k);
 
+/* _ex plus an optional fp16 residual[M, N] added in the epilogue (y = x @ W + bias + residual in fp32, one rounding):
+ * the decoder block's `hidden + o_proj(...)` / `hidden + down_proj(...)` without a separate add kernel.
+ * `residual` may alias `y`. */
+int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* scales, const void* qzeros,
+                               const void* bias, const void* residual, void* y, void* workspace,
+                               size_t workspace_bytes, int M, int K, int N, int group_size, int kernel,
+                               int grid_split_k, void* hip_stream);
+
 /*
  * Measurement aid (bench.py): enqueue the GEMM `iters` times on `hip_stream`, cycling through `n_sets`
  * weight sets (host arrays of device pointers) so that consecutive launches do not hit in the 256 MiB
@@ -103,6 +111,26 @@ int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const v
 /* Measurement aid: the same event-pair clock on `iters` dispatches of an EMPTY kernel with the GEMM's launch
  * shape (256 workgroups x 512 threads): the fixed part of every "kernel duration" reading on this stack. */
 int quick_amd_dispatch_floor(int iters, float* kernel_us, void* hip_stream);
+
+/*
+ * Decode-step glue around the GEMMs (callers of the hot path; counterparts of the out-of-tree kernels the
+ * reference's fused runtime uses: awq_ext.layernorm_forward_cuda, quick/awq/modules/fused/norm.py:18;
+ * awq_ft_ext.single_query_attention, quick/awq/modules/fused/attn.py:217).  fp16 tensors, fp32 arithmetic.
+ *   quick_rmsnorm_f16          y[r,:] = x[r,:] * rsqrt(mean(x[r,:]^2) + eps) * weight
+ *   quick_rope_kv_append_f16   one new token per sequence: rotate q, k of qkv[B, (nh+2nkv)*D] by table row *pos
+ *                              (rotate-half convention), q -> q_out[B, nh, D], k/v -> caches [B, nkv, L, D] at *pos
+ *   quick_decode_attention_f16 single-query attention over cache positions 0..*pos, GQA aware, D == 128
+ *   quick_silu_mul_f16         y[m, i] = silu(gate_up[m, i]) * gate_up[m, I + i]
+ * `pos` is a DEVICE pointer to one int64 (so a captured hipGraph can advance it).
+ */
+int quick_rmsnorm_f16(const void* x, const void* weight, void* y, int rows, int hidden, float eps, void* hip_stream);
+int quick_rope_kv_append_f16(const void* qkv, const void* cos_table, const void* sin_table, const void* pos,
+                             void* q_out, void* k_cache, void* v_cache, int batch, int n_heads, int n_kv_heads,
+                             int head_dim, int cache_len, void* hip_stream);
+int quick_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* pos, void* out,
+                               int batch, int n_heads, int n_kv_heads, int head_dim, int cache_len, float scale,
+                               void* hip_stream);
+int quick_silu_mul_f16(const void* gate_up, void* y, int rows, int intermediate, void* hip_stream);
 
 /*
  * Format bridge.  "cuda order" is byte-for-byte what the reference's WQLinear_QUICK.from_linear

@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libquick_amd.so")
-SOURCES = ["w4a16_gemm.hip", "repack.hip"]
+SOURCES = ["w4a16_gemm.hip", "repack.hip", "decode_ops.hip"]
 HEADERS = ["w4a16_common.hpp", os.path.join("..", "..", "include", "quick_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
 

@@ -1,0 +1,205 @@
+// Glue kernels of the decode step around the W4A16 GEMMs (callers of the hot path):
+// RMSNorm, RoPE + KV-cache append, single-query attention, SiLU*mul.  The reference gets these from out-of-tree
+// extensions (awq_ext.layernorm_forward_cuda, quick/awq/modules/fused/norm.py:18; awq_ft_ext.single_query_attention,
+// quick/awq/modules/fused/attn.py:217) or from eager torch (attn.py:166-210); here they are small HBM/latency-bound
+// HIP kernels so that one decode layer is 9 launches instead of ~40.  fp16 in/out, fp32 arithmetic.
+#include "w4a16_common.hpp"
+#include "../../include/quick_amd.h"
+
+namespace quick_amd {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// y[r, :] = x[r, :] * rsqrt(mean(x[r, :]^2) + eps) * w      one 256-thread workgroup per row, H % 8 == 0
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                                      half_t* __restrict__ y, int H, float eps) {
+  __shared__ float part[4];
+  const half_t* xr = x + (size_t)blockIdx.x * H;
+  float ss = 0.f;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    const half8_t v = *(const half8_t*)(xr + i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float inv = rsqrtf((part[0] + part[1] + part[2] + part[3]) / H + eps);
+  half_t* yr = y + (size_t)blockIdx.x * H;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    const half8_t v = *(const half8_t*)(xr + i), g = *(const half8_t*)(w + i);
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((half_t)((float)v[j] * inv) * g[j]);  // cast, then scale: torch order
+    *(half8_t*)(yr + i) = o;
+  }
+}
+
+// Decode step (one new token per sequence).  qkv [B, (nh + 2 nkv) * D] as produced by the fused qkv GEMM; rotates q
+// and k by the angle table row `*pos` (HF rotate-half convention), writes q to q_out [B, nh, D] and appends k, v to
+// the caches [B, nkv, L, D] at position *pos.  One workgroup per (sequence, head slot), D/2 active lanes.
+__global__ __launch_bounds__(64) void rope_kv_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t,
+                                                     const half_t* __restrict__ sin_t, const long* __restrict__ pos,
+                                                     half_t* __restrict__ q_out, half_t* __restrict__ k_cache,
+                                                     half_t* __restrict__ v_cache, int nh, int nkv, int D, int L) {
+  const int b = blockIdx.y, slot = blockIdx.x;  // slot: 0..nh-1 q heads, nh..nh+nkv-1 k heads, then v heads
+  const long p = pos[0];
+  const half_t* src = qkv + (size_t)b * (nh + 2 * nkv) * D + (size_t)slot * D;
+  const int i = threadIdx.x;
+  if (i >= D / 2) return;
+  if (slot < nh + nkv) {
+    const float x0 = (float)src[i], x1 = (float)src[i + D / 2];
+    const float c0 = (float)cos_t[p * D + i], s0 = (float)sin_t[p * D + i];
+    const float c1 = (float)cos_t[p * D + i + D / 2], s1 = (float)sin_t[p * D + i + D / 2];
+    // torch reference: x * cos + rotate_half(x) * sin, every product and the sum rounded to fp16
+    const half_t r0 = (half_t)((float)(half_t)(x0 * c0) + (float)(half_t)(-x1 * s0));
+    const half_t r1 = (half_t)((float)(half_t)(x1 * c1) + (float)(half_t)(x0 * s1));
+    half_t* dst = slot < nh ? q_out + ((size_t)b * nh + slot) * D
+                            : k_cache + (((size_t)b * nkv + (slot - nh)) * L + p) * D;
+    dst[i] = r0;
+    dst[i + D / 2] = r1;
+  } else {
+    half_t* dst = v_cache + (((size_t)b * nkv + (slot - nh - nkv)) * L + p) * D;
+    dst[i] = src[i];
+    dst[i + D / 2] = src[i + D / 2];
+  }
+}
+
+// Single-query attention over positions 0..*pos (inclusive), GQA aware.  One 256-thread workgroup per
+// (sequence, query head); D == 128.  Scores in fp32, two passes over K then V from HBM/L2 (the cache of one head at a
+// few hundred positions is tens of KB).  out [B, nh * D].
+__global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k_cache,
+                                                               const half_t* __restrict__ v_cache, const long* __restrict__ pos,
+                                                               half_t* __restrict__ out, int nh, int nkv, int L, float scale) {
+  constexpr int D = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sc = (float*)smem_raw;             // [len] scores / probabilities
+  float* red = sc + ((L + 3) & ~3);         // [4] per-wave partials, then [4][D] output partials
+  const int b = blockIdx.y, h = blockIdx.x, kvh = h / (nh / nkv);
+  const int len = (int)pos[0] + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const half_t* qp = q + ((size_t)b * nh + h) * D;
+  const half_t* kp = k_cache + ((size_t)b * nkv + kvh) * L * D;
+  const half_t* vp = v_cache + ((size_t)b * nkv + kvh) * L * D;
+
+  // scores: 16 lanes per key row (8 fp16 each), 4 rows per wave per step
+  const int sub = lane & 15, rsel = lane >> 4;
+  const half8_t qv = *(const half8_t*)(qp + sub * 8);
+  float mx = -INFINITY;
+  for (int t0 = wave * 4; t0 < len; t0 += 16) {
+    const int t = t0 + rsel;
+    float d = 0.f;
+    if (t < len) {
+      const half8_t kv = *(const half8_t*)(kp + (size_t)t * D + sub * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += (float)qv[j] * (float)kv[j];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    d *= scale;
+    if (t < len && sub == 0) sc[t] = d;
+    if (t < len) mx = fmaxf(mx, d);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int t = threadIdx.x; t < len; t += 256) {
+    const float e = __expf(sc[t] - mx);
+    sc[t] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();                          // everyone has read red[] (max) before it is reused
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();
+
+  // out = sum_t p[t] * v[t, :]: every wave takes every 4th position, lane = 2 output channels
+  float o0 = 0.f, o1 = 0.f;
+  for (int t = wave; t < len; t += 4) {
+    const float pt = sc[t];
+    const half2_t vv = *(const half2_t*)(vp + (size_t)t * D + lane * 2);
+    o0 += pt * (float)vv[0];
+    o1 += pt * (float)vv[1];
+  }
+  float* part = red;                        // [4][D]
+  part[wave * D + lane * 2] = o0;
+  part[wave * D + lane * 2 + 1] = o1;
+  __syncthreads();
+  if (threadIdx.x < D) {
+    const float v = (part[threadIdx.x] + part[D + threadIdx.x] + part[2 * D + threadIdx.x] + part[3 * D + threadIdx.x]) * inv;
+    out[((size_t)b * nh + h) * D + threadIdx.x] = (half_t)v;
+  }
+}
+
+// y[m, i] = silu(gu[m, i]) * gu[m, I + i]          gate and up halves of the fused gate_up GEMM; I % 8 == 0
+__global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict__ gu, half_t* __restrict__ y, int I, size_t n8) {
+  const size_t i8 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i8 >= n8) return;
+  const size_t m = (i8 * 8) / I, i = (i8 * 8) % I;
+  const half8_t g = *(const half8_t*)(gu + m * 2 * I + i), u = *(const half8_t*)(gu + m * 2 * I + I + i);
+  half8_t o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = (float)g[j];
+    o[j] = (half_t)((float)(half_t)(x / (1.f + __expf(-x))) * (float)u[j]);
+  }
+  *(half8_t*)(y + i8 * 8) = o;
+}
+
+}  // namespace quick_amd
+
+using namespace quick_amd;
+
+extern "C" {
+
+int quick_rmsnorm_f16(const void* x, const void* weight, void* y, int rows, int hidden, float eps, void* hip_stream) {
+  if (rows <= 0 || hidden <= 0 || hidden % 8 != 0) return QUICK_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)hip_stream, (const half_t*)x,
+                     (const half_t*)weight, (half_t*)y, hidden, eps);
+  return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+}
+
+int quick_rope_kv_append_f16(const void* qkv, const void* cos_table, const void* sin_table, const void* pos, void* q_out,
+                             void* k_cache, void* v_cache, int batch, int n_heads, int n_kv_heads, int head_dim,
+                             int cache_len, void* hip_stream) {
+  if (batch <= 0 || head_dim % 2 != 0 || head_dim > 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(rope_kv_kernel, dim3(n_heads + 2 * n_kv_heads, batch), dim3(64), 0, (hipStream_t)hip_stream,
+                     (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, (const long*)pos,
+                     (half_t*)q_out, (half_t*)k_cache, (half_t*)v_cache, n_heads, n_kv_heads, head_dim, cache_len);
+  return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+}
+
+int quick_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* pos, void* out,
+                               int batch, int n_heads, int n_kv_heads, int head_dim, int cache_len, float scale,
+                               void* hip_stream) {
+  if (batch <= 0 || head_dim != 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_UNSUPPORTED;
+  const size_t lds = (((size_t)cache_len + 3) & ~(size_t)3) * 4 + 4 * 128 * 4;
+  if (lds > 64 * 1024) return QUICK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(decode_attention_kernel, dim3(n_heads, batch), dim3(256), (unsigned)lds, (hipStream_t)hip_stream,
+                     (const half_t*)q, (const half_t*)k_cache, (const half_t*)v_cache, (const long*)pos, (half_t*)out,
+                     n_heads, n_kv_heads, cache_len, scale);
+  return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+}
+
+int quick_silu_mul_f16(const void* gate_up, void* y, int rows, int intermediate, void* hip_stream) {
+  if (rows <= 0 || intermediate <= 0 || intermediate % 8 != 0) return QUICK_ERR_INVALID_ARGUMENT;
+  const size_t n8 = (size_t)rows * intermediate / 8;
+  hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                     (const half_t*)gate_up, (half_t*)y, intermediate, n8);
+  return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -31,7 +31,8 @@ struct GemmArgs {
   const u32x4* QW;
   const half_t* S;
   const uint32_t* QZ;
-  const half_t* bias;
+  const half_t* bias;      // [N] or null
+  const half_t* residual;  // [M, N] added in the epilogue, or null
   half_t* Y;
   float* slabs;        // ksplit > 1: fp32 partial tiles, [tile][slice][slab]
   unsigned* counters;  // ksplit > 1: one arrival counter per output tile (zero on entry, zero again on exit)
@@ -229,6 +230,11 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     if (m < a.M) {
       if (a.bias) {
         const half4_t b = *(const half4_t*)(a.bias + nc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] += (float)b[r];
+      }
+      if (a.residual) {
+        const half4_t b = *(const half4_t*)(a.residual + (size_t)m * a.N + nc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) sum[r] += (float)b[r];
       }
@@ -484,9 +490,11 @@ k_loop_done:
       for (int mt = 0; mt < BMT; ++mt) {
         const int m = m0 + mt * 16 + n16;
         if (m < a.M) {
+          half4_t res = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+          if (a.residual) res = *(const half4_t*)(a.residual + (size_t)m * a.N + nc);
           half4_t o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[j][mt][r] + (float)b[r]);
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[j][mt][r] + (float)b[r] + (float)res[r]);
           *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
         }
       }
@@ -712,9 +720,11 @@ k_loop_done:
         for (int m2 = 0; m2 < BMT / 2; ++m2) {
           const int m = m0 + m2 * 32 + tok;
           if (m < a.M) {
+            half4_t res = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+            if (a.residual) res = *(const half4_t*)(a.residual + (size_t)m * a.N + nc);
             half4_t o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[p][m2][r4][r] + (float)b[r]);
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[p][m2][r4][r] + (float)b[r] + (float)res[r]);
             *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
           }
         }
@@ -938,7 +948,8 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
 #undef QA_TILED_K
 }
 
-static int run_gemm(const void* x, const void* qweight, const void* scales, const void* qzeros, const void* bias, void* y,
+static int run_gemm(const void* x, const void* qweight, const void* scales, const void* qzeros, const void* bias,
+                    const void* residual, void* y,
                     void* workspace, size_t workspace_bytes, int M, int K, int N, int G, int kernel, int grid_split_k,
                     const Launch& L) {
   if (int rc = check_shapes(M, K, N, G)) return rc;
@@ -946,7 +957,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   if ((kernel & 15) > QUICK_KERNEL_TILED || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
   const Plan p = make_plan(M, K, N, kernel, grid_split_k);
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)bias,
-             (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, nullptr};
+             (const half_t*)residual, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, nullptr};
   if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
   if (p.ksplit > 1) {
     const size_t need = workspace_need(p);
@@ -996,7 +1007,15 @@ int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scal
                             const void* bias, void* y, void* workspace, size_t workspace_bytes, int M, int K, int N,
                             int group_size, int kernel, int grid_split_k, void* hip_stream) {
   const Launch L{(hipStream_t)hip_stream, nullptr, nullptr};
-  return run_gemm(x, qweight, scales, qzeros, bias, y, workspace, workspace_bytes, M, K, N, group_size, kernel,
+  return run_gemm(x, qweight, scales, qzeros, bias, nullptr, y, workspace, workspace_bytes, M, K, N, group_size, kernel,
+                  grid_split_k, L);
+}
+
+int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* scales, const void* qzeros,
+                               const void* bias, const void* residual, void* y, void* workspace, size_t workspace_bytes,
+                               int M, int K, int N, int group_size, int kernel, int grid_split_k, void* hip_stream) {
+  const Launch L{(hipStream_t)hip_stream, nullptr, nullptr};
+  return run_gemm(x, qweight, scales, qzeros, bias, residual, y, workspace, workspace_bytes, M, K, N, group_size, kernel,
                   grid_split_k, L);
 }
 
@@ -1013,7 +1032,7 @@ int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const v
   for (int i = 0; i < iters && rc == QUICK_OK; ++i) {
     const int s = i % n_sets;
     const Launch L{st, ev[2 * i], ev[2 * i + 1]};
-    rc = run_gemm(x, qweights[s], scales[s], qzeros[s], nullptr, y, workspace, workspace_bytes, M, K, N, group_size,
+    rc = run_gemm(x, qweights[s], scales[s], qzeros[s], nullptr, nullptr, y, workspace, workspace_bytes, M, K, N, group_size,
                   kernel, grid_split_k, L);
   }
   if (rc == QUICK_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(QUICK_ERR_LAUNCH, "stream synchronize failed");

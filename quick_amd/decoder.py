@@ -16,6 +16,7 @@ from dataclasses import dataclass
 import torch
 import torch.nn.functional as F
 
+from . import kernels
 from .linear import WQLinear_QUICK
 
 
@@ -40,7 +41,7 @@ CONFIGS = {
     "llama2-7b": DecoderConfig("Llama-2-7B", 4096, 32, 32, 32, 11008),
     "mistral-7b": DecoderConfig("Mistral-7B", 4096, 32, 32, 8, 14336),
     "llama2-70b": DecoderConfig("Llama-2-70B", 8192, 80, 64, 8, 28672),
-    "tiny": DecoderConfig("tiny-test", 256, 2, 4, 2, 512, vocab=512),
+    "tiny": DecoderConfig("tiny-test", 512, 2, 4, 2, 1024, vocab=512),
 }
 
 
@@ -89,6 +90,16 @@ class SyntheticDecoder:
         self.cos = torch.cat((ang.cos(), ang.cos()), -1).half()
         self.sin = torch.cat((ang.sin(), ang.sin()), -1).half()
 
+        # static activations of the fused decode step (one new token per sequence)
+        nh, nkv = cfg.heads, cfg.kv_heads
+        f16 = dict(dtype=torch.float16, device=device)
+        self._h = torch.empty(batch, H, **f16)
+        self._qkv = torch.empty(batch, H + 2 * KV, **f16)
+        self._q = torch.empty(batch, nh, D, **f16)
+        self._att = torch.empty(batch, H, **f16)
+        self._gu = torch.empty(batch, 2 * I, **f16)
+        self._act = torch.empty(batch, I, **f16)
+
     def weight_bytes(self):
         return sum(l[k].qweight.numel() * 4 for l in self.layers for k in ("qkv", "o", "gate_up", "down"))
 
@@ -122,8 +133,34 @@ class SyntheticDecoder:
         return logits.argmax(-1)
 
 
+def _gemm(m: WQLinear_QUICK, x, out, residual=None):
+    return kernels.gemm_forward(x, m.qweight, m.scales, m.qzeros, residual=residual, out=out)
+
+
 @torch.no_grad()
-def run_generation(model: SyntheticDecoder, ctx, n_generate, use_graph=True):
+def decode_step_fused(model: SyntheticDecoder, tok, pos):
+    """One decode step (T = 1) with the HIP glue kernels: 9 launches per layer -- RMSNorm, qkv GEMM, RoPE + KV append,
+    single-query attention, o GEMM (+ residual), RMSNorm, gate_up GEMM, SiLU*mul, down GEMM (+ residual).
+    Same arithmetic as ``SyntheticDecoder.forward`` up to fp16 rounding order.  Returns (next tokens [B], hidden [B, H])."""
+    cfg = model.cfg
+    nh, nkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
+    x = model.embed.index_select(0, tok.view(-1))                  # [B, H], a fresh buffer: the residual stream
+    for l in model.layers:
+        kernels.rmsnorm(x, l["ln1"], out=model._h)
+        _gemm(l["qkv"], model._h, model._qkv)
+        kernels.rope_kv_append(model._qkv, model.cos, model.sin, pos, model._q, l["k"], l["v"], nh, nkv, D)
+        kernels.decode_attention(model._q, l["k"], l["v"], pos, model._att, nh, nkv, D)
+        _gemm(l["o"], model._att, x, residual=x)                    # x += o_proj(att), added in the GEMM epilogue
+        kernels.rmsnorm(x, l["ln2"], out=model._h)
+        _gemm(l["gate_up"], model._h, model._gu)
+        kernels.silu_mul(model._gu, out=model._act)
+        _gemm(l["down"], model._act, x, residual=x)
+    hidden = kernels.rmsnorm(x, model.norm)
+    return (hidden @ model.lm_head.t()).argmax(-1), hidden
+
+
+@torch.no_grad()
+def run_generation(model: SyntheticDecoder, ctx, n_generate, use_graph=True, fused=True):
     """examples/benchmark.py:38-67 methodology: events around every forward; prefill = iteration 0, decode = the rest.
     Returns (prefill_seconds, [decode step seconds])."""
     B, dev, L = model.B, model.dev, model.max_len
@@ -144,8 +181,11 @@ def run_generation(model: SyntheticDecoder, ctx, n_generate, use_graph=True):
     mask[..., :ctx] = 0
 
     def step():
-        mask.index_fill_(3, pos, 0.0)
-        out = model.forward(tok, pos, mask)
+        if fused:
+            out, _ = decode_step_fused(model, tok, pos)
+        else:
+            mask.index_fill_(3, pos, 0.0)
+            out = model.forward(tok, pos, mask)
         tok.copy_(out.view(B, 1))
         pos.add_(1)
 

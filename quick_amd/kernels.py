@@ -46,8 +46,10 @@ def _workspace(device, nbytes):
     return ws
 
 
-def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=KERNEL_AUTO, grid_split_k=0):
-    """y [M, N] fp16 = in_feats [M, K] @ dequant(kernel, scaling_factors, zeros) (+ bias), MI355X-order weights."""
+def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=KERNEL_AUTO, grid_split_k=0, residual=None,
+                 out=None):
+    """y [M, N] fp16 = in_feats [M, K] @ dequant(kernel, scaling_factors, zeros) (+ bias) (+ residual), MI355X-order
+    weights.  ``out`` (optional, may be ``residual``) receives the result."""
     _expect(in_feats, torch.float16, "in_feats")
     _expect(kernel, torch.int32, "kernel")
     _expect(scaling_factors, torch.float16, "scaling_factors")
@@ -60,15 +62,17 @@ def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=
     if kernel.shape[0] * 4 != K:
         raise ValueError(f"kernel has {kernel.shape[0] * 4} input channels, in_feats has {K}")
     G = K // scaling_factors.shape[0]                 # gemm_cuda_quick.cu:1477
-    out = torch.empty((M, N), dtype=torch.float16, device=in_feats.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=in_feats.device)
     if M == 0:
         return out
     with torch.cuda.device(in_feats.device):          # OptionalCUDAGuard, gemm_cuda_quick.cu:1465
         ws_bytes = lib.quick_w4a16_workspace_bytes_ex(M, K, N, G, kernel_id, grid_split_k)
         ws = _workspace(in_feats.device, ws_bytes) if ws_bytes else None
-        rc = lib.quick_w4a16_gemm_f16_ex(
+        rc = lib.quick_w4a16_gemm_f16_fused(
             in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
-            bias.data_ptr() if bias is not None else None, out.data_ptr(),
+            bias.data_ptr() if bias is not None else None, residual.data_ptr() if residual is not None else None,
+            out.data_ptr(),
             ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, M, K, N, G, kernel_id,
             grid_split_k, _stream())
     if rc != _OK:
@@ -130,4 +134,48 @@ def dequantize_mi355x(qweight, scales, qzeros):
                                              K, N, G, _stream())
     if rc != _OK:
         _raise(rc)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- decode-step glue
+def rmsnorm(x, weight, eps=1e-5, out=None):
+    """RMSNorm over the last dimension (fp16, H % 8 == 0)."""
+    lib = _lib.load()
+    H = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    rc = lib.quick_rmsnorm_f16(x.data_ptr(), weight.data_ptr(), out.data_ptr(), x.numel() // H, H, eps, _stream())
+    if rc != _OK:
+        raise RuntimeError(f"quick_rmsnorm_f16 failed ({rc})")
+    return out
+
+
+def rope_kv_append(qkv, cos_table, sin_table, pos, q_out, k_cache, v_cache, n_heads, n_kv_heads, head_dim):
+    """Decode step: rotate q/k of the fused qkv GEMM output [B, (nh + 2 nkv) D], append k/v to the caches at *pos."""
+    lib = _lib.load()
+    rc = lib.quick_rope_kv_append_f16(qkv.data_ptr(), cos_table.data_ptr(), sin_table.data_ptr(), pos.data_ptr(), q_out.data_ptr(),
+                                      k_cache.data_ptr(), v_cache.data_ptr(), qkv.shape[0], n_heads, n_kv_heads, head_dim,
+                                      k_cache.shape[2], _stream())
+    if rc != _OK:
+        raise RuntimeError(f"quick_rope_kv_append_f16 failed ({rc})")
+    return q_out
+
+
+def decode_attention(q, k_cache, v_cache, pos, out, n_heads, n_kv_heads, head_dim):
+    """Single-query attention over cache positions 0..*pos; q [B, nh, D] -> out [B, nh * D]."""
+    lib = _lib.load()
+    rc = lib.quick_decode_attention_f16(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), pos.data_ptr(), out.data_ptr(),
+                                        q.shape[0], n_heads, n_kv_heads, head_dim, k_cache.shape[2], head_dim ** -0.5, _stream())
+    if rc != _OK:
+        raise RuntimeError(f"quick_decode_attention_f16 failed ({rc})")
+    return out
+
+
+def silu_mul(gate_up, out=None):
+    """silu(gate) * up for the fused gate_up GEMM output [M, 2 I] -> [M, I]."""
+    lib = _lib.load()
+    M, I = gate_up.shape[0], gate_up.shape[1] // 2
+    out = torch.empty((M, I), dtype=torch.float16, device=gate_up.device) if out is None else out
+    rc = lib.quick_silu_mul_f16(gate_up.data_ptr(), out.data_ptr(), M, I, _stream())
+    if rc != _OK:
+        raise RuntimeError(f"quick_silu_mul_f16 failed ({rc})")
     return out
