@@ -811,7 +811,12 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   const bool no_xlds = (kernel >> 12) & 1;
   p.ablate = (kernel >> 16) & 31;
   p.mfma32 = ((kernel >> 13) & 1) && p.ablate == 0;
-  p.kernel = family == QUICK_KERNEL_AUTO ? (M <= 64 ? QUICK_KERNEL_SKINNY : QUICK_KERNEL_TILED) : family;
+  // skinny: one workgroup per 16 tokens x 16..64 channels for all of K (x re-read per channel block, no cross-workgroup
+  // reduction); tiled: 32..64 tokens x 128 channels through LDS.  Measured crossover [r01]: the tiled kernel wins from
+  // M = 65, and from M = 17 once there are >= 64 tiles of 128 channels (N >= 8192) so that it needs no K split.
+  const int tiled_tiles = (N / 128) * ((M + 63) / 64);
+  const bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= 64);
+  p.kernel = family == QUICK_KERNEL_AUTO ? (want_tiled ? QUICK_KERNEL_TILED : QUICK_KERNEL_SKINNY) : family;
   int ks = 1;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
     const int mblocks = (M + 15) / 16;
