@@ -88,13 +88,27 @@ int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scal
                             void* hip_stream);
 size_t quick_w4a16_workspace_bytes_ex(int M, int K, int N, int group_size, int kernel, int grid_split_k);
 
-/* _ex plus an optional fp16 residual[M, N] added in the epilogue (y = x @ W + bias + residual in fp32, one rounding):
- * the decoder block's `hidden + o_proj(...)` / `hidden + down_proj(...)` without a separate add kernel.
- * `residual` may alias `y`. */
+/* What may be fused around the GEMM (all optional; zero-initialise the struct):
+ *   rmsnorm_weight  fp16 [K]: y = rmsnorm(x; weight, eps) @ W -- every workgroup normalises its LDS copy of x, so
+ *                   the separate norm launch in front of qkv / gate_up disappears.  Only when
+ *                   quick_w4a16_can_fuse_rmsnorm(M, K, N, G) is non-zero (small M, x held whole in LDS).
+ *   bias            fp16 [N]      (replaces the torch add of quick/awq/modules/linear/quick.py:165)
+ *   residual        fp16 [M, N], may alias y: the decoder block's `hidden + proj(...)`
+ *   silu_mul        output channels are gate/up interleaved in blocks of 8 (16t+i gate, 16t+8+i up, i < 8) and the
+ *                   epilogue writes y[M, N/2] with y[m, 8t+i] = silu(gate) * up -- the intent of the reference's unused
+ *                   QuantFusedMLP (quick/awq/modules/fused/mlp.py:52-71).  Excludes bias and residual.
+ * Everything is accumulated in fp32 and rounded to fp16 once (silu_mul rounds gate, up and silu as torch does). */
+typedef struct quick_gemm_fusion {
+  const void* bias;
+  const void* residual;
+  const void* rmsnorm_weight;
+  float rmsnorm_eps;
+  int silu_mul;
+} quick_gemm_fusion;
 int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* scales, const void* qzeros,
-                               const void* bias, const void* residual, void* y, void* workspace,
-                               size_t workspace_bytes, int M, int K, int N, int group_size, int kernel,
-                               int grid_split_k, void* hip_stream);
+                               const quick_gemm_fusion* fusion, void* y, void* workspace, size_t workspace_bytes,
+                               int M, int K, int N, int group_size, int kernel, int grid_split_k, void* hip_stream);
+int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size);
 
 /*
  * Measurement aid (bench.py): enqueue the GEMM `iters` times on `hip_stream`, cycling through `n_sets`
@@ -120,7 +134,7 @@ int quick_amd_dispatch_floor(int iters, float* kernel_us, void* hip_stream);
  *   quick_rope_kv_append_f16   one new token per sequence: rotate q, k of qkv[B, (nh+2nkv)*D] by table row *pos
  *                              (rotate-half convention), q -> q_out[B, nh, D], k/v -> caches [B, nkv, L, D] at *pos
  *   quick_decode_attention_f16 single-query attention over cache positions 0..*pos, GQA aware, D == 128
- *   quick_silu_mul_f16         y[m, i] = silu(gate_up[m, i]) * gate_up[m, I + i]
+ *   quick_silu_mul_f16         y[m, 8t+i] = silu(gate_up[m, 16t+i]) * gate_up[m, 16t+8+i]  (gate/up interleaved by 8)
  * `pos` is a DEVICE pointer to one int64 (so a captured hipGraph can advance it).
  */
 int quick_rmsnorm_f16(const void* x, const void* weight, void* y, int rows, int hidden, float eps, void* hip_stream);
@@ -130,6 +144,10 @@ int quick_rope_kv_append_f16(const void* qkv, const void* cos_table, const void*
 int quick_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* pos, void* out,
                                int batch, int n_heads, int n_kv_heads, int head_dim, int cache_len, float scale,
                                void* hip_stream);
+/* quick_rope_kv_append_f16 + quick_decode_attention_f16 in one launch, reading the qkv GEMM output directly */
+int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, const void* sin_table, const void* pos,
+                                    void* k_cache, void* v_cache, void* out, int batch, int n_heads, int n_kv_heads,
+                                    int head_dim, int cache_len, float scale, void* hip_stream);
 int quick_silu_mul_f16(const void* gate_up, void* y, int rows, int intermediate, void* hip_stream);
 
 /*

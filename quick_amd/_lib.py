@@ -6,6 +6,12 @@ from .build import LIB
 
 _P, _I, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
+
+class GemmFusion(ctypes.Structure):
+    """struct quick_gemm_fusion (include/quick_amd.h)."""
+    _fields_ = [("bias", _P), ("residual", _P), ("rmsnorm_weight", _P), ("rmsnorm_eps", ctypes.c_float), ("silu_mul", _I)]
+
+
 _SIGNATURES = {
     "quick_amd_abi_version": (_I, []),
     "quick_amd_last_error": (ctypes.c_char_p, []),
@@ -14,10 +20,12 @@ _SIGNATURES = {
     "quick_w4a16_gemm_f16_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     "quick_w4a16_workspace_bytes_ex": (_Z, [_I, _I, _I, _I, _I, _I]),
     "quick_w4a16_gemm_profile": (_I, [_P, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "quick_w4a16_gemm_f16_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
+    "quick_w4a16_gemm_f16_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
+    "quick_w4a16_can_fuse_rmsnorm": (_I, [_I, _I, _I, _I]),
     "quick_rmsnorm_f16": (_I, [_P, _P, _P, _I, _I, ctypes.c_float, _P]),
     "quick_rope_kv_append_f16": (_I, [_P] * 7 + [_I] * 5 + [_P]),
     "quick_decode_attention_f16": (_I, [_P] * 5 + [_I] * 5 + [ctypes.c_float, _P]),
+    "quick_decode_rope_attention_f16": (_I, [_P] * 7 + [_I] * 5 + [ctypes.c_float, _P]),
     "quick_silu_mul_f16": (_I, [_P, _P, _I, _I, _P]),
     "quick_amd_dispatch_floor": (_I, [_I, _P, _P]),
     "quick_repack_cuda_to_mi355x": (_I, [_P] * 6 + [_I, _I, _I, _P]),

@@ -8,17 +8,6 @@
 
 namespace quick_amd {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-
 // y[r, :] = x[r, :] * rsqrt(mean(x[r, :]^2) + eps) * w      one 256-thread workgroup per row, H % 8 == 0
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
                                                       half_t* __restrict__ y, int H, float eps) {
@@ -144,18 +133,122 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
   }
 }
 
-// y[m, i] = silu(gu[m, i]) * gu[m, I + i]          gate and up halves of the fused gate_up GEMM; I % 8 == 0
-__global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict__ gu, half_t* __restrict__ y, int I, size_t n8) {
-  const size_t i8 = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i8 >= n8) return;
-  const size_t m = (i8 * 8) / I, i = (i8 * 8) % I;
-  const half8_t g = *(const half8_t*)(gu + m * 2 * I + i), u = *(const half8_t*)(gu + m * 2 * I + I + i);
-  half8_t o;
+// RoPE + KV append + single-query attention in ONE launch (decode step, D == 128).  Workgroup (sequence b, query head
+// h) rotates its own q and -- redundantly per query head of a GQA group -- the new k of its kv head in registers, scores
+// cache positions 0..*pos-1 from HBM/L2 and position *pos from those registers, and the group's first head appends
+// the rotated k and the v to the caches.  Nobody reads cache position *pos in this launch, so there is no ordering
+// problem between the workgroups of a group.
+__device__ __forceinline__ void rope8(const half8_t x, const half_t* __restrict__ cos_row, const half_t* __restrict__ sin_row,
+                                      int sub, float (&r)[8]) {
+  const half8_t c = *(const half8_t*)(cos_row + sub * 8), sn = *(const half8_t*)(sin_row + sub * 8);
+  const float sign = sub < 8 ? -1.f : 1.f;  // rotate_half: dims 0..63 pair with -x[i+64], dims 64..127 with +x[i-64]
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float x = (float)g[j];
-    o[j] = (half_t)((float)(half_t)(x / (1.f + __expf(-x))) * (float)u[j]);
+    const float xj = (float)x[j];
+    const float partner = __shfl_xor(xj, 8);  // lane sub^8 of the same 16-lane group holds the paired dims
+    r[j] = (float)(half_t)((float)(half_t)(xj * (float)c[j]) + (float)(half_t)(sign * partner * (float)sn[j]));
   }
+}
+
+__global__ __launch_bounds__(256) void decode_rope_attention_kernel(
+    const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t, const half_t* __restrict__ sin_t,
+    const long* __restrict__ pos, half_t* __restrict__ k_cache, half_t* __restrict__ v_cache, half_t* __restrict__ out,
+    int nh, int nkv, int L, float scale) {
+  constexpr int D = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sc = (float*)smem_raw;      // [len] scores / probabilities
+  float* red = sc + ((L + 3) & ~3);  // [4] per-wave partials, then [4][D] output partials
+  float* vnew = red + 4 * D;         // [D] the new token's v
+  const int b = blockIdx.y, h = blockIdx.x, group = nh / nkv, kvh = h / group;
+  const int p = (int)pos[0], len = p + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 15, rsel = lane >> 4;
+  const half_t* row = qkv + (size_t)b * (nh + 2 * nkv) * D;
+  const half_t* kp = k_cache + ((size_t)b * nkv + kvh) * L * D;
+  const half_t* vp = v_cache + ((size_t)b * nkv + kvh) * L * D;
+
+  float qr[8], kr[8];
+  rope8(*(const half8_t*)(row + (size_t)h * D + sub * 8), cos_t + (size_t)p * D, sin_t + (size_t)p * D, sub, qr);
+  rope8(*(const half8_t*)(row + (size_t)(nh + kvh) * D + sub * 8), cos_t + (size_t)p * D, sin_t + (size_t)p * D, sub, kr);
+  const half8_t vn = *(const half8_t*)(row + (size_t)(nh + nkv + kvh) * D + sub * 8);
+  if (threadIdx.x < 16) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vnew[sub * 8 + j] = (float)vn[j];
+    if (h % group == 0) {  // append to the caches (position p is not read by anyone in this launch)
+      half8_t kh;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kh[j] = (half_t)kr[j];
+      *(half8_t*)(k_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = kh;
+      *(half8_t*)(v_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = vn;
+    }
+  }
+
+  float mx = -INFINITY;
+  for (int t0 = wave * 4; t0 < len; t0 += 16) {
+    const int t = t0 + rsel;
+    float d = 0.f;
+    if (t < p) {
+      const half8_t kv = *(const half8_t*)(kp + (size_t)t * D + sub * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += qr[j] * (float)kv[j];
+    } else if (t == p) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += qr[j] * kr[j];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    d *= scale;
+    if (t < len && sub == 0) sc[t] = d;
+    if (t < len) mx = fmaxf(mx, d);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int t = threadIdx.x; t < len; t += 256) {
+    const float e = __expf(sc[t] - mx);
+    sc[t] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();
+
+  float o0 = 0.f, o1 = 0.f;
+  for (int t = wave; t < len; t += 4) {
+    const float pt = sc[t];
+    if (t < p) {
+      const half2_t vv = *(const half2_t*)(vp + (size_t)t * D + lane * 2);
+      o0 += pt * (float)vv[0];
+      o1 += pt * (float)vv[1];
+    } else {
+      o0 += pt * vnew[lane * 2];
+      o1 += pt * vnew[lane * 2 + 1];
+    }
+  }
+  red[wave * D + lane * 2] = o0;
+  red[wave * D + lane * 2 + 1] = o1;
+  __syncthreads();
+  if (threadIdx.x < D) {
+    const float v = (red[threadIdx.x] + red[D + threadIdx.x] + red[2 * D + threadIdx.x] + red[3 * D + threadIdx.x]) * inv;
+    out[((size_t)b * nh + h) * D + threadIdx.x] = (half_t)v;
+  }
+}
+
+// y[m, 8t + i] = silu(gu[m, 16t + i]) * gu[m, 16t + 8 + i], i < 8: gate and up channels interleaved in blocks of 8, the
+// order the fused gate_up GEMM produces (and consumes directly when its silu_mul epilogue is on); I % 8 == 0
+__global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict__ gu, half_t* __restrict__ y, int I, size_t n8) {
+  const size_t i8 = (size_t)blockIdx.x * 256 + threadIdx.x;  // one block of 8 outputs
+  if (i8 >= n8) return;
+  const size_t m = (i8 * 8) / I, t = ((i8 * 8) % I) / 8;
+  const half8_t g = *(const half8_t*)(gu + m * 2 * I + 16 * t), u = *(const half8_t*)(gu + m * 2 * I + 16 * t + 8);
+  half8_t o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = silu_mul_f16(g[j], u[j]);
   *(half8_t*)(y + i8 * 8) = o;
 }
 
@@ -191,6 +284,18 @@ int quick_decode_attention_f16(const void* q, const void* k_cache, const void* v
   hipLaunchKernelGGL(decode_attention_kernel, dim3(n_heads, batch), dim3(256), (unsigned)lds, (hipStream_t)hip_stream,
                      (const half_t*)q, (const half_t*)k_cache, (const half_t*)v_cache, (const long*)pos, (half_t*)out,
                      n_heads, n_kv_heads, cache_len, scale);
+  return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+}
+
+int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, const void* sin_table, const void* pos,
+                                    void* k_cache, void* v_cache, void* out, int batch, int n_heads, int n_kv_heads,
+                                    int head_dim, int cache_len, float scale, void* hip_stream) {
+  if (batch <= 0 || head_dim != 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_UNSUPPORTED;
+  const size_t lds = (((size_t)cache_len + 3) & ~(size_t)3) * 4 + 4 * 128 * 4 + 128 * 4;
+  if (lds > 64 * 1024) return QUICK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(decode_rope_attention_kernel, dim3(n_heads, batch), dim3(256), (unsigned)lds, (hipStream_t)hip_stream,
+                     (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, (const long*)pos,
+                     (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads, cache_len, scale);
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
 }
 

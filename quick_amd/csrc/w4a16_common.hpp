@@ -122,6 +122,22 @@ __device__ __forceinline__ floatx4 mfma16(half8_t a, half8_t b, floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+// silu(g) * u with torch's fp16 rounding points: silu rounded to fp16, product rounded to fp16
+__device__ __forceinline__ half_t silu_mul_f16(half_t g, half_t u) {
+  const float x = (float)g;
+  return (half_t)((float)(half_t)(x / (1.f + __expf(-x))) * (float)u);
+}
+
 // wave-uniform values the compiler cannot prove uniform (anything derived from threadIdx)
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

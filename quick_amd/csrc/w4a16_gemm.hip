@@ -33,6 +33,9 @@ struct GemmArgs {
   const uint32_t* QZ;
   const half_t* bias;      // [N] or null
   const half_t* residual;  // [M, N] added in the epilogue, or null
+  const half_t* ln_w;      // skinny + LDS copy of x only: RMSNorm weight [K] applied to x on the way in, or null
+  float ln_eps;
+  int silu_mul;            // epilogue: y[m, 8t+i] = silu(acc[m, 16t+i]) * acc[m, 16t+8+i]  (gate/up interleaved by 8), Y is [M, N/2]
   half_t* Y;
   float* slabs;        // ksplit > 1: fp32 partial tiles, [tile][slice][slab]
   unsigned* counters;  // ksplit > 1: one arrival counter per output tile (zero on entry, zero again on exit)
@@ -192,6 +195,30 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     }
     xl = xlds + min(n16, rows - 1) * pitch + q * 16 - wg_begin * 256;
     __syncthreads();
+    if (a.ln_w) {
+      // fused RMSNorm prologue (planner guarantees this workgroup holds whole rows: ksplit == 1).  Every workgroup
+      // normalises its private LDS copy -- K elements per row, redundant across workgroups but far cheaper than a
+      // separate launch in front of every GEMM of a decode step.  Rounding points follow the torch reference:
+      // fp16(x * inv_rms), then fp16(. * w).
+      for (int r = wave; r < rows; r += WAVES) {
+        char* rowp = xlds + r * pitch;
+        float ss = 0.f;
+        for (int c = lane; c < kc; c += 64) {
+          const half8_t v = *(const half8_t*)(rowp + c * 16);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+        }
+        const float inv = rsqrtf(wave_sum(ss) / (float)a.K + a.ln_eps);
+        for (int c = lane; c < kc; c += 64) {
+          const half8_t v = *(const half8_t*)(rowp + c * 16), g = *(const half8_t*)(a.ln_w + c * 8);
+          half8_t o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (half_t)((half_t)((float)v[j] * inv) * g[j]);
+          *(half8_t*)(rowp + c * 16) = o;
+        }
+      }
+      __syncthreads();
+    }
   }
 
   for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
@@ -223,6 +250,21 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
       for (int o = 0; o < a.ksplit; ++o)
         if (o != ks) sum += slab_load(rs, o * SLAB_BYTES + (wave * 64 + lane) * 16);
     }
+  }
+  if (a.silu_mul) {
+    if (wave < NTW) {
+      floatx4 up;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) up[r] = __shfl_xor(sum[r], 32);  // lanes q = 0,1 hold gate, their partners q = 2,3 up
+      const int m = mb * 16 + n16;
+      if (m < a.M && q < 2) {
+        half4_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = silu_mul_f16((half_t)sum[r], (half_t)up[r]);
+        *(half4_t*)(a.Y + (size_t)m * (a.N >> 1) + (nb * NTW + wave) * 8 + 4 * q) = o;
+      }
+    }
+    return;
   }
   if (wave < NTW) {
     const int m = mb * 16 + n16;
@@ -479,6 +521,26 @@ k_loop_done:
           for (int mt = 0; mt < BMT; ++mt) acc[j][mt] += slab_load(rs, o * SLAB_BYTES + my + (j * BMT + mt) * 1024);
       }
     }
+  }
+  if (a.silu_mul) {
+    if (wk == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int mt = 0; mt < BMT; ++mt) {
+          floatx4 up;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) up[r] = __shfl_xor(acc[j][mt][r], 32);
+          const int m = m0 + mt * 16 + n16;
+          if (m < a.M && q < 2) {
+            half4_t o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = silu_mul_f16((half_t)acc[j][mt][r], (half_t)up[r]);
+            *(half4_t*)(a.Y + (size_t)m * (a.N >> 1) + (nt0 + j) * 8 + 4 * q) = o;
+          }
+        }
+    }
+    return;
   }
   if (wk == 0) {
 #pragma unroll
@@ -953,16 +1015,28 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
 #undef QA_TILED_K
 }
 
-static int run_gemm(const void* x, const void* qweight, const void* scales, const void* qzeros, const void* bias,
-                    const void* residual, void* y,
+struct Fusion {
+  const void* bias = nullptr;
+  const void* residual = nullptr;
+  const void* ln_w = nullptr;
+  float ln_eps = 0.f;
+  int silu_mul = 0;
+};
+
+static int run_gemm(const void* x, const void* qweight, const void* scales, const void* qzeros, const Fusion& f, void* y,
                     void* workspace, size_t workspace_bytes, int M, int K, int N, int G, int kernel, int grid_split_k,
                     const Launch& L) {
   if (int rc = check_shapes(M, K, N, G)) return rc;
   if (!x || !qweight || !scales || !qzeros || !y) return fail(QUICK_ERR_INVALID_ARGUMENT, "null tensor pointer");
   if ((kernel & 15) > QUICK_KERNEL_TILED || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
   const Plan p = make_plan(M, K, N, kernel, grid_split_k);
-  GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)bias,
-             (const half_t*)residual, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, nullptr};
+  if (f.silu_mul && (f.bias || f.residual)) return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual");
+  if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
+  if (f.ln_w && !(p.kernel == QUICK_KERNEL_SKINNY && p.xlds && p.ksplit == 1))
+    return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue needs the skinny kernel with x in LDS and no K split "
+                                       "(quick_w4a16_can_fuse_rmsnorm)");
+  GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
+             (const half_t*)f.residual, (const half_t*)f.ln_w, f.ln_eps, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, nullptr};
   if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
   if (p.ksplit > 1) {
     const size_t need = workspace_need(p);
@@ -1012,16 +1086,30 @@ int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scal
                             const void* bias, void* y, void* workspace, size_t workspace_bytes, int M, int K, int N,
                             int group_size, int kernel, int grid_split_k, void* hip_stream) {
   const Launch L{(hipStream_t)hip_stream, nullptr, nullptr};
-  return run_gemm(x, qweight, scales, qzeros, bias, nullptr, y, workspace, workspace_bytes, M, K, N, group_size, kernel,
-                  grid_split_k, L);
+  Fusion f;
+  f.bias = bias;
+  return run_gemm(x, qweight, scales, qzeros, f, y, workspace, workspace_bytes, M, K, N, group_size, kernel, grid_split_k, L);
 }
 
 int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* scales, const void* qzeros,
-                               const void* bias, const void* residual, void* y, void* workspace, size_t workspace_bytes,
-                               int M, int K, int N, int group_size, int kernel, int grid_split_k, void* hip_stream) {
+                               const quick_gemm_fusion* fusion, void* y, void* workspace, size_t workspace_bytes, int M,
+                               int K, int N, int group_size, int kernel, int grid_split_k, void* hip_stream) {
   const Launch L{(hipStream_t)hip_stream, nullptr, nullptr};
-  return run_gemm(x, qweight, scales, qzeros, bias, residual, y, workspace, workspace_bytes, M, K, N, group_size, kernel,
-                  grid_split_k, L);
+  Fusion f;
+  if (fusion) {
+    f.bias = fusion->bias;
+    f.residual = fusion->residual;
+    f.ln_w = fusion->rmsnorm_weight;
+    f.ln_eps = fusion->rmsnorm_eps;
+    f.silu_mul = fusion->silu_mul;
+  }
+  return run_gemm(x, qweight, scales, qzeros, f, y, workspace, workspace_bytes, M, K, N, group_size, kernel, grid_split_k, L);
+}
+
+int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size) {
+  if (check_shapes(M, K, N, group_size) != QUICK_OK) return 0;
+  const Plan p = make_plan(M, K, N, QUICK_KERNEL_AUTO, 0);
+  return p.kernel == QUICK_KERNEL_SKINNY && p.xlds && p.ksplit == 1;
 }
 
 int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const void* const* scales,
@@ -1037,7 +1125,7 @@ int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const v
   for (int i = 0; i < iters && rc == QUICK_OK; ++i) {
     const int s = i % n_sets;
     const Launch L{st, ev[2 * i], ev[2 * i + 1]};
-    rc = run_gemm(x, qweights[s], scales[s], qzeros[s], nullptr, nullptr, y, workspace, workspace_bytes, M, K, N, group_size,
+    rc = run_gemm(x, qweights[s], scales[s], qzeros[s], Fusion{}, y, workspace, workspace_bytes, M, K, N, group_size,
                   kernel, grid_split_k, L);
   }
   if (rc == QUICK_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(QUICK_ERR_LAUNCH, "stream synchronize failed");

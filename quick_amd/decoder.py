@@ -9,7 +9,8 @@ quantised projection goes through ``WQLinear_QUICK`` -> libquick_amd.so.
 Differences from the reference's layer wiring, both on the GEMM side of the boundary:
   * q/k/v are one fused GEMM also for GQA models (the reference's QUICK_cat rejects unequal widths);
   * gate_proj and up_proj are one GEMM of width 2*intermediate (the intent of the reference's unused QuantFusedMLP,
-    quick/awq/modules/fused/mlp.py:52-71), followed by a torch SiLU*mul.
+    quick/awq/modules/fused/mlp.py:52-71) whose output channels interleave gate and up in blocks of 8, so that the
+    SiLU*mul can run in the GEMM epilogue.
 """
 from dataclasses import dataclass
 
@@ -126,8 +127,9 @@ class SyntheticDecoder:
                 att = F.scaled_dot_product_attention(q, l["k"], l["v"], attn_mask=mask, enable_gqa=nkv != nh)
             x = x + l["o"](att.transpose(1, 2).reshape(B, T, H))       # W4A16 GEMM
             h = _rms_norm(x, l["ln2"])
-            gu = l["gate_up"](h)                                       # W4A16 GEMM, N = 2*intermediate
-            gate, up = gu.split(cfg.intermediate, dim=-1)
+            gu = l["gate_up"](h).view(B, T, cfg.intermediate // 8, 2, 8)   # W4A16 GEMM, N = 2*intermediate,
+            gate = gu[..., 0, :].reshape(B, T, cfg.intermediate)           # gate/up channels interleaved in blocks of 8
+            up = gu[..., 1, :].reshape(B, T, cfg.intermediate)
             x = x + l["down"](F.silu(gate) * up)                       # W4A16 GEMM
         logits = _rms_norm(x[:, -1], self.norm) @ self.lm_head.t()
         return logits.argmax(-1)
@@ -139,21 +141,31 @@ def _gemm(m: WQLinear_QUICK, x, out, residual=None):
 
 @torch.no_grad()
 def decode_step_fused(model: SyntheticDecoder, tok, pos):
-    """One decode step (T = 1) with the HIP glue kernels: 9 launches per layer -- RMSNorm, qkv GEMM, RoPE + KV append,
-    single-query attention, o GEMM (+ residual), RMSNorm, gate_up GEMM, SiLU*mul, down GEMM (+ residual).
-    Same arithmetic as ``SyntheticDecoder.forward`` up to fp16 rounding order.  Returns (next tokens [B], hidden [B, H])."""
+    """One decode step (T = 1) with everything around the GEMMs fused: 5 launches per layer --
+         qkv GEMM (RMSNorm prologue) | RoPE + KV append + single-query attention | o GEMM (+ residual) |
+         gate_up GEMM (RMSNorm prologue, SiLU*mul epilogue) | down GEMM (+ residual)
+    -- or 7 when the batch is too large for the norm prologue (separate RMSNorm kernels).  Same arithmetic as
+    ``SyntheticDecoder.forward`` up to fp16 rounding order.  Returns (next tokens [B], hidden [B, H])."""
     cfg = model.cfg
-    nh, nkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
+    nh, nkv, D, H, I, G = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden, cfg.intermediate, cfg.group_size
+    B = tok.shape[0]
     x = model.embed.index_select(0, tok.view(-1))                  # [B, H], a fresh buffer: the residual stream
+    fuse_qkv = kernels.can_fuse_rmsnorm(B, H, H + 2 * nkv * D, G)
+    fuse_gu = kernels.can_fuse_rmsnorm(B, H, 2 * I, G)
     for l in model.layers:
-        kernels.rmsnorm(x, l["ln1"], out=model._h)
-        _gemm(l["qkv"], model._h, model._qkv)
-        kernels.rope_kv_append(model._qkv, model.cos, model.sin, pos, model._q, l["k"], l["v"], nh, nkv, D)
-        kernels.decode_attention(model._q, l["k"], l["v"], pos, model._att, nh, nkv, D)
+        qkv, gu = l["qkv"], l["gate_up"]
+        if fuse_qkv:
+            kernels.gemm_forward(x, qkv.qweight, qkv.scales, qkv.qzeros, out=model._qkv, rmsnorm_weight=l["ln1"])
+        else:
+            kernels.rmsnorm(x, l["ln1"], out=model._h)
+            _gemm(qkv, model._h, model._qkv)
+        kernels.rope_attention(model._qkv, model.cos, model.sin, pos, l["k"], l["v"], model._att, nh, nkv, D)
         _gemm(l["o"], model._att, x, residual=x)                    # x += o_proj(att), added in the GEMM epilogue
-        kernels.rmsnorm(x, l["ln2"], out=model._h)
-        _gemm(l["gate_up"], model._h, model._gu)
-        kernels.silu_mul(model._gu, out=model._act)
+        if fuse_gu:
+            kernels.gemm_forward(x, gu.qweight, gu.scales, gu.qzeros, out=model._act, rmsnorm_weight=l["ln2"], silu_mul=True)
+        else:
+            kernels.rmsnorm(x, l["ln2"], out=model._h)
+            kernels.gemm_forward(model._h, gu.qweight, gu.scales, gu.qzeros, out=model._act, silu_mul=True)
         _gemm(l["down"], model._act, x, residual=x)
     hidden = kernels.rmsnorm(x, model.norm)
     return (hidden @ model.lm_head.t()).argmax(-1), hidden

@@ -2,6 +2,8 @@
 (csrc/pybind.cpp:5-8), plus the format bridge.  Device pointers and the current HIP stream come from
 torch; the arithmetic is entirely in the HIP library -- there is no CPU / eager fallback.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -46,10 +48,17 @@ def _workspace(device, nbytes):
     return ws
 
 
+def can_fuse_rmsnorm(M, K, N, G):
+    """True when gemm_forward(..., rmsnorm_weight=...) is available for this shape (small M, x held whole in LDS)."""
+    return bool(_lib.load().quick_w4a16_can_fuse_rmsnorm(M, K, N, G))
+
+
 def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=KERNEL_AUTO, grid_split_k=0, residual=None,
-                 out=None):
+                 out=None, rmsnorm_weight=None, rmsnorm_eps=1e-5, silu_mul=False):
     """y [M, N] fp16 = in_feats [M, K] @ dequant(kernel, scaling_factors, zeros) (+ bias) (+ residual), MI355X-order
-    weights.  ``out`` (optional, may be ``residual``) receives the result."""
+    weights.  ``out`` (optional, may be ``residual``) receives the result.  ``rmsnorm_weight`` [K] normalises in_feats on
+    the way in (see can_fuse_rmsnorm); ``silu_mul`` treats the output channels as gate/up interleaved in blocks of 8 and
+    returns silu(gate) * up, [M, N/2]."""
     _expect(in_feats, torch.float16, "in_feats")
     _expect(kernel, torch.int32, "kernel")
     _expect(scaling_factors, torch.float16, "scaling_factors")
@@ -63,15 +72,17 @@ def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=
         raise ValueError(f"kernel has {kernel.shape[0] * 4} input channels, in_feats has {K}")
     G = K // scaling_factors.shape[0]                 # gemm_cuda_quick.cu:1477
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float16, device=in_feats.device)
+        out = torch.empty((M, N // 2 if silu_mul else N), dtype=torch.float16, device=in_feats.device)
     if M == 0:
         return out
     with torch.cuda.device(in_feats.device):          # OptionalCUDAGuard, gemm_cuda_quick.cu:1465
         ws_bytes = lib.quick_w4a16_workspace_bytes_ex(M, K, N, G, kernel_id, grid_split_k)
         ws = _workspace(in_feats.device, ws_bytes) if ws_bytes else None
+        fusion = _lib.GemmFusion(bias.data_ptr() if bias is not None else None,
+                                 residual.data_ptr() if residual is not None else None,
+                                 rmsnorm_weight.data_ptr() if rmsnorm_weight is not None else None, rmsnorm_eps, int(silu_mul))
         rc = lib.quick_w4a16_gemm_f16_fused(
-            in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
-            bias.data_ptr() if bias is not None else None, residual.data_ptr() if residual is not None else None,
+            in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), ctypes.byref(fusion),
             out.data_ptr(),
             ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, M, K, N, G, kernel_id,
             grid_split_k, _stream())
@@ -170,8 +181,19 @@ def decode_attention(q, k_cache, v_cache, pos, out, n_heads, n_kv_heads, head_di
     return out
 
 
+def rope_attention(qkv, cos_table, sin_table, pos, k_cache, v_cache, out, n_heads, n_kv_heads, head_dim):
+    """rope_kv_append + decode_attention in one launch: qkv [B, (nh + 2 nkv) D] -> out [B, nh * D]."""
+    lib = _lib.load()
+    rc = lib.quick_decode_rope_attention_f16(qkv.data_ptr(), cos_table.data_ptr(), sin_table.data_ptr(), pos.data_ptr(),
+                                             k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(), qkv.shape[0], n_heads,
+                                             n_kv_heads, head_dim, k_cache.shape[2], head_dim ** -0.5, _stream())
+    if rc != _OK:
+        raise RuntimeError(f"quick_decode_rope_attention_f16 failed ({rc})")
+    return out
+
+
 def silu_mul(gate_up, out=None):
-    """silu(gate) * up for the fused gate_up GEMM output [M, 2 I] -> [M, I]."""
+    """silu(gate) * up for the fused gate_up GEMM output [M, 2 I] (gate/up interleaved in blocks of 8) -> [M, I]."""
     lib = _lib.load()
     M, I = gate_up.shape[0], gate_up.shape[1] // 2
     out = torch.empty((M, I), dtype=torch.float16, device=gate_up.device) if out is None else out

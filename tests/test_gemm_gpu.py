@@ -274,6 +274,64 @@ def test_synthetic_decoder_graph_replay_matches_eager(qa, device):
         assert torch.equal(caches[0], caches[1])
 
 
+def test_decode_glue_kernels_against_torch(qa, device):
+    """Each HIP glue kernel / GEMM fusion on its own against the torch expression it replaces."""
+    import torch.nn.functional as F
+    from quick_amd import kernels as K_
+    from quick_amd.decoder import _rms_norm, _rope
+    torch.manual_seed(0)
+    B, H, nh, nkv, D, L, I = 3, 512, 4, 2, 128, 40, 1024
+    x = torch.randn(B, H, device=device).half()
+    w = (torch.rand(H, device=device) + 0.5).half()
+    assert torch.equal(K_.rmsnorm(x, w), _rms_norm(x, w))
+    gu = torch.randn(B, 2 * I, device=device).half()
+    g5 = gu.view(B, I // 8, 2, 8)
+    assert torch.equal(K_.silu_mul(gu), (F.silu(g5[:, :, 0]) * g5[:, :, 1]).reshape(B, I))
+    # RoPE + KV append + attention, split and fused launches, against torch
+    ang = torch.outer(torch.arange(L, device=device).float(), 1.0 / (10000 ** (torch.arange(0, D, 2, device=device).float() / D)))
+    cos, sin = torch.cat((ang.cos(), ang.cos()), -1).half(), torch.cat((ang.sin(), ang.sin()), -1).half()
+    qkv = torch.randn(B, (nh + 2 * nkv) * D, device=device).half()
+    kc0, vc0 = torch.randn(B, nkv, L, D, device=device).half(), torch.randn(B, nkv, L, D, device=device).half()
+    p = 17
+    pos = torch.full((1,), p, dtype=torch.int64, device=device)
+    q, k, v = qkv.split((nh * D, nkv * D, nkv * D), dim=-1)
+    qr = _rope(q.view(B, 1, nh, D).transpose(1, 2), cos[p:p + 1], sin[p:p + 1])
+    kr = _rope(k.view(B, 1, nkv, D).transpose(1, 2), cos[p:p + 1], sin[p:p + 1])
+    kc_ref, vc_ref = kc0.clone(), vc0.clone()
+    kc_ref[:, :, p] = kr[:, :, 0]
+    vc_ref[:, :, p] = v.view(B, nkv, D)
+    ref = F.scaled_dot_product_attention(qr.float(), kc_ref[:, :, :p + 1].float(), vc_ref[:, :, :p + 1].float(), enable_gqa=True)
+    ref = ref.transpose(1, 2).reshape(B, nh * D)
+    kc1, vc1 = kc0.clone(), vc0.clone()
+    qo = torch.empty(B, nh, D, dtype=torch.float16, device=device)
+    K_.rope_kv_append(qkv, cos, sin, pos, qo, kc1, vc1, nh, nkv, D)
+    assert torch.equal(qo, qr[:, :, 0]) and torch.equal(kc1, kc_ref) and torch.equal(vc1, vc_ref)
+    o1 = K_.decode_attention(qo, kc1, vc1, pos, torch.empty(B, nh * D, dtype=torch.float16, device=device), nh, nkv, D)
+    kc2, vc2 = kc0.clone(), vc0.clone()
+    o2 = K_.rope_attention(qkv, cos, sin, pos, kc2, vc2, torch.empty(B, nh * D, dtype=torch.float16, device=device), nh, nkv, D)
+    assert torch.equal(kc2, kc_ref) and torch.equal(vc2, vc_ref)
+    for o in (o1, o2):
+        assert (o.float() - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-3
+    # GEMM fusions: RMSNorm prologue, residual and SiLU*mul epilogues
+    for M in (1, 5, 40):
+        Kd, N, G = 512, 512, 128
+        xs, iw, s, z = oracle.make_synthetic(M, Kd, N, G, seed=M)
+        packed = _pack_dev(iw, s, z, device)
+        xd, lnw = _dev(xs, device), (torch.rand(Kd, device=device) + 0.5).half()
+        res = torch.randn(M, N, device=device).half()
+        y = qa.gemm_forward(xd, *packed)
+        y_res = qa.gemm_forward(xd, *packed, residual=res)
+        assert (y_res.float() - (y.float() + res.float())).abs().max() <= 2e-2
+        y_act = qa.gemm_forward(xd, *packed, silu_mul=True)
+        assert torch.equal(y_act, K_.silu_mul(y))
+        if K_.can_fuse_rmsnorm(M, Kd, N, G):
+            assert torch.equal(qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw), qa.gemm_forward(_rms_norm(xd, lnw), *packed))
+        else:
+            with pytest.raises(NotImplementedError):
+                qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw)
+    assert K_.can_fuse_rmsnorm(1, 4096, 12288, 128) and not K_.can_fuse_rmsnorm(64, 4096, 12288, 128)
+
+
 def test_fused_decode_step_matches_torch_glue(qa, device):
     """HIP glue kernels (RMSNorm, RoPE + KV append, single-query attention, SiLU*mul, residual epilogue) against the
     torch-op decode step on the same synthetic model: same hidden state up to fp16 rounding order."""
@@ -321,6 +379,6 @@ def _torch_decode_hidden(model, tok, pos, mask):
         l["v"].index_copy_(2, pos, v.view(B, 1, nkv, D).transpose(1, 2))
         att = F.scaled_dot_product_attention(q, l["k"], l["v"], attn_mask=mask, enable_gqa=nkv != nh)
         x = x + l["o"](att.transpose(1, 2).reshape(B, 1, H))
-        gate, up = l["gate_up"](_rms_norm(x, l["ln2"])).split(cfg.intermediate, dim=-1)
-        x = x + l["down"](F.silu(gate) * up)
+        gu = l["gate_up"](_rms_norm(x, l["ln2"])).view(B, 1, cfg.intermediate // 8, 2, 8)
+        x = x + l["down"](F.silu(gu[..., 0, :].reshape(B, 1, -1)) * gu[..., 1, :].reshape(B, 1, -1))
     return _rms_norm(x[:, -1], model.norm)
