@@ -283,7 +283,7 @@ def test_decode_glue_kernels_against_torch(qa, device):
     B, H, nh, nkv, D, L, I = 3, 512, 4, 2, 128, 40, 1024
     x = torch.randn(B, H, device=device).half()
     w = (torch.rand(H, device=device) + 0.5).half()
-    assert torch.equal(K_.rmsnorm(x, w), _rms_norm(x, w))
+    torch.testing.assert_close(K_.rmsnorm(x, w), _rms_norm(x, w), rtol=2e-3, atol=2e-3)
     gu = torch.randn(B, 2 * I, device=device).half()
     g5 = gu.view(B, I // 8, 2, 8)
     torch.testing.assert_close(K_.silu_mul(gu), (F.silu(g5[:, :, 0]) * g5[:, :, 1]).reshape(B, I), rtol=2e-3, atol=1e-3)
@@ -305,11 +305,12 @@ def test_decode_glue_kernels_against_torch(qa, device):
     kc1, vc1 = kc0.clone(), vc0.clone()
     qo = torch.empty(B, nh, D, dtype=torch.float16, device=device)
     K_.rope_kv_append(qkv, cos, sin, pos, qo, kc1, vc1, nh, nkv, D)
-    assert torch.equal(qo, qr[:, :, 0]) and torch.equal(kc1, kc_ref) and torch.equal(vc1, vc_ref)
+    close = lambda a, b: torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3)
+    close(qo, qr[:, :, 0]); close(kc1, kc_ref); close(vc1, vc_ref)
     o1 = K_.decode_attention(qo, kc1, vc1, pos, torch.empty(B, nh * D, dtype=torch.float16, device=device), nh, nkv, D)
     kc2, vc2 = kc0.clone(), vc0.clone()
     o2 = K_.rope_attention(qkv, cos, sin, pos, kc2, vc2, torch.empty(B, nh * D, dtype=torch.float16, device=device), nh, nkv, D)
-    assert torch.equal(kc2, kc_ref) and torch.equal(vc2, vc_ref)
+    close(kc2, kc_ref); close(vc2, vc_ref)
     for o in (o1, o2):
         assert (o.float() - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-3
     # GEMM fusions: RMSNorm prologue, residual and SiLU*mul epilogues
@@ -323,9 +324,9 @@ def test_decode_glue_kernels_against_torch(qa, device):
         y_res = qa.gemm_forward(xd, *packed, residual=res)
         assert (y_res.float() - (y.float() + res.float())).abs().max() <= 2e-2
         y_act = qa.gemm_forward(xd, *packed, silu_mul=True)
-        assert torch.equal(y_act, K_.silu_mul(y))
+        close(y_act, K_.silu_mul(y))
         if K_.can_fuse_rmsnorm(M, Kd, N, G):
-            assert torch.equal(qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw), qa.gemm_forward(_rms_norm(xd, lnw), *packed))
+            close(qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw), qa.gemm_forward(_rms_norm(xd, lnw), *packed))
         else:
             with pytest.raises(NotImplementedError):
                 qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw)
