@@ -83,20 +83,29 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
   // scores: 16 lanes per key row (8 fp16 each), 4 rows per wave per step
   const int sub = lane & 15, rsel = lane >> 4;
   const half8_t qv = *(const half8_t*)(qp + sub * 8);
+  // scores: a wave takes 4 key rows per step (16 lanes x 16 B each); the loads of UNR steps are issued together so
+  // that one L2/HBM round trip serves 4*UNR rows instead of one per row
+  constexpr int UNR = 8;
   float mx = -INFINITY;
-  for (int t0 = wave * 4; t0 < len; t0 += 16) {
-    const int t = t0 + rsel;
-    float d = 0.f;
-    if (t < len) {
-      const half8_t kv = *(const half8_t*)(kp + (size_t)t * D + sub * 8);
+  for (int t0 = wave * 4; t0 < len; t0 += 16 * UNR) {
+    half8_t kv[UNR];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) d += (float)qv[j] * (float)kv[j];
+    for (int u = 0; u < UNR; ++u) {
+      const int t = min(t0 + 16 * u + rsel, len - 1);
+      kv[u] = *(const half8_t*)(kp + (size_t)t * D + sub * 8);
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
-    d *= scale;
-    if (t < len && sub == 0) sc[t] = d;
-    if (t < len) mx = fmaxf(mx, d);
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + 16 * u + rsel;
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += (float)qv[j] * (float)kv[u][j];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
+      d *= scale;
+      if (t < len && sub == 0) sc[t] = d;
+      if (t < len) mx = fmaxf(mx, d);
+    }
   }
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
@@ -115,17 +124,33 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
   const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
   __syncthreads();
 
-  // out = sum_t p[t] * v[t, :]: every wave takes every 4th position, lane = 2 output channels
-  float o0 = 0.f, o1 = 0.f;
-  for (int t = wave; t < len; t += 4) {
-    const float pt = sc[t];
-    const half2_t vv = *(const half2_t*)(vp + (size_t)t * D + lane * 2);
-    o0 += pt * (float)vv[0];
-    o1 += pt * (float)vv[1];
+  // out = sum_t p[t] * v[t, :], same row-per-16-lanes mapping and batched loads; lane accumulates 8 channels
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int t0 = wave * 4; t0 < len; t0 += 16 * UNR) {
+    half8_t vv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = min(t0 + 16 * u + rsel, len - 1);
+      vv[u] = *(const half8_t*)(vp + (size_t)t * D + sub * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + 16 * u + rsel;
+      const float pt = t < len ? sc[t] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += pt * (float)vv[u][j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    acc[j] += __shfl_xor(acc[j], 16);
+    acc[j] += __shfl_xor(acc[j], 32);
   }
   float* part = red;                        // [4][D]
-  part[wave * D + lane * 2] = o0;
-  part[wave * D + lane * 2 + 1] = o1;
+  if (rsel == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[wave * D + sub * 8 + j] = acc[j];
+  }
   __syncthreads();
   if (threadIdx.x < D) {
     const float v = (part[threadIdx.x] + part[D + threadIdx.x] + part[2 * D + threadIdx.x] + part[3 * D + threadIdx.x]) * inv;
@@ -158,7 +183,6 @@ __global__ __launch_bounds__(256) void decode_rope_attention_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* sc = (float*)smem_raw;      // [len] scores / probabilities
   float* red = sc + ((L + 3) & ~3);  // [4] per-wave partials, then [4][D] output partials
-  float* vnew = red + 4 * D;         // [D] the new token's v
   const int b = blockIdx.y, h = blockIdx.x, group = nh / nkv, kvh = h / group;
   const int p = (int)pos[0], len = p + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -172,8 +196,6 @@ __global__ __launch_bounds__(256) void decode_rope_attention_kernel(
   rope8(*(const half8_t*)(row + (size_t)(nh + kvh) * D + sub * 8), cos_t + (size_t)p * D, sin_t + (size_t)p * D, sub, kr);
   const half8_t vn = *(const half8_t*)(row + (size_t)(nh + nkv + kvh) * D + sub * 8);
   if (threadIdx.x < 16) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) vnew[sub * 8 + j] = (float)vn[j];
     if (h % group == 0) {  // append to the caches (position p is not read by anyone in this launch)
       half8_t kh;
 #pragma unroll
@@ -183,23 +205,27 @@ __global__ __launch_bounds__(256) void decode_rope_attention_kernel(
     }
   }
 
+  constexpr int UNR = 8;
   float mx = -INFINITY;
-  for (int t0 = wave * 4; t0 < len; t0 += 16) {
-    const int t = t0 + rsel;
-    float d = 0.f;
-    if (t < p) {
-      const half8_t kv = *(const half8_t*)(kp + (size_t)t * D + sub * 8);
+  for (int t0 = wave * 4; t0 < len; t0 += 16 * UNR) {
+    half8_t kv[UNR];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) d += qr[j] * (float)kv[j];
-    } else if (t == p) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) d += qr[j] * kr[j];
+    for (int u = 0; u < UNR; ++u) {
+      const int t = min(t0 + 16 * u + rsel, max(p - 1, 0));  // cache rows 0..p-1; row p comes from registers
+      kv[u] = *(const half8_t*)(kp + (size_t)t * D + sub * 8);
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
-    d *= scale;
-    if (t < len && sub == 0) sc[t] = d;
-    if (t < len) mx = fmaxf(mx, d);
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + 16 * u + rsel;
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += qr[j] * (t == p ? kr[j] : (float)kv[u][j]);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
+      d *= scale;
+      if (t < len && sub == 0) sc[t] = d;
+      if (t < len) mx = fmaxf(mx, d);
+    }
   }
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
@@ -218,20 +244,31 @@ __global__ __launch_bounds__(256) void decode_rope_attention_kernel(
   const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
   __syncthreads();
 
-  float o0 = 0.f, o1 = 0.f;
-  for (int t = wave; t < len; t += 4) {
-    const float pt = sc[t];
-    if (t < p) {
-      const half2_t vv = *(const half2_t*)(vp + (size_t)t * D + lane * 2);
-      o0 += pt * (float)vv[0];
-      o1 += pt * (float)vv[1];
-    } else {
-      o0 += pt * vnew[lane * 2];
-      o1 += pt * vnew[lane * 2 + 1];
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int t0 = wave * 4; t0 < len; t0 += 16 * UNR) {
+    half8_t vv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = min(t0 + 16 * u + rsel, max(p - 1, 0));
+      vv[u] = *(const half8_t*)(vp + (size_t)t * D + sub * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + 16 * u + rsel;
+      const float pt = t < len ? sc[t] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += pt * (t == p ? (float)vn[j] : (float)vv[u][j]);
     }
   }
-  red[wave * D + lane * 2] = o0;
-  red[wave * D + lane * 2 + 1] = o1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    acc[j] += __shfl_xor(acc[j], 16);
+    acc[j] += __shfl_xor(acc[j], 32);
+  }
+  if (rsel == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave * D + sub * 8 + j] = acc[j];
+  }
   __syncthreads();
   if (threadIdx.x < D) {
     const float v = (red[threadIdx.x] + red[D + threadIdx.x] + red[2 * D + threadIdx.x] + red[3 * D + threadIdx.x]) * inv;
