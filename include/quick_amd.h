@@ -89,9 +89,8 @@ int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scal
 size_t quick_w4a16_workspace_bytes_ex(int M, int K, int N, int group_size, int kernel, int grid_split_k);
 
 /* What may be fused around the GEMM (all optional; zero-initialise the struct):
- *   rmsnorm_weight  fp16 [K]: y = rmsnorm(x; weight, eps) @ W -- every workgroup normalises its LDS copy of x, so
- *                   the separate norm launch in front of qkv / gate_up disappears.  Only when
- *                   quick_w4a16_can_fuse_rmsnorm(M, K, N, G) is non-zero (small M, x held whole in LDS).
+ *   rmsnorm_weight  reserved (must be NULL): an in-kernel RMSNorm prologue was tried in r01 and cost as much as the
+ *                   2 us launch it replaced; quick_w4a16_can_fuse_rmsnorm() returns 0 and quick_rmsnorm_f16 is used.
  *   bias            fp16 [N]      (replaces the torch add of quick/awq/modules/linear/quick.py:165)
  *   residual        fp16 [M, N], may alias y: the decoder block's `hidden + proj(...)`
  *   silu_mul        output channels are gate/up interleaved in blocks of 8 (16t+i gate, 16t+8+i up, i < 8) and the

@@ -33,8 +33,6 @@ struct GemmArgs {
   const uint32_t* QZ;
   const half_t* bias;      // [N] or null
   const half_t* residual;  // [M, N] added in the epilogue, or null
-  const half_t* ln_w;      // skinny + LDS copy of x only: RMSNorm weight [K] applied to x on the way in, or null
-  float ln_eps;
   int silu_mul;            // epilogue: y[m, 8t+i] = silu(acc[m, 16t+i]) * acc[m, 16t+8+i]  (gate/up interleaved by 8), Y is [M, N/2]
   half_t* Y;
   float* slabs;        // ksplit > 1: fp32 partial tiles, [tile][slice][slab]
@@ -189,59 +187,12 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     const int kc = cnt * 16;  // 16-byte chunks per row
     const int pitch = cnt * 256 + 16;
     xl = xlds + min(n16, rows - 1) * pitch + q * 16 - wg_begin * 256;
-    if (a.ln_w == nullptr) {
-      for (int i = threadIdx.x; i < rows * kc; i += WAVES * 64) {
-        const int r = i / kc, c = i - r * kc;
-        const u32x4 v = *(const u32x4*)(a.X + (size_t)(mb * 16 + r) * a.K + wg_begin * 128 + c * 8);
-        *(u32x4*)(xlds + r * pitch + c * 16) = v;
-      }
-      __syncthreads();
-    } else {
-      // Fused RMSNorm prologue.  The planner guarantees: whole rows in this workgroup (ksplit == 1), rows <= 8 and
-      // K % 512 == 0, so a row is a whole number of waves' worth of chunks and every thread owns at most 8 chunks.
-      // x and the matching slice of the norm weight are fetched together and stay in registers; per-row sums of
-      // squares meet in LDS; each thread then writes fp16(fp16(x * inv_rms) * w) -- the torch rounding points --
-      // for its own chunks.  Redundant across workgroups, but it replaces a separate launch in front of the GEMM.
-      constexpr int MAXC = 8;
-      float* rowss = (float*)(xlds + rows * pitch);  // [rows], after the x image
-      half8_t xv[MAXC], wv[MAXC];
-      if (threadIdx.x < rows) rowss[threadIdx.x] = 0.f;
-#pragma unroll
-      for (int it = 0; it < MAXC; ++it) {
-        const int i = threadIdx.x + it * WAVES * 64;
-        if (i < rows * kc) {
-          const int r = i / kc, c = i - r * kc;
-          xv[it] = *(const half8_t*)(a.X + (size_t)(mb * 16 + r) * a.K + c * 8);
-          wv[it] = *(const half8_t*)(a.ln_w + c * 8);
-        }
-      }
-      __syncthreads();  // rowss zeroed
-#pragma unroll
-      for (int it = 0; it < MAXC; ++it) {
-        const int i = threadIdx.x + it * WAVES * 64;
-        if (i < rows * kc) {  // wave-uniform (kc % 64 == 0)
-          float ss = 0.f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) ss += (float)xv[it][j] * (float)xv[it][j];
-          ss = wave_sum(ss);
-          if (lane == 0) atomicAdd(rowss + i / kc, ss);
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < MAXC; ++it) {
-        const int i = threadIdx.x + it * WAVES * 64;
-        if (i < rows * kc) {
-          const int r = i / kc, c = i - r * kc;
-          const float inv = rsqrtf(rowss[r] / (float)a.K + a.ln_eps);
-          half8_t o;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (half_t)((half_t)((float)xv[it][j] * inv) * wv[it][j]);
-          *(half8_t*)(xlds + r * pitch + c * 16) = o;
-        }
-      }
-      __syncthreads();
+    for (int i = threadIdx.x; i < rows * kc; i += WAVES * 64) {
+      const int r = i / kc, c = i - r * kc;
+      const u32x4 v = *(const u32x4*)(a.X + (size_t)(mb * 16 + r) * a.K + wg_begin * 128 + c * 8);
+      *(u32x4*)(xlds + r * pitch + c * 16) = v;
     }
+    __syncthreads();
   }
 
   for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
@@ -948,7 +899,7 @@ template <int NTW, int WAVES, bool XLDS>
 static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) {
   dim3 grid(a.N / (16 * NTW), (a.M + 15) / 16, p.ksplit), block(WAVES * 64);
   size_t lds = (size_t)WAVES * NTW * 1024;
-  if (XLDS) lds += (size_t)std::min(a.M, 16) * (p.kt_per_split * 256 + 16) + 64;
+  if (XLDS) lds += (size_t)std::min(a.M, 16) * (p.kt_per_split * 256 + 16);
 #define QA_SKINNY(GMV)                                                                                               \
   hipExtLaunchKernelGGL((w4a16_skinny_kernel<NTW, WAVES, GMV, XLDS>), grid, block, (unsigned)lds, L.st, L.start, L.stop, \
                         0, a)
@@ -1038,11 +989,6 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
 #undef QA_TILED_K
 }
 
-static bool can_fuse_norm(const Plan& p, int M, int K) {
-  return p.kernel == QUICK_KERNEL_SKINNY && p.xlds && p.ksplit == 1 && M <= 8 && K % 512 == 0 &&
-         (size_t)M * (K / 8) <= (size_t)8 * p.waves * 64;
-}
-
 struct Fusion {
   const void* bias = nullptr;
   const void* residual = nullptr;
@@ -1060,11 +1006,9 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   const Plan p = make_plan(M, K, N, kernel, grid_split_k);
   if (f.silu_mul && (f.bias || f.residual)) return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual");
   if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
-  if (f.ln_w && !can_fuse_norm(p, M, K))
-    return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue needs the skinny kernel with x in LDS and no K split "
-                                       "(quick_w4a16_can_fuse_rmsnorm)");
+  if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: not available (measured slower than a separate launch)");
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
-             (const half_t*)f.residual, (const half_t*)f.ln_w, f.ln_eps, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, nullptr};
+             (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, nullptr};
   if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
   if (p.ksplit > 1) {
     const size_t need = workspace_need(p);
@@ -1135,9 +1079,8 @@ int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* s
 }
 
 int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size) {
-  if (check_shapes(M, K, N, group_size) != QUICK_OK) return 0;
-  const Plan p = make_plan(M, K, N, QUICK_KERNEL_AUTO, 0);
-  return can_fuse_norm(p, M, K);
+  (void)M; (void)K; (void)N; (void)group_size;
+  return 0;  // r01: the in-kernel RMSNorm prologue cost as much as the 2 us launch it replaced and was removed
 }
 
 int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const void* const* scales,

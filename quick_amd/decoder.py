@@ -141,10 +141,10 @@ def _gemm(m: WQLinear_QUICK, x, out, residual=None):
 
 @torch.no_grad()
 def decode_step_fused(model: SyntheticDecoder, tok, pos):
-    """One decode step (T = 1) with everything around the GEMMs fused: 5 launches per layer --
-         qkv GEMM (RMSNorm prologue) | RoPE + KV append + single-query attention | o GEMM (+ residual) |
-         gate_up GEMM (RMSNorm prologue, SiLU*mul epilogue) | down GEMM (+ residual)
-    -- or 7 when the batch is too large for the norm prologue (separate RMSNorm kernels).  Same arithmetic as
+    """One decode step (T = 1) with the glue around the GEMMs fused: 7 launches per layer --
+         RMSNorm | qkv GEMM | RoPE + KV append + single-query attention | o GEMM (+ residual) |
+         RMSNorm | gate_up GEMM (SiLU*mul epilogue) | down GEMM (+ residual).
+    Same arithmetic as
     ``SyntheticDecoder.forward`` up to fp16 rounding order.  Returns (next tokens [B], hidden [B, H])."""
     cfg = model.cfg
     nh, nkv, D, H, I, G = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden, cfg.intermediate, cfg.group_size

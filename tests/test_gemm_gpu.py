@@ -325,13 +325,9 @@ def test_decode_glue_kernels_against_torch(qa, device):
         assert (y_res.float() - (y.float() + res.float())).abs().max() <= 2e-2
         y_act = qa.gemm_forward(xd, *packed, silu_mul=True)
         close(y_act, K_.silu_mul(y))
-        if K_.can_fuse_rmsnorm(M, Kd, N, G):
-            close(qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw), qa.gemm_forward(_rms_norm(xd, lnw), *packed))
-        else:
-            with pytest.raises(NotImplementedError):
-                qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw)
-    assert K_.can_fuse_rmsnorm(1, 4096, 12288, 128) and K_.can_fuse_rmsnorm(4, 4096, 22016, 128)
-    assert not K_.can_fuse_rmsnorm(64, 4096, 12288, 128) and not K_.can_fuse_rmsnorm(1, 11008, 4096, 128)
+        assert not K_.can_fuse_rmsnorm(M, Kd, N, G)           # prologue removed in r01 (no faster than the 2 us launch)
+        with pytest.raises(NotImplementedError):
+            qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw)
 
 
 def test_fused_decode_step_matches_torch_glue(qa, device):
