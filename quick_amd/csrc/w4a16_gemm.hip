@@ -220,9 +220,12 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     const __amdgpu_buffer_rsrc_t rs = slab_rsrc(a.slabs + (size_t)tile * a.ksplit * (NTW * 256), a.ksplit * SLAB_BYTES);
     if (wave < NTW) slab_store(rs, ks * SLAB_BYTES + (wave * 64 + lane) * 16, sum);
     if (!splitk_arrive(a.counters + tile, a.ksplit, (unsigned*)smem)) return;
-    if (wave < NTW) {  // all slices in index order, its own included: the sum does not depend on who arrived last
-      sum = slab_load(rs, (wave * 64 + lane) * 16);
-      for (int o = 1; o < a.ksplit; ++o) sum += slab_load(rs, o * SLAB_BYTES + (wave * 64 + lane) * 16);
+    if (wave < NTW) {  // slices are added in index order (own partial from registers at its index): the result does
+      const floatx4 own = sum;  // not depend on which workgroup happened to arrive last
+      for (int o = 0; o < a.ksplit; ++o) {
+        const floatx4 part = o == ks ? own : slab_load(rs, o * SLAB_BYTES + (wave * 64 + lane) * 16);
+        sum = o == 0 ? part : sum + part;
+      }
     }
   }
   if (a.silu_mul) {
@@ -486,13 +489,18 @@ k_loop_done:
         for (int mt = 0; mt < BMT; ++mt) slab_store(rs, ks * SLAB_BYTES + my + (j * BMT + mt) * 1024, acc[j][mt]);
     }
     if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
-    if (wk == 0) {  // all slices in index order, its own included: the sum does not depend on who arrived last
+    if (wk == 0) {  // slices are added in index order (own partial from registers at its index): the result does not
+      floatx4 own[TN][BMT];  // depend on which workgroup happened to arrive last
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int mt = 0; mt < BMT; ++mt) own[j][mt] = acc[j][mt];
       for (int o = 0; o < a.ksplit; ++o) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int mt = 0; mt < BMT; ++mt) {
-            const floatx4 part = slab_load(rs, o * SLAB_BYTES + my + (j * BMT + mt) * 1024);
+            const floatx4 part = o == ks ? own[j][mt] : slab_load(rs, o * SLAB_BYTES + my + (j * BMT + mt) * 1024);
             acc[j][mt] = o == 0 ? part : acc[j][mt] + part;
           }
       }
@@ -740,7 +748,8 @@ k_loop_done:
           for (int m2 = 0; m2 < BMT / 2; ++m2)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-              const floatx4 part = slab_load(rs, o * SLAB_BYTES + my + ((p * (BMT / 2) + m2) * 4 + r4) * 1024);
+              const floatx4 part = o == ks ? chunk(p, m2, r4)
+                                           : slab_load(rs, o * SLAB_BYTES + my + ((p * (BMT / 2) + m2) * 4 + r4) * 1024);
               v[p][m2][r4] = o == 0 ? part : v[p][m2][r4] + part;
             }
       }
