@@ -741,6 +741,13 @@ k_loop_done:
     }
     if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
     if (wk == 0) {
+      floatx4 own[TN / 2][BMT / 2][4];
+#pragma unroll
+      for (int p = 0; p < TN / 2; ++p)
+#pragma unroll
+        for (int m2 = 0; m2 < BMT / 2; ++m2)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) own[p][m2][r4] = v[p][m2][r4];
       for (int o = 0; o < a.ksplit; ++o) {
 #pragma unroll
         for (int p = 0; p < TN / 2; ++p)
@@ -748,7 +755,7 @@ k_loop_done:
           for (int m2 = 0; m2 < BMT / 2; ++m2)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-              const floatx4 part = o == ks ? chunk(p, m2, r4)
+              const floatx4 part = o == ks ? own[p][m2][r4]
                                            : slab_load(rs, o * SLAB_BYTES + my + ((p * (BMT / 2) + m2) * 4 + r4) * 1024);
               v[p][m2][r4] = o == 0 ? part : v[p][m2][r4] + part;
             }
