@@ -41,6 +41,7 @@ struct GemmArgs {
   int tpg;     // G / 128 (group mode 1)
   int ksplit;  // K slices across workgroups
   int kt_per_split;
+  int xcd_gm;  // tiled: XCD-aware tile order -- the 8 XCDs form an xcd_gm x (8/xcd_gm) grid over (token, channel) blocks; 0 = plain order
   unsigned long long* dbg;  // ablation bit 16: per-wave phase cycle totals [workgroup][wave][8]
 };
 
@@ -375,7 +376,17 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled_kernel(const GemmArgs a)
   const int wn = wave & 3, wk = wave >> 2;
   const int n16 = lane & 15, q = lane >> 4;
   const int NB = a.N / (64 * TN);
-  const int nb = blockIdx.x % NB, mb = blockIdx.x / NB, ks = blockIdx.y;
+  int nb = blockIdx.x % NB, mb = blockIdx.x / NB;
+  if (a.xcd_gm > 0) {
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it).  Give every XCD a compact
+    // rectangle of tiles so that its private L2 fetches few distinct x rows AND few distinct weight columns.
+    const int MB = gridDim.x / NB, gn = 8 / a.xcd_gm;
+    const int mcnt = MB / a.xcd_gm, ncnt = NB / gn;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    mb = (xcd / gn) * mcnt + idx / ncnt;
+    nb = (xcd % gn) * ncnt + idx % ncnt;
+  }
+  const int ks = blockIdx.y;
   const int KT = a.K >> 7;
   TiledCtx<BMT, TN, WK> c;
   c.kt_lo = ks * a.kt_per_split;
@@ -634,7 +645,17 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled32_kernel(const GemmArgs 
   const int wn = wave & 3, wk = wave >> 2;
   const int n16 = lane & 15, q = lane >> 4;
   const int NB = a.N / (64 * TN);
-  const int nb = blockIdx.x % NB, mb = blockIdx.x / NB, ks = blockIdx.y;
+  int nb = blockIdx.x % NB, mb = blockIdx.x / NB;
+  if (a.xcd_gm > 0) {
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it).  Give every XCD a compact
+    // rectangle of tiles so that its private L2 fetches few distinct x rows AND few distinct weight columns.
+    const int MB = gridDim.x / NB, gn = 8 / a.xcd_gm;
+    const int mcnt = MB / a.xcd_gm, ncnt = NB / gn;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    mb = (xcd / gn) * mcnt + idx / ncnt;
+    nb = (xcd % gn) * ncnt + idx % ncnt;
+  }
+  const int ks = blockIdx.y;
   const int KT = a.K >> 7;
   TiledCtx<BMT, TN, WK> c;
   c.kt_lo = ks * a.kt_per_split;
@@ -834,6 +855,7 @@ struct Plan {
   size_t slab_floats;  // fp32 elements of one partial tile
   int kt_per_split;
   int ablate;  // kernel bits 16-20: ablation variant of the tiled kernel (timing experiments only)
+  int xcd_gm;  // tiled: rows of the XCD grid over the tile grid (0 = plain order)
   bool mfma32; // tiled: v_mfma_f32_32x32x16_f16 flavour (kernel bit 13; measured slower than 16x16x32 in r01)
 };
 
@@ -897,6 +919,19 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
     while (p.ntiles * ks * 2 <= 256 && nstage / (ks * 2) >= 2) ks *= 2;
     p.ksplit = std::max(1, std::min(grid_split_k > 0 ? grid_split_k : ks, nstage));
     p.kt_per_split = ((nstage + p.ksplit - 1) / p.ksplit) * wk;  // whole stages
+    // XCD-aware tile order: minimise what each XCD's L2 has to fetch, (MB/gm) token blocks of 4*BMT*K bytes plus
+    // (NB*gm/8) channel blocks of 64*K bytes
+    const int MBk = (M + p.mt * 16 - 1) / (p.mt * 16), NBk = N / 128;
+    long best = -1;
+    if (!((kernel >> 14) & 1) && (MBk * NBk) % 8 == 0)
+      for (int gm = 1; gm <= 8; gm *= 2) {
+        if (MBk % gm != 0 || NBk % (8 / gm) != 0) continue;
+        const long cost = (long)(MBk / gm) * 4 * p.mt + (long)(NBk * gm / 8) * 64;
+        if (best < 0 || cost < best) {
+          best = cost;
+          p.xcd_gm = gm;
+        }
+      }
   }
   p.ksplit = (KT + p.kt_per_split - 1) / p.kt_per_split;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
@@ -1027,7 +1062,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
   if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: not available (measured slower than a separate launch)");
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
-             (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, nullptr};
+             (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr};
   if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
   if (p.ksplit > 1) {
     const size_t need = workspace_need(p);
