@@ -54,17 +54,13 @@ def main():
     import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from quick_amd import replicas
+    rank, local_rank, world = replicas.world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the W4A16 GEMM has no CPU implementation")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    dist = replicas.init("nccl", dev)        # replicas only: RCCL is used for the barrier and the max over ranks, nothing else
 
     from quick_amd import _lib, packing
     from quick_amd.build import build
@@ -137,11 +133,7 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        ms_step = e0.elapsed_time(e1) / steps
-        if dist is not None:
-            t = torch.tensor([ms_step], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ms_step = float(t.item())
+        ms_step = replicas.max_over_ranks(dist, e0.elapsed_time(e1) / steps, dev)
 
         # the kernel's own duration: event pair bound to each dispatch, cycling the same weight sets
         kus = (ctypes.c_float * steps)()
@@ -190,7 +182,7 @@ def main():
 
     head = results[args.M]
     out = {
-        "metric": "w4a16_gemm_tops", "value": head["tops"] * world, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+        "metric": "w4a16_gemm_tops", "value": replicas.job_throughput(head["roofline"]["flops"], head["ms_per_step"], world) / 1e12, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"W4A16 GEMM M={args.M} K={K} N={N} group_size={G} (BASELINE.json configs[1])", "M": args.M, "K": K, "N": N,

@@ -270,37 +270,39 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
 // tiled kernel
 // ------------------------------------------------------------------------------------------------
 // per-wave state of the tiled kernel that does not change over the K loop
-template <int BMT, int TN, int WK>
+template <int BMT, int TN, int WK, int WN = 4>
 struct TiledCtx {
-  static constexpr int XPW = (4 * WK * BMT) / (4 * WK);  // x fragments staged per wave per stage (= BMT)
+  static constexpr int XPW = 4 * BMT / WN;  // x fragments staged per wave per stage (4*WK*BMT fragments, WN*WK waves)
   const u32x4* wp[TN];      // this lane's 16 bytes of weight tile (channel tile j, k-tile 0)
   int ncol[TN];             // this lane's output channel in channel tile j
-  const half_t* xsrc[BMT];  // global source of the fragments this wave stages (k-tile 0 of a stage)
-  int xkt[BMT];             // which of the stage's WK k-tiles fragment i belongs to
+  const half_t* xsrc[XPW];  // global source of the fragments this wave stages (k-tile 0 of a stage)
+  int xkt[XPW];             // which of the stage's WK k-tiles fragment i belongs to
   int kt_lo, kt_hi, wave, wk;
 };
 
 // x fragments of stage s: global -> registers (ordinary loads: hipcc counts them, so they can stay in flight
 // across barriers; global_load_lds cannot -- the compiler drains it at every barrier and at the first use of any
 // other load)
-template <int BMT, int TN, int WK>
-__device__ __forceinline__ void tiled_load_x(const TiledCtx<BMT, TN, WK>& c, int s, u32x4 (&xr)[BMT]) {
+template <int BMT, int TN, int WK, int WN>
+__device__ __forceinline__ void tiled_load_x(const TiledCtx<BMT, TN, WK, WN>& c, int s, u32x4 (&xr)[4 * BMT / WN]) {
 #pragma unroll
-  for (int i = 0; i < BMT; ++i) {
+  for (int i = 0; i < 4 * BMT / WN; ++i) {
     const int kt = min(c.kt_lo + WK * s + c.xkt[i], c.kt_hi - 1);  // past the end: replay the last tile (unused)
     xr[i] = *(const u32x4*)(c.xsrc[i] + kt * 128);
   }
 }
 // registers -> LDS in B-fragment order: fragment f = wave*BMT + i is 1 KiB, lane l at byte 16 l
-template <int BMT, int TN, int WK>
-__device__ __forceinline__ void tiled_store_x(const TiledCtx<BMT, TN, WK>& c, char* buf, int lane, const u32x4 (&xr)[BMT]) {
+template <int BMT, int TN, int WK, int WN>
+__device__ __forceinline__ void tiled_store_x(const TiledCtx<BMT, TN, WK, WN>& c, char* buf, int lane,
+                                              const u32x4 (&xr)[4 * BMT / WN]) {
+  constexpr int XPW = 4 * BMT / WN;
 #pragma unroll
-  for (int i = 0; i < BMT; ++i) *(u32x4*)(buf + (c.wave * BMT + i) * 1024 + lane * 16) = xr[i];
+  for (int i = 0; i < XPW; ++i) *(u32x4*)(buf + (c.wave * XPW + i) * 1024 + lane * 16) = xr[i];
 }
 
 // weights + raw group constants of this wave's k-tile of stage s (no dependent ALU: see GroupRaw)
-template <int BMT, int TN, int WK, int GM>
-__device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN, WK>& c, const GemmArgs& a, int s, u32x4 (&w)[TN],
+template <int BMT, int TN, int WK, int GM, int WN>
+__device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN, WK, WN>& c, const GemmArgs& a, int s, u32x4 (&w)[TN],
                                              uint32_t (&gs)[TN][groups_per_tile<GM>()],
                                              uint32_t (&gz)[TN][groups_per_tile<GM>()]) {
   constexpr int NG = groups_per_tile<GM>();
@@ -320,8 +322,8 @@ __device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN, WK>& c, con
 
 // ABL (ablation bits, timing experiments only -- results are wrong when set): 1 = no global loads in the K loop,
 // 2 = no LDS traffic in the K loop, 4 = no dequantisation, 8 = no barrier.
-template <int BMT, int TN, int WK, int GM, int ABL = 0>
-__device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK>& c, const char* sb, int s, const u32x4 (&w)[TN],
+template <int BMT, int TN, int WK, int GM, int ABL, int WN>
+__device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK, WN>& c, const char* sb, int s, const u32x4 (&w)[TN],
                                               const uint32_t (&gs)[TN][groups_per_tile<GM>()],
                                               const uint32_t (&gz)[TN][groups_per_tile<GM>()],
                                               floatx4 (&acc)[TN][BMT]) {
@@ -363,19 +365,20 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK>& c, co
 // LDS[cur] with weights[s%2] ; issue weights(s+2) into the set just freed ; barrier }.
 // Loads past the last stage are NOT guarded: they replay the last tile (clamped index) and are never consumed -- a
 // guard would merge "issued" and "not issued" paths and make hipcc drain the whole load queue at every consumer.
-template <int BMT, int TN, int WK, int GM, int ABL = 0>
-__global__ __launch_bounds__(256 * WK) void w4a16_tiled_kernel(const GemmArgs a) {
+template <int BMT, int TN, int WK, int GM, int ABL = 0, int WN = 4>
+__global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArgs a) {
+  constexpr int XPW = 4 * BMT / WN;
   constexpr int NG = groups_per_tile<GM>();
   constexpr int FRAGS = 4 * WK * BMT;        // 1 KiB fragments per stage
   constexpr int STAGE_BYTES = FRAGS * 1024;  // 32 KiB at BMT = 4, WK = 2
-  static_assert((WK - 1) * 4 * TN * BMT * 1024 <= 2 * STAGE_BYTES, "epilogue exchange must fit in the stage buffers");
+  static_assert((WK - 1) * WN * TN * BMT * 1024 <= 2 * STAGE_BYTES, "epilogue exchange must fit in the stage buffers");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE_BYTES
 
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
-  const int wn = wave & 3, wk = wave >> 2;
+  const int wn = wave % WN, wk = wave / WN;
   const int n16 = lane & 15, q = lane >> 4;
-  const int NB = a.N / (64 * TN);
+  const int NB = a.N / (16 * WN * TN);
   int nb = blockIdx.x % NB, mb = blockIdx.x / NB;
   if (a.xcd_gm > 0) {
     // Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it).  Give every XCD a compact
@@ -388,14 +391,14 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled_kernel(const GemmArgs a)
   }
   const int ks = blockIdx.y;
   const int KT = a.K >> 7;
-  TiledCtx<BMT, TN, WK> c;
+  TiledCtx<BMT, TN, WK, WN> c;
   c.kt_lo = ks * a.kt_per_split;
   c.kt_hi = min(KT, c.kt_lo + a.kt_per_split);
   c.wave = wave;
   c.wk = wk;
   const int nstage = (c.kt_hi - c.kt_lo + WK - 1) / WK;
   const int m0 = mb * BMT * 16;
-  const int nt0 = (nb * 4 + wn) * TN;  // first 16-channel tile of this wave
+  const int nt0 = (nb * WN + wn) * TN;  // first 16-channel tile of this wave
 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -404,8 +407,8 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled_kernel(const GemmArgs a)
   }
   // fragments this wave stages: f = wave*BMT + i  ->  (k-tile f / (4 BMT), k-step (f / BMT) % 4, token tile f % BMT)
 #pragma unroll
-  for (int i = 0; i < BMT; ++i) {
-    const int f = wave * BMT + i, t = (f / BMT) & 3, mt = f % BMT;
+  for (int i = 0; i < XPW; ++i) {
+    const int f = wave * XPW + i, t = (f / BMT) & 3, mt = f % BMT;
     c.xkt[i] = f / (4 * BMT);
     const int row = min(m0 + mt * 16 + n16, a.M - 1);
     c.xsrc[i] = a.X + (size_t)row * a.K + 32 * t + 8 * q;
@@ -417,17 +420,17 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled_kernel(const GemmArgs a)
 #pragma unroll
     for (int mt = 0; mt < BMT; ++mt) acc[j][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 xr[BMT];
+  u32x4 xr[XPW];
   u32x4 w[2][TN];
   uint32_t gs[2][TN][NG], gz[2][TN][NG];
   const int rd = wk * (4 * BMT * 1024) + lane * 16;  // this wave reads its k-tile's part of a stage
 
   if (nstage > 0) {
-    tiled_load_w<BMT, TN, WK, GM>(c, a, 0, w[0], gs[0], gz[0]);
-    tiled_load_x<BMT, TN, WK>(c, 0, xr);
-    tiled_load_w<BMT, TN, WK, GM>(c, a, 1, w[1], gs[1], gz[1]);
-    tiled_store_x<BMT, TN, WK>(c, smem, lane, xr);
-    tiled_load_x<BMT, TN, WK>(c, 1, xr);
+    tiled_load_w<BMT, TN, WK, GM, WN>(c, a, 0, w[0], gs[0], gz[0]);
+    tiled_load_x<BMT, TN, WK, WN>(c, 0, xr);
+    tiled_load_w<BMT, TN, WK, GM, WN>(c, a, 1, w[1], gs[1], gz[1]);
+    tiled_store_x<BMT, TN, WK, WN>(c, smem, lane, xr);
+    tiled_load_x<BMT, TN, WK, WN>(c, 1, xr);
   }
   __syncthreads();
 
@@ -448,13 +451,13 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled_kernel(const GemmArgs a)
       if (s >= nstage) goto k_loop_done;
       char* const cur = smem + u * STAGE_BYTES;
       char* const nxt = smem + (u ^ 1) * STAGE_BYTES;
-      if constexpr (!(ABL & 2)) tiled_store_x<BMT, TN, WK>(c, nxt, lane, xr);  // stage s+1 (a replay at the very end)
+      if constexpr (!(ABL & 2)) tiled_store_x<BMT, TN, WK, WN>(c, nxt, lane, xr);  // stage s+1 (a replay at the very end)
       QA_STAMP(0)
-      if constexpr (!(ABL & 1)) tiled_load_x<BMT, TN, WK>(c, s + 2, xr);
+      if constexpr (!(ABL & 1)) tiled_load_x<BMT, TN, WK, WN>(c, s + 2, xr);
       QA_STAMP(1)
-      tiled_compute<BMT, TN, WK, GM, ABL>(c, cur + rd, s, w[u], gs[u], gz[u], acc);
+      tiled_compute<BMT, TN, WK, GM, ABL, WN>(c, cur + rd, s, w[u], gs[u], gz[u], acc);
       QA_STAMP(2)
-      if constexpr (!(ABL & 1)) tiled_load_w<BMT, TN, WK, GM>(c, a, s + 2, w[u], gs[u], gz[u]);
+      if constexpr (!(ABL & 1)) tiled_load_w<BMT, TN, WK, GM, WN>(c, a, s + 2, w[u], gs[u], gz[u]);
       QA_STAMP(3)
       if constexpr (!(ABL & 8)) __syncthreads();
       QA_STAMP(4)
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled_kernel(const GemmArgs a)
 k_loop_done:
   if constexpr (ABL & 16) {
     if (lane == 0 && a.dbg) {
-      unsigned long long* o = a.dbg + ((size_t)blockIdx.x * (4 * WK) + wave) * 8;
+      unsigned long long* o = a.dbg + ((size_t)blockIdx.x * (WN * WK) + wave) * 8;
 #pragma unroll
       for (int i = 0; i < 5; ++i) o[i] = ph[i];
       o[5] = nstage;
@@ -477,7 +480,7 @@ k_loop_done:
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int mt = 0; mt < BMT; ++mt) ex[((((wk - 1) * 4 + wn) * TN + j) * BMT + mt) * 64 + lane] = acc[j][mt];
+      for (int mt = 0; mt < BMT; ++mt) ex[((((wk - 1) * WN + wn) * TN + j) * BMT + mt) * 64 + lane] = acc[j][mt];
   }
   __syncthreads();
   if (wk == 0) {
@@ -486,10 +489,10 @@ k_loop_done:
 #pragma unroll
       for (int mt = 0; mt < BMT; ++mt)
 #pragma unroll
-        for (int k = 1; k < WK; ++k) acc[j][mt] += ex[((((k - 1) * 4 + wn) * TN + j) * BMT + mt) * 64 + lane];
+        for (int k = 1; k < WK; ++k) acc[j][mt] += ex[((((k - 1) * WN + wn) * TN + j) * BMT + mt) * 64 + lane];
   }
   if (a.ksplit > 1) {
-    constexpr unsigned SLAB_BYTES = 4 * TN * BMT * 1024;  // one fp32 partial tile
+    constexpr unsigned SLAB_BYTES = WN * TN * BMT * 1024;  // one fp32 partial tile
     const __amdgpu_buffer_rsrc_t rs =
         slab_rsrc(a.slabs + (size_t)blockIdx.x * a.ksplit * (SLAB_BYTES / 4), a.ksplit * SLAB_BYTES);
     const unsigned my = ((wn * TN) * BMT * 64 + lane) * 16;
@@ -693,11 +696,11 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled32_kernel(const GemmArgs 
   const int rd = wk * (4 * BMT * 1024) + lane * 16;
 
   if (nstage > 0) {
-    tiled_load_w<BMT, TN, WK, GM>(c, a, 0, w[0], gs[0], gz[0]);
-    tiled_load_x<BMT, TN, WK>(c, 0, xr);
-    tiled_load_w<BMT, TN, WK, GM>(c, a, 1, w[1], gs[1], gz[1]);
+    tiled_load_w<BMT, TN, WK, GM, 4>(c, a, 0, w[0], gs[0], gz[0]);
+    tiled_load_x<BMT, TN, WK, 4>(c, 0, xr);
+    tiled_load_w<BMT, TN, WK, GM, 4>(c, a, 1, w[1], gs[1], gz[1]);
     tiled32_store_x<BMT, TN, WK>(c, smem, lane, xr);
-    tiled_load_x<BMT, TN, WK>(c, 1, xr);
+    tiled_load_x<BMT, TN, WK, 4>(c, 1, xr);
   }
   __syncthreads();
 
@@ -709,9 +712,9 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled32_kernel(const GemmArgs 
       char* const cur = smem + u * STAGE_BYTES;
       char* const nxt = smem + (u ^ 1) * STAGE_BYTES;
       tiled32_store_x<BMT, TN, WK>(c, nxt, lane, xr);
-      tiled_load_x<BMT, TN, WK>(c, s + 2, xr);
+      tiled_load_x<BMT, TN, WK, 4>(c, s + 2, xr);
       tiled32_compute<BMT, TN, WK, GM>(c, cur + rd, s, w[u], gs[u], gz[u], acc, lane);
-      tiled_load_w<BMT, TN, WK, GM>(c, a, s + 2, w[u], gs[u], gz[u]);
+      tiled_load_w<BMT, TN, WK, GM, 4>(c, a, s + 2, w[u], gs[u], gz[u]);
       __syncthreads();
     }
   }
@@ -856,6 +859,7 @@ struct Plan {
   int kt_per_split;
   int ablate;  // kernel bits 16-20: ablation variant of the tiled kernel (timing experiments only)
   int xcd_gm;  // tiled: rows of the XCD grid over the tile grid (0 = plain order)
+  bool wn2;    // tiled: 2 x 4 wave grid (kernel bit 15)
   bool mfma32; // tiled: v_mfma_f32_32x32x16_f16 flavour (kernel bit 13; measured slower than 16x16x32 in r01)
 };
 
@@ -888,6 +892,7 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   const bool no_xlds = (kernel >> 12) & 1;
   p.ablate = (kernel >> 16) & 31;
   p.mfma32 = ((kernel >> 13) & 1) && p.ablate == 0;
+  p.wn2 = (kernel >> 15) & 1;
   // skinny: one workgroup per 16 tokens x 16..64 channels for all of K (x re-read per channel block, no cross-workgroup
   // reduction); tiled: 32..64 tokens x 128 channels through LDS.  Measured crossover [r01]: the tiled kernel wins from
   // M = 65, and from M = 17 once there are >= 64 tiles of 128 channels (N >= 8192) so that it needs no K split.
@@ -911,7 +916,7 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   } else {
     p.mt = mt_req ? (mt_req == 2 ? 2 : (mt_req == 8 ? 8 : 4)) : (M <= 32 ? 2 : 4);
     p.waves = waves_req == 16 ? 16 : 8;
-    const int wk = p.waves / 4;
+    const int wk = p.wn2 ? 4 : p.waves / 4;
     p.ntiles = (N / 128) * ((M + p.mt * 16 - 1) / (p.mt * 16));
     p.slab_floats = (size_t)4 * 2 * p.mt * 256;
     // one workgroup per CU: split K until the 256 CUs are covered, keeping >= 2 stages per slice
@@ -980,14 +985,14 @@ static void launch_skinny(const Plan& p, const GemmArgs& a, const Launch& L) {
   }
 }
 
-template <int BMT, int WK>
+template <int BMT, int WK, int WN = 4>
 static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
-  constexpr int TN = 2;
-  dim3 grid((a.N / (64 * TN)) * ((a.M + BMT * 16 - 1) / (BMT * 16)), p.ksplit), block(256 * WK);
+  constexpr int TN = 8 / WN;  // 128 channels per workgroup either way
+  dim3 grid((a.N / 128) * ((a.M + BMT * 16 - 1) / (BMT * 16)), p.ksplit), block(64 * WN * WK);
   const unsigned lds = 2 * 4 * WK * BMT * 1024;
 #define QA_TILED_K(GMV, ABLV)                                                                                      \
   do {                                                                                                             \
-    auto kfn = w4a16_tiled_kernel<BMT, TN, WK, GMV, ABLV>;                                                         \
+    auto kfn = w4a16_tiled_kernel<BMT, TN, WK, GMV, ABLV, WN>;                                                        \
     static bool attr_set = false;                                                                                  \
     if (!attr_set) {                                                                                               \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
@@ -995,7 +1000,7 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
     }                                                                                                              \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
-  if (BMT == 4 && p.ablate && a.G == 128) {  // timing experiments (tools/): results are wrong on purpose
+  if constexpr (BMT == 4 && WN == 4) if (p.ablate && a.G == 128) {  // timing experiments (tools/): results are wrong on purpose
     switch (p.ablate) {
       case 1: QA_TILED_K(0, 1); return;
       case 2: QA_TILED_K(0, 2); return;
@@ -1012,7 +1017,7 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
       default: break;
     }
   }
-  if (p.mfma32) {
+  if constexpr (WN == 4) if (p.mfma32) {
 #define QA_TILED32_K(GMV)                                                                                          \
   do {                                                                                                             \
     auto kfn = w4a16_tiled32_kernel<BMT, TN, WK, GMV>;                                                             \
@@ -1078,7 +1083,8 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
       default: launch_skinny<4>(p, a, L); break;
     }
   } else {
-    if (p.mt == 2) launch_tiled<2, 2>(p, a, L);
+    if (p.mt == 4 && p.wn2) launch_tiled<4, 4, 2>(p, a, L);  // 2 waves along N x 4 along K, 64 channels per wave
+    else if (p.mt == 2) launch_tiled<2, 2>(p, a, L);
     else if (p.mt == 8) launch_tiled<8, 2>(p, a, L);
     else if (p.waves == 8) launch_tiled<4, 2>(p, a, L);
     else launch_tiled<4, 4>(p, a, L);
