@@ -384,3 +384,19 @@ def _torch_decode_hidden(model, tok, pos, mask):
         gu = l["gate_up"](_rms_norm(x, l["ln2"])).view(B, 1, cfg.intermediate // 8, 2, 8)
         x = x + l["down"](F.silu(gu[..., 0, :].reshape(B, 1, -1)) * gu[..., 1, :].reshape(B, 1, -1))
     return _rms_norm(x[:, -1], model.norm)
+
+
+@pytest.mark.parametrize("K,N", [(8192, 10240), (8192, 57344), (28672, 8192)])
+@pytest.mark.parametrize("M", [1, 16, 80])
+def test_llama70b_shapes_against_dense_dequant(qa, device, K, N, M):
+    """The largest layers of the e2e configs (Llama-2-70B fused qkv, fused gate_up, down).  The CPU oracle would take minutes
+    here, so the reference is x @ W_deq with W_deq from the dequantisation kernel, which the golden tests pin bit-exactly."""
+    from quick_amd.decoder import random_wqlinear
+    g = torch.Generator(device=device).manual_seed(K + N)
+    layer = random_wqlinear(K, N, 128, device, g)
+    x = torch.randn(M, K, device=device, generator=g).half()
+    w = qa.dequantize_mi355x(layer.qweight, layer.scales, layer.qzeros)
+    want = x.float() @ w.float()
+    y = layer(x)
+    assert tuple(y.shape) == (M, N)
+    assert float((y.float() - want).abs().max() / want.abs().max()) <= TOL
