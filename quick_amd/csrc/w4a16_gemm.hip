@@ -101,27 +101,27 @@ struct SkinnyChunk {
 };
 
 template <int NTW, int GM, int U, bool XLDS>
-__device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS>& c, int kt, int kt_end,
+__device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS>& c, int kt, int kt_last,
                                             const u32x4* __restrict__ wp, size_t wstride, const half_t* xp,
                                             const GemmArgs& a, int n) {
   constexpr int NG = groups_per_tile<GM>();
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) c.w[u][j] = wp[j * wstride + (size_t)min(kt + u, kt_end - 1) * 64];  // past the end: replay
+    for (int j = 0; j < NTW; ++j) c.w[u][j] = wp[j * wstride + (size_t)min(kt + u, kt_last) * 64];  // past the end: replay
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int i = 0; i < NG; ++i)
-        c.raw[u][j][i] = load_group_raw(a.S, a.QZ, group_index<GM>(min(kt + u, kt_end - 1), i * (4 / NG), a.tpg, a.G),
+        c.raw[u][j][i] = load_group_raw(a.S, a.QZ, group_index<GM>(min(kt + u, kt_last), i * (4 / NG), a.tpg, a.G),
                                         n + 16 * j, a.N);
   if constexpr (!XLDS) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) c.xf[u][t] = *(const half8_t*)(xp + min(kt + u, kt_end - 1) * 128 + 32 * t);
+      for (int t = 0; t < 4; ++t) c.xf[u][t] = *(const half8_t*)(xp + min(kt + u, kt_last) * 128 + 32 * t);
   }
 }
 
@@ -145,31 +145,117 @@ __device__ __forceinline__ void skinny_compute(const SkinnyChunk<NTW, GM, U, XLD
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[j] = mfma16(dequant8(c.w[u][j][t], grp[j][group_slot<GM>(t)]), bf, acc[j]);
       }
+    } else {
+      // a skipped (replayed) tile still counts as consumed: otherwise hipcc's s_waitcnt pass carries its loads as
+      // pending into the next iteration and stalls the next prefetch on the write-after-write hazard
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        asm volatile("" ::"v"(c.w[u][j]));
+#pragma unroll
+        for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(c.raw[u][j][i].s2), "v"(c.raw[u][j][i].zq));
+      }
+      if constexpr (!XLDS) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(c.xf[u][t]));
+      }
     }
   }
 }
 
+// Finishes the channel block `nb`: the waves' K partials meet in LDS (buffer `red`), wave j < NTW adds them for
+// channel tile j, joins the other K slices if there are any, applies the epilogue and stores.  Returns with `acc`
+// zeroed for the next block.  One workgroup barrier (two more when K is split across workgroups).
+template <int NTW, int WAVES>
+__device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[NTW], floatx4* red, char* smem, int nb,
+                                              int nblocks, int mb, int ks, int lane, int wave) {
+  const int n16 = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    red[(wave * NTW + j) * 64 + lane] = acc[j];
+    acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  floatx4 sum = floatx4{0.f, 0.f, 0.f, 0.f};
+  if (wave < NTW) {
+    sum = red[wave * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) sum += red[(w * NTW + wave) * 64 + lane];
+  }
+  if (a.ksplit > 1) {  // never combined with the persistent loop: this workgroup owns exactly one block
+    const int tile = mb * nblocks + nb;
+    constexpr unsigned SLAB_BYTES = NTW * 1024;
+    const __amdgpu_buffer_rsrc_t rs = slab_rsrc(a.slabs + (size_t)tile * a.ksplit * (NTW * 256), a.ksplit * SLAB_BYTES);
+    if (wave < NTW) slab_store(rs, ks * SLAB_BYTES + (wave * 64 + lane) * 16, sum);
+    if (!splitk_arrive(a.counters + tile, a.ksplit, (unsigned*)smem)) return;
+    if (wave < NTW) {  // slices are added in index order (own partial from registers at its index): the result does
+      const floatx4 own = sum;  // not depend on which workgroup happened to arrive last
+      for (int o = 0; o < a.ksplit; ++o) {
+        const floatx4 part = o == ks ? own : slab_load(rs, o * SLAB_BYTES + (wave * 64 + lane) * 16);
+        sum = o == 0 ? part : sum + part;
+      }
+    }
+  }
+  if (wave >= NTW) return;
+  const int m = mb * 16 + n16;
+  if (a.silu_mul) {
+    floatx4 up;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) up[r] = __shfl_xor(sum[r], 32);  // lanes q = 0,1 hold gate, their partners q = 2,3 up
+    if (m < a.M && q < 2) {
+      half4_t o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = silu_mul_f16((half_t)sum[r], (half_t)up[r]);
+      *(half4_t*)(a.Y + (size_t)m * (a.N >> 1) + (nb * NTW + wave) * 8 + 4 * q) = o;
+    }
+    return;
+  }
+  const int nc = (nb * NTW + wave) * 16 + 4 * q;  // lane holds channels nc..nc+3 of token m
+  if (m < a.M) {
+    if (a.bias) {
+      const half4_t b = *(const half4_t*)(a.bias + nc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum[r] += (float)b[r];
+    }
+    if (a.residual) {
+      const half4_t b = *(const half4_t*)(a.residual + (size_t)m * a.N + nc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum[r] += (float)b[r];
+    }
+    half4_t o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (half_t)sum[r];
+    *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
+  }
+}
+
+// PERSISTENT launch (gridDim.x < channel blocks; needs ksplit == 1): a workgroup walks the channel blocks
+// blockIdx.x, + gridDim.x, ...  The chunk pipeline runs across block boundaries -- while the last chunk of a block
+// is computed and its partials are reduced, the first chunk of the workgroup's next block is already in flight --
+// so the HBM stream does not stop for the load-latency / compute / reduce phases of each block, and x is copied to
+// LDS once per workgroup instead of once per block.  Consecutive blocks alternate between two reduction buffers,
+// which makes one barrier per block enough.
 template <int NTW, int WAVES, int GM, bool XLDS>
 __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
   static_assert(WAVES >= NTW, "the final reduction assigns one channel tile per wave");
   constexpr int U = XLDS ? (NTW == 1 ? 4 : 2) : (NTW <= 2 ? 2 : 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  floatx4* red = (floatx4*)smem;  // [WAVES][NTW][64]
-  char* xlds = smem + WAVES * NTW * 64 * sizeof(floatx4);
+  const int nblocks = a.N / (16 * NTW);
+  const int nred = (int)gridDim.x < nblocks ? 2 : 1;
+  floatx4* red = (floatx4*)smem;  // [nred][WAVES][NTW][64]
+  char* xlds = smem + nred * (WAVES * NTW * 64 * sizeof(floatx4));
 
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
   const int n16 = lane & 15, q = lane >> 4;
-  const int nb = blockIdx.x, mb = blockIdx.y, ks = blockIdx.z;
+  const int mb = blockIdx.y, ks = blockIdx.z;
   const int KT = a.K >> 7;
   const int wg_begin = ks * a.kt_per_split, wg_end = min(KT, wg_begin + a.kt_per_split);
   const int cnt = wg_end - wg_begin;
   const int kt_begin = wg_begin + cnt * wave / WAVES, kt_end = wg_begin + cnt * (wave + 1) / WAVES;
-  const int n = nb * (16 * NTW) + n16;  // channel of this lane in channel tile 0 (tile j: + 16 j)
-  const LaneSel ls = lane_sel(n);
+  const int kt_last = max(kt_end - 1, kt_begin);  // clamp for replayed loads (a wave may own no k-tile at all)
+  const LaneSel ls = lane_sel(n16);               // channel n = 16 * tile + n16: n % 8 and n % 2 are those of n16
 
   const size_t wstride = (size_t)KT * 64;  // u32x4 elements between consecutive channel tiles
-  const u32x4* wp = a.QW + (size_t)nb * NTW * wstride + lane;
   const int row = min(mb * 16 + n16, a.M - 1);  // rows >= M replay row M-1; never stored
   const half_t* xp = a.X + (size_t)row * a.K + q * 8;
 
@@ -177,8 +263,44 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
 #pragma unroll
   for (int j = 0; j < NTW; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+  // (block, k-tile) of the chunk being computed / of the chunk being loaded; both wave-uniform
+  int nb_cur = blockIdx.x, kt_cur = kt_begin;
+  int nb_nxt = nb_cur, kt_nxt = kt_cur;
+  int parity = 0;
+  // The load of the next chunk is issued in a block that always issues it: a guarded load would make hipcc's
+  // s_waitcnt pass assume the smaller in-flight count and wait for most of the prefetch before the compute.
+#define QA_SKINNY_LOAD(c)                                                                                          \
+  skinny_load<NTW, GM, U, XLDS>(c, kt_nxt, kt_last, a.QW + (size_t)nb_nxt * NTW * wstride + lane, wstride, xp, a,    \
+                                nb_nxt * (16 * NTW) + n16)
+#define QA_SKINNY_ADVANCE(nb, kt)                                                                                  \
+  do {                                                                                                             \
+    kt += U;                                                                                                       \
+    if (kt >= kt_end) {                                                                                            \
+      kt = kt_begin;                                                                                               \
+      nb += gridDim.x;                                                                                             \
+    }                                                                                                              \
+  } while (0)
+#define QA_SKINNY_COMPUTE(ccomp)                                                                                   \
+  skinny_compute<NTW, GM, U, XLDS>(ccomp, kt_cur, kt_end, xl, ls, acc);                                            \
+  if (kt_cur + U >= kt_end) {                                                                                      \
+    skinny_finish<NTW, WAVES>(a, acc, red + parity * (WAVES * NTW * 64), smem, nb_cur, nblocks, mb, ks, lane, wave); \
+    parity = (nred - 1) - parity;                                                                                  \
+  }
+#define QA_SKINNY_STEP(cload, ccomp)                                                                               \
+  if (nb_nxt >= nblocks) { /* the chunk in hand is this workgroup's last */                                        \
+    QA_SKINNY_COMPUTE(ccomp);                                                                                      \
+    break;                                                                                                         \
+  }                                                                                                                \
+  QA_SKINNY_LOAD(cload);                                                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                               \
+  QA_SKINNY_COMPUTE(ccomp);                                                                                        \
+  nb_cur = nb_nxt;                                                                                                 \
+  kt_cur = kt_nxt;                                                                                                 \
+  QA_SKINNY_ADVANCE(nb_nxt, kt_nxt)
+
   SkinnyChunk<NTW, GM, U, XLDS> cA, cB;
-  if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt_begin, kt_end, wp, wstride, xp, a, n);  // HBM requests first
+  QA_SKINNY_LOAD(cA);  // HBM requests first
+  QA_SKINNY_ADVANCE(nb_nxt, kt_nxt);
   __builtin_amdgcn_sched_barrier(0);
 
   const char* xl = nullptr;
@@ -196,74 +318,14 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     __syncthreads();
   }
 
-  for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
-    if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS>(cB, kt + U, kt_end, wp, wstride, xp, a, n);
-    __builtin_amdgcn_sched_barrier(0);
-    skinny_compute<NTW, GM, U, XLDS>(cA, kt, kt_end, xl, ls, acc);
-    if (kt + U >= kt_end) break;
-    if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt + 2 * U, kt_end, wp, wstride, xp, a, n);
-    __builtin_amdgcn_sched_barrier(0);
-    skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, xl, ls, acc);
+  while (true) {
+    QA_SKINNY_STEP(cB, cA);
+    QA_SKINNY_STEP(cA, cB);
   }
-
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) red[(wave * NTW + j) * 64 + lane] = acc[j];
-  __syncthreads();
-  floatx4 sum = floatx4{0.f, 0.f, 0.f, 0.f};
-  if (wave < NTW) {
-    sum = red[wave * 64 + lane];
-#pragma unroll
-    for (int w = 1; w < WAVES; ++w) sum += red[(w * NTW + wave) * 64 + lane];
-  }
-  if (a.ksplit > 1) {
-    const int tile = mb * gridDim.x + nb;
-    constexpr unsigned SLAB_BYTES = NTW * 1024;
-    const __amdgpu_buffer_rsrc_t rs = slab_rsrc(a.slabs + (size_t)tile * a.ksplit * (NTW * 256), a.ksplit * SLAB_BYTES);
-    if (wave < NTW) slab_store(rs, ks * SLAB_BYTES + (wave * 64 + lane) * 16, sum);
-    if (!splitk_arrive(a.counters + tile, a.ksplit, (unsigned*)smem)) return;
-    if (wave < NTW) {  // slices are added in index order (own partial from registers at its index): the result does
-      const floatx4 own = sum;  // not depend on which workgroup happened to arrive last
-      for (int o = 0; o < a.ksplit; ++o) {
-        const floatx4 part = o == ks ? own : slab_load(rs, o * SLAB_BYTES + (wave * 64 + lane) * 16);
-        sum = o == 0 ? part : sum + part;
-      }
-    }
-  }
-  if (a.silu_mul) {
-    if (wave < NTW) {
-      floatx4 up;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) up[r] = __shfl_xor(sum[r], 32);  // lanes q = 0,1 hold gate, their partners q = 2,3 up
-      const int m = mb * 16 + n16;
-      if (m < a.M && q < 2) {
-        half4_t o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = silu_mul_f16((half_t)sum[r], (half_t)up[r]);
-        *(half4_t*)(a.Y + (size_t)m * (a.N >> 1) + (nb * NTW + wave) * 8 + 4 * q) = o;
-      }
-    }
-    return;
-  }
-  if (wave < NTW) {
-    const int m = mb * 16 + n16;
-    const int nc = (nb * NTW + wave) * 16 + 4 * q;  // lane holds channels nc..nc+3 of token m
-    if (m < a.M) {
-      if (a.bias) {
-        const half4_t b = *(const half4_t*)(a.bias + nc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sum[r] += (float)b[r];
-      }
-      if (a.residual) {
-        const half4_t b = *(const half4_t*)(a.residual + (size_t)m * a.N + nc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sum[r] += (float)b[r];
-      }
-      half4_t o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (half_t)sum[r];
-      *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
-    }
-  }
+#undef QA_SKINNY_STEP
+#undef QA_SKINNY_COMPUTE
+#undef QA_SKINNY_ADVANCE
+#undef QA_SKINNY_LOAD
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -853,6 +915,7 @@ struct Plan {
   int mt;      // skinny: channel tiles (of 16) per workgroup, NTW; tiled: token tiles per workgroup, BMT
   int waves;   // skinny: waves per workgroup
   bool xlds;   // skinny: x through an LDS copy
+  int grid_x;  // skinny: workgroups along the channel blocks; fewer than the blocks = persistent workgroups
   int ksplit;  // K slices across workgroups, reduced in-kernel by the last arriver
   int ntiles;  // output tiles (one arrival counter each)
   size_t slab_floats;  // fp32 elements of one partial tile
@@ -942,6 +1005,17 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   if (p.kernel == QUICK_KERNEL_SKINNY) {
     const int rows = std::min(M, 16);
     p.xlds = !no_xlds && M <= 16 && (size_t)rows * (p.kt_per_split * 256 + 16) <= (size_t)kSkinnyXldsBytes;
+    // persistent workgroups once the channel blocks outnumber the resident workgroup slots (kernel bit 21 asks for it,
+    // bits 22-24 = slots per CU, default 2): every workgroup takes the same number of blocks, +-1.  Off by default:
+    // measured [r01] within +-5 % of one block per workgroup for the exact kernel, which is VALU-bound, not HBM-bound
+    const int nblocks = N / (16 * p.mt), mblocks = (M + 15) / 16;
+    const int per_cu = ((kernel >> 22) & 7) ? ((kernel >> 22) & 7) : 2;
+    const int slots = std::max(1, 256 * per_cu / mblocks);
+    p.grid_x = nblocks;
+    if ((((kernel >> 21) & 1) || ((kernel >> 22) & 7)) && p.ksplit == 1 && nblocks > slots) {
+      const int rounds = (nblocks + slots - 1) / slots;
+      p.grid_x = (nblocks + rounds - 1) / rounds;
+    }
   }
   return p;
 }
@@ -956,12 +1030,19 @@ static int group_mode(int G) { return G == 128 ? 0 : (G % 128 == 0 ? 1 : (G == 6
 
 template <int NTW, int WAVES, bool XLDS>
 static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) {
-  dim3 grid(a.N / (16 * NTW), (a.M + 15) / 16, p.ksplit), block(WAVES * 64);
-  size_t lds = (size_t)WAVES * NTW * 1024;
+  dim3 grid(p.grid_x, (a.M + 15) / 16, p.ksplit), block(WAVES * 64);
+  size_t lds = (size_t)(p.grid_x < a.N / (16 * NTW) ? 2 : 1) * WAVES * NTW * 1024;  // reduction buffer(s), see the kernel
   if (XLDS) lds += (size_t)std::min(a.M, 16) * (p.kt_per_split * 256 + 16);
-#define QA_SKINNY(GMV)                                                                                               \
-  hipExtLaunchKernelGGL((w4a16_skinny_kernel<NTW, WAVES, GMV, XLDS>), grid, block, (unsigned)lds, L.st, L.start, L.stop, \
-                        0, a)
+#define QA_SKINNY(GMV)                                                                                             \
+  do {                                                                                                             \
+    auto kfn = w4a16_skinny_kernel<NTW, WAVES, GMV, XLDS>;                                                         \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);         \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)lds, L.st, L.start, L.stop, 0, a);                           \
+  } while (0)
   switch (group_mode(a.G)) {
     case 0: QA_SKINNY(0); break;
     case 1: QA_SKINNY(1); break;
