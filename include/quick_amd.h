@@ -89,8 +89,10 @@ int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scal
 size_t quick_w4a16_workspace_bytes_ex(int M, int K, int N, int group_size, int kernel, int grid_split_k);
 
 /* What may be fused around the GEMM (all optional; zero-initialise the struct):
- *   rmsnorm_weight  reserved (must be NULL): an in-kernel RMSNorm prologue was tried in r01 and cost as much as the
- *                   2 us launch it replaced; quick_w4a16_can_fuse_rmsnorm() returns 0 and quick_rmsnorm_f16 is used.
+ *   rmsnorm_weight  fp16 [K]: x is RMS-normalised (eps = rmsnorm_eps) and scaled by this weight on its way into the
+ *                   kernel, with quick_rmsnorm_f16's rounding points (fp16(fp16(x * rstd) * weight)).  Only where
+ *                   quick_w4a16_can_fuse_rmsnorm() says so -- the small-M kernel that holds x whole in LDS --
+ *                   QUICK_ERR_UNSUPPORTED otherwise (run quick_rmsnorm_f16 first).
  *   bias            fp16 [N]      (replaces the torch add of quick/awq/modules/linear/quick.py:165)
  *   residual        fp16 [M, N], may alias y: the decoder block's `hidden + proj(...)`
  *   silu_mul        output channels are gate/up interleaved in blocks of 8 (16t+i gate, 16t+8+i up, i < 8) and the

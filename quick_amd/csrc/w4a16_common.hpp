@@ -65,6 +65,34 @@ __device__ __forceinline__ half8_t dequant8(uint32_t q, const GroupQ& g) {
   return r;
 }
 
+// One packed dword -> eight fp16 values, the weight still carrying its bias: (1024 + w) for k % 8 in {0,1,4,5}, where
+// the nibble lands in the mantissa of 1024.0 (ulp 1), and (64 + w) for k % 8 in {2,3,6,7}, where it lands four bits
+// higher in the mantissa of 64.0 (ulp 1/16).  Exact, 5 VALU ops; the deferred-zero kernel feeds this to the MFMA and
+// removes bias, zero point and scale once per group in fp32 (see w4a16_gemm.hip).
+__device__ __forceinline__ half8_t biased8(uint32_t q) {
+  const uint32_t m1024 = 0x64006400u, m64 = 0x54005400u;
+  const uint32_t q8 = q >> 8;
+  const u32x4 r = {and_or(q, 0x000f000fu, m1024), and_or(q, 0x00f000f0u, m64), and_or(q8, 0x000f000fu, m1024),
+                   and_or(q8, 0x00f000f0u, m64)};
+  return __builtin_bit_cast(half8_t, r);
+}
+
+// v + (v of the lane the DPP control selects); CTRL: 0xB1 = quad_perm[1,0,3,2], 0x4E = quad_perm[2,3,0,1],
+// 0x141 = row_half_mirror, 0x140 = row_mirror
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over aligned groups of L = 4, 8 or 16 lanes, delivered to every lane of the group
+template <int L>
+__device__ __forceinline__ float lanes_sum(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  if constexpr (L >= 8) v = dpp_add<0x141>(v);
+  if constexpr (L >= 16) v = dpp_add<0x140>(v);
+  return v;
+}
+
 // Raw group constants as they come out of memory; make_group() is applied at the point of use so that a
 // prefetch of the next k-tile's constants carries no dependent ALU work (which would make the compiler
 // wait for the whole in-order load queue right after issuing it).  Both are plain dword loads: the

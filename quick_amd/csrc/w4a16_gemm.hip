@@ -43,6 +43,8 @@ struct GemmArgs {
   int kt_per_split;
   int xcd_gm;  // tiled: XCD-aware tile order -- the 8 XCDs form an xcd_gm x (8/xcd_gm) grid over (token, channel) blocks; 0 = plain order
   unsigned long long* dbg;  // ablation bit 16: per-wave phase cycle totals [workgroup][wave][8]
+  const half_t* ln_w;  // deferred-zero skinny kernel: RMSNorm weight [K] applied to x on its way into LDS, or null
+  float ln_eps;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -162,16 +164,78 @@ __device__ __forceinline__ void skinny_compute(const SkinnyChunk<NTW, GM, U, XLD
   }
 }
 
+// DEFERRED-ZERO compute (M <= 16, x in LDS).  The exact kernel spends 13 VALU ops per packed dword on fp16((w - z) * s)
+// and the matrix core hides none of them; at M <= 16 that, not HBM, bounds the kernel.  Here the roles of the MFMA
+// operands are swapped -- x is the A operand (rows = tokens), the still-biased weights biased8() the B operand (columns =
+// channels) -- so that a lane's accumulators are 4 tokens of ONE channel and the group constants are per-lane scalars:
+//     y[m, n] = sum_units s[g, n] * ( sum_{k in unit} x[m, k] * (b_k + w[n, k])  -  C[unit, m]  -  z[g, n] * A[unit, m] )
+// with b_k = 1024 or 64 (see biased8), A[unit, m] = sum_k x[m, k] and C[unit, m] = sum_k b_k x[m, k] tabulated once per
+// workgroup while x is copied to LDS (`tab`: per unit 16 x A then 16 x -C, fp32).  A unit is min(G, 128) consecutive k.
+// The accumulator of a unit starts at -C, so the epilogue of a unit is 2 FMAs per register.  5 VALU per dword plus
+// ~12 per (unit, channel tile) instead of 13 + 5; products x * (b + w) are exact in the fp32 accumulator and w - z is
+// never rounded to fp16, i.e. this path differs from the exact kernel by less than the latter's own weight rounding
+// (2^-11 relative per weight) -- see DESIGN.md for the bound and tests/test_gemm_gpu.py for the comparison.
+template <int NTW, int GM, int U>
+__device__ __forceinline__ void skinny_compute_dz(const SkinnyChunk<NTW, GM, U, true>& c, int kt, int kt_end,
+                                                  const char* xl, const float* tab, const LaneSel& ls,
+                                                  floatx4 (&acc)[NTW]) {
+  constexpr int NG = groups_per_tile<GM>();  // units per 128-k tile
+  constexpr int TPU = 4 / NG;                // k-steps per unit
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (kt + u < kt_end) {  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const float* tp = tab + ((kt + u) * NG + i) * 32;
+        const floatx4 xa = *(const floatx4*)tp;
+        const floatx4 nc = *(const floatx4*)(tp + 16);
+        floatx4 g[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) g[j] = nc;
+#pragma unroll
+        for (int t = i * TPU; t < (i + 1) * TPU; ++t) {
+          const half8_t xf = *(const half8_t*)(xl + ((kt + u) * 128 + 32 * t) * 2);
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) g[j] = mfma16(xf, biased8(c.w[u][j][t]), g[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          const float s = (float)as_h2(__builtin_amdgcn_perm(c.raw[u][j][i].s2, c.raw[u][j][i].s2, ls.sperm))[0];
+          const float z = (float)__builtin_amdgcn_ubfe(c.raw[u][j][i].zq, ls.zshift, 4u);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-z, xa[r], g[j][r]), acc[j][r]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        asm volatile("" ::"v"(c.w[u][j]));
+#pragma unroll
+        for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(c.raw[u][j][i].s2), "v"(c.raw[u][j][i].zq));
+      }
+    }
+  }
+}
+
 // Finishes the channel block `nb`: the waves' K partials meet in LDS (buffer `red`), wave j < NTW adds them for
 // channel tile j, joins the other K slices if there are any, applies the epilogue and stores.  Returns with `acc`
 // zeroed for the next block.  One workgroup barrier (two more when K is split across workgroups).
-template <int NTW, int WAVES>
+// TR: the accumulators come from the deferred-zero path (lane = channel n16, registers = tokens 4q..4q+3) and are
+// written to LDS transposed, so that everything after the barrier sees the usual fragment (lane = token, registers =
+// channels 4q..4q+3).
+template <int NTW, int WAVES, bool TR>
 __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[NTW], floatx4* red, char* smem, int nb,
                                               int nblocks, int mb, int ks, int lane, int wave) {
   const int n16 = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
-    red[(wave * NTW + j) * 64 + lane] = acc[j];
+    if constexpr (TR) {
+      float* rf = (float*)(red + (wave * NTW + j) * 64) + 64 * (n16 >> 2) + 16 * q + (n16 & 3);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rf[4 * r] = acc[j][r];
+    } else {
+      red[(wave * NTW + j) * 64 + lane] = acc[j];
+    }
     acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
@@ -234,9 +298,10 @@ __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[
 // so the HBM stream does not stop for the load-latency / compute / reduce phases of each block, and x is copied to
 // LDS once per workgroup instead of once per block.  Consecutive blocks alternate between two reduction buffers,
 // which makes one barrier per block enough.
-template <int NTW, int WAVES, int GM, bool XLDS>
+template <int NTW, int WAVES, int GM, bool XLDS, bool DZ>
 __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
   static_assert(WAVES >= NTW, "the final reduction assigns one channel tile per wave");
+  static_assert(XLDS || !DZ, "the deferred-zero path tabulates x while copying it to LDS");
   constexpr int U = XLDS ? (NTW == 1 ? 4 : 2) : (NTW <= 2 ? 2 : 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nblocks = a.N / (16 * NTW);
@@ -281,9 +346,11 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     }                                                                                                              \
   } while (0)
 #define QA_SKINNY_COMPUTE(ccomp)                                                                                   \
-  skinny_compute<NTW, GM, U, XLDS>(ccomp, kt_cur, kt_end, xl, ls, acc);                                            \
+  if constexpr (DZ) skinny_compute_dz<NTW, GM, U>(ccomp, kt_cur, kt_end, xl, tab, ls, acc);                        \
+  else skinny_compute<NTW, GM, U, XLDS>(ccomp, kt_cur, kt_end, xl, ls, acc);                                       \
   if (kt_cur + U >= kt_end) {                                                                                      \
-    skinny_finish<NTW, WAVES>(a, acc, red + parity * (WAVES * NTW * 64), smem, nb_cur, nblocks, mb, ks, lane, wave); \
+    skinny_finish<NTW, WAVES, DZ>(a, acc, red + parity * (WAVES * NTW * 64), smem, nb_cur, nblocks, mb, ks, lane,  \
+                                  wave);                                                                           \
     parity = (nred - 1) - parity;                                                                                  \
   }
 #define QA_SKINNY_STEP(cload, ccomp)                                                                               \
@@ -304,16 +371,77 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   __builtin_amdgcn_sched_barrier(0);
 
   const char* xl = nullptr;
+  const float* tab = nullptr;
   if constexpr (XLDS) {
-    // copy x[mb*16 .. , wg_begin*128 .. wg_end*128) -> LDS [rows][pitch]
+    // copy x[mb*16 .. , wg_begin*128 .. wg_end*128) -> LDS [rows][pitch]; DZ: tabulate the unit sums on the way
     const int rows = min(16, a.M - mb * 16);
     const int kc = cnt * 16;  // 16-byte chunks per row
     const int pitch = cnt * 256 + 16;
     xl = xlds + min(n16, rows - 1) * pitch + q * 16 - wg_begin * 256;
-    for (int i = threadIdx.x; i < rows * kc; i += WAVES * 64) {
-      const int r = i / kc, c = i - r * kc;
-      const u32x4 v = *(const u32x4*)(a.X + (size_t)(mb * 16 + r) * a.K + wg_begin * 128 + c * 8);
-      *(u32x4*)(xlds + r * pitch + c * 16) = v;
+    float* tab0 = (float*)(xlds + rows * pitch);
+    constexpr int NG = groups_per_tile<GM>();
+    constexpr int L = 16 / NG;  // lanes (16-byte chunks) per unit
+    if constexpr (DZ) tab = tab0 + 4 * q - wg_begin * NG * 32;
+    if constexpr (DZ) {
+      if (a.ln_w) {
+        // RMSNorm prologue (needs the whole row: ksplit == 1).  Pass 1 copies x raw and sums its squares per row;
+        // pass 2, below, finds x in LDS instead of in global memory, scales it in place and tabulates the result.
+        float* ssq = (float*)smem;  // [rows][WAVES], in the still unused reduction buffer
+        for (int r = 0; r < rows; ++r) {
+          const half_t* src = a.X + (size_t)(mb * 16 + r) * a.K;
+          float ss = 0.f;
+          for (int c = threadIdx.x; c < kc; c += WAVES * 64) {
+            const u32x4 v = *(const u32x4*)(src + c * 8);
+            *(u32x4*)(xlds + r * pitch + c * 16) = v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ss = __builtin_amdgcn_fdot2(as_h2(v[i]), as_h2(v[i]), ss, false);
+          }
+          ss = wave_sum(ss);
+          if (lane == 0) ssq[r * WAVES + wave] = ss;
+        }
+        __syncthreads();
+      }
+    }
+    for (int r = 0; r < rows; ++r) {
+      const half_t* src = a.X + (size_t)(mb * 16 + r) * a.K + wg_begin * 128;
+      float inv = 0.f;
+      if constexpr (DZ) {
+        if (a.ln_w) {
+          float ss = 0.f;
+#pragma unroll
+          for (int w = 0; w < WAVES; ++w) ss += ((const float*)smem)[r * WAVES + w];
+          inv = rsqrtf(ss / (float)a.K + a.ln_eps);
+        }
+      }
+      for (int c = threadIdx.x; c < kc; c += WAVES * 64) {  // kc % 16 == 0: rows of 16 lanes are all in or all out
+        u32x4 v;
+        if constexpr (DZ) {
+          if (a.ln_w) {  // fp16(fp16(x * inv) * weight): the rounding points of quick_rmsnorm_f16 (and of torch)
+            const half8_t xv = *(const half8_t*)(xlds + r * pitch + c * 16), gv = *(const half8_t*)(a.ln_w + c * 8);
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)((half_t)((float)xv[j] * inv) * gv[j]);
+            v = __builtin_bit_cast(u32x4, o);
+          } else {
+            v = *(const u32x4*)(src + c * 8);
+          }
+        } else {
+          v = *(const u32x4*)(src + c * 8);
+        }
+        *(u32x4*)(xlds + r * pitch + c * 16) = v;
+        if constexpr (DZ) {
+          const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+          const float lo = __builtin_amdgcn_fdot2(as_h2(v[0]), one2, __builtin_amdgcn_fdot2(as_h2(v[2]), one2, 0.f, false), false);
+          const float hi = __builtin_amdgcn_fdot2(as_h2(v[1]), one2, __builtin_amdgcn_fdot2(as_h2(v[3]), one2, 0.f, false), false);
+          const float sa = lanes_sum<L>(lo + hi);
+          const float sc = lanes_sum<L>(1024.f * lo + 64.f * hi);
+          if ((lane & (L - 1)) == 0) {
+            float* t = tab0 + (c / L) * 32 + r;
+            t[0] = sa;
+            t[16] = -sc;
+          }
+        }
+      }
     }
     __syncthreads();
   }
@@ -916,6 +1044,7 @@ struct Plan {
   int waves;   // skinny: waves per workgroup
   bool xlds;   // skinny: x through an LDS copy
   int grid_x;  // skinny: workgroups along the channel blocks; fewer than the blocks = persistent workgroups
+  bool dz;     // skinny: deferred-zero compute (needs xlds)
   int ksplit;  // K slices across workgroups, reduced in-kernel by the last arriver
   int ntiles;  // output tiles (one arrival counter each)
   size_t slab_floats;  // fp32 elements of one partial tile
@@ -944,11 +1073,20 @@ static int check_shapes(int M, int K, int N, int G) {
   return QUICK_OK;
 }
 
-static constexpr int kSkinnyXldsBytes = 64 * 1024;  // LDS budget of the x copy
+static constexpr size_t kLdsPerCu = 160 * 1024;  // gfx950
+
+// LDS of one skinny workgroup: reduction buffer(s), the x copy, the deferred-zero table
+static size_t skinny_lds_bytes(int M, int G, int ntw, int waves, int kt_per_split, bool persistent, bool xlds, bool dz) {
+  size_t b = (size_t)(persistent ? 2 : 1) * waves * ntw * 1024;
+  if (xlds) b += (size_t)std::min(M, 16) * (kt_per_split * 256 + 16);
+  if (dz) b += (size_t)kt_per_split * (G >= 128 ? 1 : (G == 64 ? 2 : 4)) * 128;
+  return b;
+}
 
 // `kernel`: low 4 bits = family (QUICK_KERNEL_*), bits 4-7 = token tiles (0 = auto), bits 8-11 = skinny waves / 4
-// (0 = auto), bit 12 = skinny: forbid the LDS copy of x.  Upper bits are for tests and tuning only.
-static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
+// (0 = auto), bit 12 = skinny: forbid the LDS copy of x, bit 25 = skinny: exact per-weight dequantisation instead of
+// the deferred-zero path.  Upper bits are for tests and tuning only.
+static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) {
   Plan p{};
   const int KT = K / 128;
   const int family = kernel & 15, mt_req = (kernel >> 4) & 15, waves_req = ((kernel >> 8) & 15) * 4;
@@ -1003,18 +1141,42 @@ static Plan make_plan(int M, int K, int N, int kernel, int grid_split_k) {
   }
   p.ksplit = (KT + p.kt_per_split - 1) / p.kt_per_split;
   if (p.kernel == QUICK_KERNEL_SKINNY) {
-    const int rows = std::min(M, 16);
-    p.xlds = !no_xlds && M <= 16 && (size_t)rows * (p.kt_per_split * 256 + 16) <= (size_t)kSkinnyXldsBytes;
-    // persistent workgroups once the channel blocks outnumber the resident workgroup slots (kernel bit 21 asks for it,
-    // bits 22-24 = slots per CU, default 2): every workgroup takes the same number of blocks, +-1.  Off by default:
-    // measured [r01] within +-5 % of one block per workgroup for the exact kernel, which is VALU-bound, not HBM-bound
     const int nblocks = N / (16 * p.mt), mblocks = (M + 15) / 16;
-    const int per_cu = ((kernel >> 22) & 7) ? ((kernel >> 22) & 7) : 2;
-    const int slots = std::max(1, 256 * per_cu / mblocks);
+    const bool exact = (kernel >> 25) & 1, flip = (kernel >> 21) & 1;
+    const int cu_req = (kernel >> 22) & 7;  // workgroup slots per CU for a persistent launch, 0 = choose
     p.grid_x = nblocks;
-    if ((((kernel >> 21) & 1) || ((kernel >> 22) & 7)) && p.ksplit == 1 && nblocks > slots) {
-      const int rounds = (nblocks + slots - 1) / slots;
-      p.grid_x = (nblocks + rounds - 1) / rounds;
+    // Deferred-zero path (M <= 16, one channel tile per workgroup, x and its unit sums in LDS).  It launches PERSISTENT
+    // workgroups -- each walks the channel blocks b, b + grid, ... with the chunk pipeline running across blocks -- so
+    // that the x copy and the table are paid once per workgroup.  Slots per CU c in {1, 2} (what LDS allows): two
+    // co-resident workgroups finish a block each ~1.6x slower than one alone [r01 sweep], so pick the c with the
+    // smaller rounds(c) * (c == 1 ? 1 : 1.6).  With M > 2 the copy + table only pay off from two blocks per workgroup
+    // [r01: N = 4096, M = 8: 7.1 us against 5.4 us exact]; below that the exact path runs.
+    p.dz = false;
+    const size_t lds_dz = skinny_lds_bytes(M, G, 1, p.waves, p.kt_per_split, true, true, true);
+    const int fit = (int)std::min<size_t>(2, kLdsPerCu / lds_dz);
+    if (!no_xlds && !exact && p.mt == 1 && M <= 16 && fit >= 1) {
+      int c = 1;
+      if (cu_req) c = std::min(cu_req, 8);
+      else if (fit >= 2 && ((nblocks + 511) / 512) * 1.6 < (double)((nblocks + 255) / 256)) c = 2;
+      int rounds = (nblocks + 256 * c - 1) / (256 * c);
+      if (!cu_req && M > 2 && rounds < 2 && c == 2) {
+        c = 1;
+        rounds = (nblocks + 255) / 256;
+      }
+      if (M <= 2 || ((kernel >> 26) & 1) || (rounds >= 2 && p.ksplit == 1)) {  // bit 26: tests force the path
+        p.dz = p.xlds = true;
+        if (!flip && p.ksplit == 1 && rounds >= 2) p.grid_x = (nblocks + rounds - 1) / rounds;
+      }
+    }
+    if (!p.dz) {
+      // exact path: x through LDS while the copy is small (64 KiB), else fragments straight from L2; persistent
+      // launches measured within +-5 % of one block per workgroup [r01] and are off unless asked for
+      p.xlds = !no_xlds && M <= 16 && (size_t)std::min(M, 16) * (p.kt_per_split * 256 + 16) <= (size_t)64 * 1024;
+      const int slots = std::max(1, 256 * (cu_req ? cu_req : 2) / mblocks);
+      if ((flip || cu_req) && p.ksplit == 1 && nblocks > slots) {
+        const int rounds = (nblocks + slots - 1) / slots;
+        p.grid_x = (nblocks + rounds - 1) / rounds;
+      }
     }
   }
   return p;
@@ -1028,17 +1190,16 @@ static size_t workspace_need(const Plan& p) {
 
 static int group_mode(int G) { return G == 128 ? 0 : (G % 128 == 0 ? 1 : (G == 64 ? 2 : (G == 32 ? 3 : 4))); }
 
-template <int NTW, int WAVES, bool XLDS>
+template <int NTW, int WAVES, bool XLDS, bool DZ>
 static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) {
   dim3 grid(p.grid_x, (a.M + 15) / 16, p.ksplit), block(WAVES * 64);
-  size_t lds = (size_t)(p.grid_x < a.N / (16 * NTW) ? 2 : 1) * WAVES * NTW * 1024;  // reduction buffer(s), see the kernel
-  if (XLDS) lds += (size_t)std::min(a.M, 16) * (p.kt_per_split * 256 + 16);
+  const size_t lds = skinny_lds_bytes(a.M, a.G, NTW, WAVES, p.kt_per_split, p.grid_x < a.N / (16 * NTW), XLDS, DZ);
 #define QA_SKINNY(GMV)                                                                                             \
   do {                                                                                                             \
-    auto kfn = w4a16_skinny_kernel<NTW, WAVES, GMV, XLDS>;                                                         \
+    auto kfn = w4a16_skinny_kernel<NTW, WAVES, GMV, XLDS, DZ>;                                                     \
     static bool attr_set = false;                                                                                  \
     if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);         \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);     \
       attr_set = true;                                                                                             \
     }                                                                                                              \
     hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)lds, L.st, L.start, L.stop, 0, a);                           \
@@ -1055,14 +1216,22 @@ static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) 
 
 template <int NTW>
 static void launch_skinny(const Plan& p, const GemmArgs& a, const Launch& L) {
+  if constexpr (NTW == 1) {
+    if (p.dz) {  // M <= 16: one channel tile per workgroup
+      if (p.waves == 4) launch_skinny_gm<1, 4, true, true>(p, a, L);
+      else if (p.waves == 16) launch_skinny_gm<1, 16, true, true>(p, a, L);
+      else launch_skinny_gm<1, 8, true, true>(p, a, L);
+      return;
+    }
+  }
   if (p.xlds) {
-    if (p.waves == 4) launch_skinny_gm<NTW, 4, true>(p, a, L);
-    else if (p.waves == 16) launch_skinny_gm<NTW, 16, true>(p, a, L);
-    else launch_skinny_gm<NTW, 8, true>(p, a, L);
+    if (p.waves == 4) launch_skinny_gm<NTW, 4, true, false>(p, a, L);
+    else if (p.waves == 16) launch_skinny_gm<NTW, 16, true, false>(p, a, L);
+    else launch_skinny_gm<NTW, 8, true, false>(p, a, L);
   } else {
-    if (p.waves == 4) launch_skinny_gm<NTW, 4, false>(p, a, L);
-    else if (p.waves == 16) launch_skinny_gm<NTW, 16, false>(p, a, L);
-    else launch_skinny_gm<NTW, 8, false>(p, a, L);
+    if (p.waves == 4) launch_skinny_gm<NTW, 4, false, false>(p, a, L);
+    else if (p.waves == 16) launch_skinny_gm<NTW, 16, false, false>(p, a, L);
+    else launch_skinny_gm<NTW, 8, false, false>(p, a, L);
   }
 }
 
@@ -1143,12 +1312,13 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   if (int rc = check_shapes(M, K, N, G)) return rc;
   if (!x || !qweight || !scales || !qzeros || !y) return fail(QUICK_ERR_INVALID_ARGUMENT, "null tensor pointer");
   if ((kernel & 15) > QUICK_KERNEL_TILED || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
-  const Plan p = make_plan(M, K, N, kernel, grid_split_k);
+  const Plan p = make_plan(M, K, N, G, kernel, grid_split_k);
   if (f.silu_mul && (f.bias || f.residual)) return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual");
   if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
-  if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: not available (measured slower than a separate launch)");
+  if (f.ln_w && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1))
+    return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
-             (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr};
+             (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr, (const half_t*)f.ln_w, f.ln_eps};
   if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
   if (p.ksplit > 1) {
     const size_t need = workspace_need(p);
@@ -1186,7 +1356,7 @@ const char* quick_amd_last_error(void) { return g_err; }
 
 size_t quick_w4a16_workspace_bytes_ex(int M, int K, int N, int group_size, int kernel, int grid_split_k) {
   if (check_shapes(M, K, N, group_size) != QUICK_OK) return 0;
-  const Plan p = make_plan(M, K, N, kernel, grid_split_k);
+  const Plan p = make_plan(M, K, N, group_size, kernel, grid_split_k);
   return workspace_need(p);
 }
 
@@ -1220,8 +1390,11 @@ int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* s
 }
 
 int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size) {
-  (void)M; (void)K; (void)N; (void)group_size;
-  return 0;  // r01: the in-kernel RMSNorm prologue cost as much as the 2 us launch it replaced and was removed
+  if (check_shapes(M, K, N, group_size) != QUICK_OK) return 0;
+  // the deferred-zero skinny kernel copies (and tabulates) x per workgroup anyway: normalising on the way costs a
+  // second pass over LDS, not a launch
+  const Plan p = make_plan(M, K, N, group_size, QUICK_KERNEL_AUTO, 0);
+  return p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1;
 }
 
 int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const void* const* scales,

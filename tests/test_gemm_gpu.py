@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
 
 TOL = 2e-3
 SKINNY, TILED = 1, 2
+SKINNY_EXACT = SKINNY | (1 << 25)     # M <= 16: per-weight fp16((w - z) * s) instead of the deferred-zero path
+SKINNY_DZ = SKINNY | (1 << 26)        # M <= 16: deferred-zero path even where the planner would not pick it
 
 
 def _dev(a, device):
@@ -42,7 +44,8 @@ def qa(device):
 GOLD = [p for p in golden_files("exact_") if "k64" not in p] + golden_files("quant_")
 
 
-@pytest.mark.parametrize("kernel_id,ksplit", [(0, 0), (SKINNY, 1), (SKINNY, 2), (TILED, 1), (TILED, 2)])
+@pytest.mark.parametrize("kernel_id,ksplit", [(0, 0), (SKINNY_DZ, 1), (SKINNY_DZ, 2), (SKINNY_EXACT, 1), (SKINNY_EXACT, 2),
+                                              (TILED, 1), (TILED, 2)])
 @pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[:-4])
 def test_golden_fixture_forward(qa, device, path, kernel_id, ksplit):
     g = load_golden(path)
@@ -104,13 +107,64 @@ TILED_MFMA32 = TILED | (1 << 13)      # experimental 32x32x16 flavour of the til
 TILED_16WAVES = TILED | (4 << 8)      # 4 x 4 waves per workgroup
 
 
-@pytest.mark.parametrize("kernel_id", [0, SKINNY, TILED, TILED_MFMA32, TILED_16WAVES])
+@pytest.mark.parametrize("kernel_id", [0, SKINNY_DZ, SKINNY_EXACT, TILED, TILED_MFMA32, TILED_16WAVES])
 @pytest.mark.parametrize("M,K,N,G", SHAPES)
 def test_synthetic_sweep(qa, device, M, K, N, G, kernel_id):
     x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M * 7 + K + N + G)
     want = oracle.w4a16_forward(x, iw, s, z, G)
     y = qa.gemm_forward(_dev(x, device), *_pack_dev(iw, s, z, device), kernel_id=kernel_id)
     assert rel_err(y.cpu().numpy(), want) <= TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# skinny kernel, M <= 16: deferred-zero vs exact arithmetic, persistent vs one-block-per-workgroup launches
+# ------------------------------------------------------------------------------------------------
+PERSIST_FLIP = 1 << 21                # flips the default (deferred-zero: persistent, exact: not)
+ONE_WG_PER_CU = 1 << 22
+
+
+@pytest.mark.parametrize("variant", [0, PERSIST_FLIP, ONE_WG_PER_CU], ids=["default", "flip", "1wg"])
+@pytest.mark.parametrize("base", [SKINNY_DZ, SKINNY_EXACT], ids=["dz", "exact"])
+@pytest.mark.parametrize("M,K,N,G", [(1, 1024, 8320, 128), (5, 512, 8320, 64), (16, 512, 8448, 32), (3, 1024, 8320, 256),
+                                     (9, 640, 8320, 128), (16, 4096, 4224, 128), (2, 384, 8320, 96)])
+def test_skinny_variants_many_channel_blocks(qa, device, M, K, N, G, base, variant):
+    # N / 16 > 512 channel blocks: the persistent launches walk >= 2 blocks per workgroup
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + K + N + G)
+    want = oracle.w4a16_forward(x, iw, s, z, G)
+    bias = np.linspace(-1, 1, N).astype(np.float16)
+    y = qa.gemm_forward(_dev(x, device), *_pack_dev(iw, s, z, device), bias=_dev(bias, device), kernel_id=base | variant)
+    assert rel_err(y.cpu().numpy(), want.astype(np.float32) + bias.astype(np.float32)) <= TOL
+
+
+@pytest.mark.parametrize("M,K,N,G", [(1, 4096, 4096, 128), (8, 4096, 11008, 128), (16, 2048, 512, 64), (4, 1024, 256, 32)])
+def test_deferred_zero_matches_exact_kernel(qa, device, M, K, N, G):
+    """The deferred-zero path keeps w - z unrounded; the exact path (and the reference) round (w - z) * s to fp16 per
+    weight.  Both must sit within TOL of the oracle, and within 1e-3 of each other."""
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=K + 3 * N + M)
+    want = oracle.w4a16_forward(x, iw, s, z, G)
+    packed = _pack_dev(iw, s, z, device)
+    ydz = qa.gemm_forward(_dev(x, device), *packed, kernel_id=SKINNY_DZ).cpu().numpy()
+    yex = qa.gemm_forward(_dev(x, device), *packed, kernel_id=SKINNY_EXACT).cpu().numpy()
+    assert rel_err(ydz, want) <= TOL and rel_err(yex, want) <= TOL
+    assert rel_err(ydz, yex) <= 1e-3
+
+
+def test_deferred_zero_with_activation_outliers(qa, device):
+    """Massive activations (a few |x| ~ 2000 among |x| ~ 1) put 1024 * x into the fp32 accumulator before the group's
+    bias term is removed; the cancellation error has to stay far below the tolerance."""
+    M, K, N, G = 4, 4096, 1024, 128
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=21)
+    rng = np.random.default_rng(5)
+    x = x.astype(np.float32)
+    x[:, rng.integers(0, K, 6)] = rng.choice([-2048.0, 1536.0, 2047.0], size=(M, 6))
+    x[2] = np.abs(x[2])                      # one all-positive row: the largest group sums
+    x = x.astype(np.float16)
+    want = oracle.w4a16_forward(x, iw, s, z, G)
+    packed = _pack_dev(iw, s, z, device)
+    ydz = qa.gemm_forward(_dev(x, device), *packed, kernel_id=SKINNY_DZ).cpu().numpy()
+    yex = qa.gemm_forward(_dev(x, device), *packed, kernel_id=SKINNY_EXACT).cpu().numpy()
+    assert np.isfinite(ydz).all()
+    assert rel_err(ydz, want) <= TOL and rel_err(yex, want) <= TOL
 
 
 @pytest.mark.parametrize("ksplit", [2, 3, 8])
@@ -329,9 +383,35 @@ def test_decode_glue_kernels_against_torch(qa, device):
         assert (y_res.float() - (y.float() + res.float())).abs().max() <= 2e-2
         y_act = qa.gemm_forward(xd, *packed, silu_mul=True)
         close(y_act, K_.silu_mul(y))
-        assert not K_.can_fuse_rmsnorm(M, Kd, N, G)           # prologue removed in r01 (no faster than the 2 us launch)
-        with pytest.raises(NotImplementedError):
-            qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw)
+        assert K_.can_fuse_rmsnorm(M, Kd, N, G) == (M == 1)   # the deferred-zero skinny kernel carries the prologue
+        if M == 1:
+            y_ln = qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw)
+            y_two = qa.gemm_forward(K_.rmsnorm(xd, lnw), *packed)
+            assert rel_err(y_ln.cpu().numpy(), y_two.cpu().numpy()) <= TOL
+        else:
+            with pytest.raises(NotImplementedError):
+                qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw)
+
+
+@pytest.mark.parametrize("M,K,N,G", [(1, 4096, 12288, 128), (1, 4096, 4096, 128), (8, 4096, 11008, 128), (16, 1024, 8320, 64),
+                                     (3, 11008, 8320, 128)])
+def test_rmsnorm_prologue_matches_two_launches(qa, device, M, K, N, G):
+    """gemm(rmsnorm(x) * w) in one launch: the prologue reproduces quick_rmsnorm_f16's rounding points, so the only
+    difference to the two-launch result is the summation order of the squares (an ulp of the row scale)."""
+    from quick_amd import kernels as K_
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + K + N)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device) * 3
+    lnw = (torch.rand(K, device=device) + 0.5).half()
+    res = torch.randn(M, N, device=device).half()
+    assert K_.can_fuse_rmsnorm(M, K, N, G)
+    y1 = qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw, rmsnorm_eps=1e-5, residual=res)
+    y2 = qa.gemm_forward(K_.rmsnorm(xd, lnw, 1e-5), *packed, residual=res)
+    assert rel_err(y1.cpu().numpy(), y2.cpu().numpy()) <= 1e-3
+    # and against torch's RMSNorm + the oracle GEMM
+    xn = (xd.float() * torch.rsqrt(xd.float().pow(2).mean(-1, keepdim=True) + 1e-5)).half() * lnw
+    want = oracle.w4a16_forward(xn.cpu().numpy(), iw, s, z, G).astype(np.float32) + res.cpu().numpy().astype(np.float32)
+    assert rel_err(y1.cpu().numpy(), want) <= TOL
 
 
 def test_fused_decode_step_matches_torch_glue(qa, device):
