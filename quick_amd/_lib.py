@@ -2,7 +2,9 @@
 import ctypes
 import os
 
-from .build import LIB
+from .build import LIB as _DEFAULT_LIB
+
+LIB = _DEFAULT_LIB   # the shared object in use (see load())
 
 _P, _I, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
@@ -39,8 +41,9 @@ _lib = None
 
 def load():
     """Load the in-tree shared object; raise if it is missing (build it with `python -m quick_amd.build`)."""
-    global _lib
+    global _lib, LIB
     if _lib is None:
+        LIB = os.environ.get("QUICK_AMD_LIB_OVERRIDE") or _DEFAULT_LIB   # override: A/B timing of kernel builds (tools/ab.sh)
         if not os.path.exists(LIB):
             raise ImportError(
                 f"{LIB} is missing: the HIP extension has not been built. "
