@@ -163,7 +163,9 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const half_t* __r
 // cache positions 0..*pos-1 from HBM/L2 and position *pos from those registers, and the group's first head appends
 // the rotated k and the v to the caches.  Nobody reads cache position *pos in this launch, so there is no ordering
 // problem between the workgroups of a group.
-__device__ __forceinline__ void rope8(const half8_t x, const half8_t c, const half8_t sn, int sub, float (&r)[8]) {
+__device__ __forceinline__ void rope8(const half8_t x, const half_t* __restrict__ cos_row, const half_t* __restrict__ sin_row,
+                                      int sub, float (&r)[8]) {
+  const half8_t c = *(const half8_t*)(cos_row + sub * 8), sn = *(const half8_t*)(sin_row + sub * 8);
   const float sign = sub < 8 ? -1.f : 1.f;  // rotate_half: dims 0..63 pair with -x[i+64], dims 64..127 with +x[i-64]
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -182,36 +184,17 @@ __global__ __launch_bounds__(256) void decode_rope_attention_kernel(
   float* sc = (float*)smem_raw;      // [len] scores / probabilities
   float* red = sc + ((L + 3) & ~3);  // [4] per-wave partials, then [4][D] output partials
   const int b = blockIdx.y, h = blockIdx.x, group = nh / nkv, kvh = h / group;
+  const int p = (int)pos[0], len = p + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & 15, rsel = lane >> 4;
   const half_t* row = qkv + (size_t)b * (nh + 2 * nkv) * D;
   const half_t* kp = k_cache + ((size_t)b * nkv + kvh) * L * D;
   const half_t* vp = v_cache + ((size_t)b * nkv + kvh) * L * D;
-  // The kernel is a chain of round trips to L2/HBM, not a bandwidth problem (a head's cache at a few hundred positions
-  // is tens of KB): request everything that does not depend on the position before reading it, and everything that
-  // depends only on the position -- angle rows, first batch of K and V rows -- right after, in one go.
-  const half8_t qraw = *(const half8_t*)(row + (size_t)h * D + sub * 8);
-  const half8_t kraw = *(const half8_t*)(row + (size_t)(nh + kvh) * D + sub * 8);
-  const half8_t vn = *(const half8_t*)(row + (size_t)(nh + nkv + kvh) * D + sub * 8);
-  const int p = (int)pos[0], len = p + 1;
-  constexpr int UNR = 8;
-  half8_t kv0[UNR], vv[UNR];
-#pragma unroll
-  for (int u = 0; u < UNR; ++u) {
-    const int t = min(wave * 4 + 16 * u + rsel, max(p - 1, 0));  // cache rows 0..p-1; row p comes from registers
-    kv0[u] = *(const half8_t*)(kp + (size_t)t * D + sub * 8);
-  }
-  const half8_t cs = *(const half8_t*)(cos_t + (size_t)p * D + sub * 8), sn = *(const half8_t*)(sin_t + (size_t)p * D + sub * 8);
-#pragma unroll
-  for (int u = 0; u < UNR; ++u) {
-    const int t = min(wave * 4 + 16 * u + rsel, max(p - 1, 0));
-    vv[u] = *(const half8_t*)(vp + (size_t)t * D + sub * 8);
-  }
-  __builtin_amdgcn_sched_barrier(0);
 
   float qr[8], kr[8];
-  rope8(qraw, cs, sn, sub, qr);
-  rope8(kraw, cs, sn, sub, kr);
+  rope8(*(const half8_t*)(row + (size_t)h * D + sub * 8), cos_t + (size_t)p * D, sin_t + (size_t)p * D, sub, qr);
+  rope8(*(const half8_t*)(row + (size_t)(nh + kvh) * D + sub * 8), cos_t + (size_t)p * D, sin_t + (size_t)p * D, sub, kr);
+  const half8_t vn = *(const half8_t*)(row + (size_t)(nh + nkv + kvh) * D + sub * 8);
   if (threadIdx.x < 16) {
     if (h % group == 0) {  // append to the caches (position p is not read by anyone in this launch)
       half8_t kh;
@@ -222,17 +205,14 @@ __global__ __launch_bounds__(256) void decode_rope_attention_kernel(
     }
   }
 
+  constexpr int UNR = 8;
   float mx = -INFINITY;
   for (int t0 = wave * 4; t0 < len; t0 += 16 * UNR) {
     half8_t kv[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      if (t0 == wave * 4) {
-        kv[u] = kv0[u];
-      } else {
-        const int t = min(t0 + 16 * u + rsel, max(p - 1, 0));
-        kv[u] = *(const half8_t*)(kp + (size_t)t * D + sub * 8);
-      }
+      const int t = min(t0 + 16 * u + rsel, max(p - 1, 0));  // cache rows 0..p-1; row p comes from registers
+      kv[u] = *(const half8_t*)(kp + (size_t)t * D + sub * 8);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -266,12 +246,11 @@ __global__ __launch_bounds__(256) void decode_rope_attention_kernel(
 
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int t0 = wave * 4; t0 < len; t0 += 16 * UNR) {
-    if (t0 != wave * 4) {
+    half8_t vv[UNR];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int t = min(t0 + 16 * u + rsel, max(p - 1, 0));
-        vv[u] = *(const half8_t*)(vp + (size_t)t * D + sub * 8);
-      }
+    for (int u = 0; u < UNR; ++u) {
+      const int t = min(t0 + 16 * u + rsel, max(p - 1, 0));
+      vv[u] = *(const half8_t*)(vp + (size_t)t * D + sub * 8);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {

@@ -227,6 +227,38 @@ template <int NTW, int WAVES, bool TR>
 __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[NTW], floatx4* red, char* smem, int nb,
                                               int nblocks, int mb, int ks, int lane, int wave) {
   const int n16 = lane & 15, q = lane >> 4;
+  if constexpr (TR && NTW == 1) {
+    if (a.ksplit == 1) {
+      // Deferred-zero path, K not split across workgroups: every wave finishes its own 16 / WAVES tokens (lane = one
+      // output), so no wave does the whole reduction while the others wait for it at the next block's barrier.
+      // Partials in LDS row-major [wave][token][channel].
+      float* rf = (float*)(red + wave * 64) + 64 * q + n16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rf[16 * r] = acc[0][r];
+      acc[0] = floatx4{0.f, 0.f, 0.f, 0.f};
+      __syncthreads();
+      constexpr int TPW = WAVES >= 16 ? 1 : 16 / WAVES;  // tokens per wave
+      const int t = min(wave * TPW + q, 15), m = mb * 16 + t;
+      if (wave * TPW >= min(16, a.M - mb * 16)) return;  // whole waves: the shuffle below stays wave-wide
+      const float* src = (const float*)red + t * 16 + n16;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) v += src[w * 256];
+      const bool live = q < TPW && m < a.M;
+      if (a.silu_mul) {
+        const float up = __shfl_xor(v, 8);  // channels 0..7 gate, 8..15 up
+        if (live && n16 < 8) a.Y[(size_t)m * (a.N >> 1) + nb * 8 + n16] = silu_mul_f16((half_t)v, (half_t)up);
+        return;
+      }
+      if (live) {
+        const int n = nb * 16 + n16;
+        if (a.bias) v += (float)a.bias[n];
+        if (a.residual) v += (float)a.residual[(size_t)m * a.N + n];
+        a.Y[(size_t)m * a.N + n] = (half_t)v;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     if constexpr (TR) {
@@ -298,8 +330,12 @@ __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[
 // so the HBM stream does not stop for the load-latency / compute / reduce phases of each block, and x is copied to
 // LDS once per workgroup instead of once per block.  Consecutive blocks alternate between two reduction buffers,
 // which makes one barrier per block enough.
+// Only the XLDS variants can be launched persistent.  The fragments-from-L2 variants keep the plain one-block loop: in
+// the cross-block form hipcc needs 141 instead of 121 VGPRs for NTW = 1 (one workgroup per CU instead of two: -9 % on
+// the Llama-2-70B shapes at M = 16 [r01]).
 template <int NTW, int WAVES, int GM, bool XLDS, bool DZ>
 __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
+  constexpr bool PERSIST = XLDS;
   static_assert(WAVES >= NTW, "the final reduction assigns one channel tile per wave");
   static_assert(XLDS || !DZ, "the deferred-zero path tabulates x while copying it to LDS");
   constexpr int U = XLDS ? (NTW == 1 ? 4 : 2) : (NTW <= 2 ? 2 : 1);
@@ -366,6 +402,24 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   QA_SKINNY_ADVANCE(nb_nxt, kt_nxt)
 
   SkinnyChunk<NTW, GM, U, XLDS> cA, cB;
+  if constexpr (!PERSIST) {
+    // one block per workgroup, x fragments straight from L2
+    const u32x4* wp = a.QW + (size_t)blockIdx.x * NTW * wstride + lane;
+    const int n = blockIdx.x * (16 * NTW) + n16;
+    if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt_begin, kt_end - 1, wp, wstride, xp, a, n);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
+      if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS>(cB, kt + U, kt_end - 1, wp, wstride, xp, a, n);
+      __builtin_amdgcn_sched_barrier(0);
+      skinny_compute<NTW, GM, U, XLDS>(cA, kt, kt_end, nullptr, ls, acc);
+      if (kt + U >= kt_end) break;
+      if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt + 2 * U, kt_end - 1, wp, wstride, xp, a, n);
+      __builtin_amdgcn_sched_barrier(0);
+      skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, ls, acc);
+    }
+    skinny_finish<NTW, WAVES, DZ>(a, acc, red, smem, blockIdx.x, nblocks, mb, ks, lane, wave);
+    return;
+  }
   QA_SKINNY_LOAD(cA);  // HBM requests first
   QA_SKINNY_ADVANCE(nb_nxt, kt_nxt);
   __builtin_amdgcn_sched_barrier(0);
@@ -1163,7 +1217,10 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
         c = 1;
         rounds = (nblocks + 255) / 256;
       }
-      if (M <= 2 || ((kernel >> 26) & 1) || (rounds >= 2 && p.ksplit == 1)) {  // bit 26: tests force the path
+      // ... and only when the rounds keep the slots busy (384 blocks on 256 slots = 2 rounds at 75 %: Mistral's qkv
+      // at M = 16 lost 2 % to the exact path's 384 one-block workgroups [r01])
+      const bool balanced = (double)nblocks >= 0.8 * rounds * 256 * c;
+      if (M <= 2 || ((kernel >> 26) & 1) || (rounds >= 2 && balanced && p.ksplit == 1)) {  // bit 26: tests force the path
         p.dz = p.xlds = true;
         if (!flip && p.ksplit == 1 && rounds >= 2) p.grid_x = (nblocks + rounds - 1) / rounds;
       }
@@ -1173,7 +1230,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
       // launches measured within +-5 % of one block per workgroup [r01] and are off unless asked for
       p.xlds = !no_xlds && M <= 16 && (size_t)std::min(M, 16) * (p.kt_per_split * 256 + 16) <= (size_t)64 * 1024;
       const int slots = std::max(1, 256 * (cu_req ? cu_req : 2) / mblocks);
-      if ((flip || cu_req) && p.ksplit == 1 && nblocks > slots) {
+      if (p.xlds && (flip || cu_req) && p.ksplit == 1 && nblocks > slots) {  // the fragments-from-L2 variants cannot
         const int rounds = (nblocks + slots - 1) / slots;
         p.grid_x = (nblocks + rounds - 1) / rounds;
       }
