@@ -276,6 +276,131 @@ __global__ __launch_bounds__(256) void decode_rope_attention_kernel(
   }
 }
 
+// Single-pass form of the kernel above (online softmax): K and V rows of a batch are requested together and consumed in
+// one sweep, every (wave, 16-lane row slot) keeps its own running (max, sum, 8 output dims per lane) and the 16 slots of
+// the workgroup are merged once at the end -- one barrier in the whole kernel instead of five, and no separate "all K,
+// then all V" phases (which, with every workgroup of a large batch starting at once, left HBM idle about half the
+// time: 3.9 TB/s at bs=64 [r01]).
+__global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
+    const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t, const half_t* __restrict__ sin_t,
+    const long* __restrict__ pos, half_t* __restrict__ k_cache, half_t* __restrict__ v_cache, half_t* __restrict__ out,
+    int nh, int nkv, int L, float scale) {
+  constexpr int D = 128;
+  __shared__ float part[4][D + 2];  // per wave: 128 output dims, running max, running sum
+  const int b = blockIdx.y, h = blockIdx.x, group = nh / nkv, kvh = h / group;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 15, rsel = lane >> 4;
+  const half_t* row = qkv + (size_t)b * (nh + 2 * nkv) * D;
+  const half_t* kp = k_cache + ((size_t)b * nkv + kvh) * L * D + sub * 8;
+  const half_t* vp = v_cache + ((size_t)b * nkv + kvh) * L * D + sub * 8;
+  const half8_t qraw = *(const half8_t*)(row + (size_t)h * D + sub * 8);
+  const half8_t kraw = *(const half8_t*)(row + (size_t)(nh + kvh) * D + sub * 8);
+  const half8_t vn = *(const half8_t*)(row + (size_t)(nh + nkv + kvh) * D + sub * 8);
+  const int p = (int)pos[0];  // cache rows 0..p-1 are attended from memory, row p (this token) from registers
+
+  constexpr int UNR = 8;
+  const float LOG2E = 1.44269504088896f;
+  float m = -INFINITY, l = 0.f;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float qr[8], kr[8];
+  bool roped = false;
+  for (int tb = wave * 4; tb < p || !roped; tb += 16 * UNR) {  // wave-uniform trip count
+    const int t0 = tb + rsel;
+    half8_t kv[UNR], vv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) kv[u] = *(const half8_t*)(kp + (size_t)min(t0 + 16 * u, max(p - 1, 0)) * D);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) vv[u] = *(const half8_t*)(vp + (size_t)min(t0 + 16 * u, max(p - 1, 0)) * D);
+    if (!roped) {  // first trip: rotate q and the new k while the cache rows are in flight
+      const half8_t cs = *(const half8_t*)(cos_t + (size_t)p * D + sub * 8), sn = *(const half8_t*)(sin_t + (size_t)p * D + sub * 8);
+      const float sign = sub < 8 ? -1.f : 1.f;  // rotate_half: dims 0..63 pair with -x[i+64], dims 64..127 with +x[i-64]
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float qj = (float)qraw[j], kj = (float)kraw[j];
+        const float qp = __shfl_xor(qj, 8), kpn = __shfl_xor(kj, 8);  // lane sub^8 of the same row slot holds the paired dims
+        qr[j] = (float)(half_t)((float)(half_t)(qj * (float)cs[j]) + (float)(half_t)(sign * qp * (float)sn[j])) * (scale * LOG2E);
+        kr[j] = (float)(half_t)((float)(half_t)(kj * (float)cs[j]) + (float)(half_t)(sign * kpn * (float)sn[j]));
+      }
+      if (threadIdx.x < 16 && h % group == 0) {  // append to the caches (position p is not read by anyone in this launch)
+        half8_t kh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kh[j] = (half_t)kr[j];
+        *(half8_t*)(k_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = kh;
+        *(half8_t*)(v_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = vn;
+      }
+      roped = true;
+    }
+    // scores in the log2 domain (q carries scale * log2 e): 8 rows of this slot
+    float d[UNR], mb = m;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float x = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x += qr[j] * (float)kv[u][j];
+      x = lanes_sum<16>(x);
+      d[u] = t0 + 16 * u < p ? x : -INFINITY;
+      mb = fmaxf(mb, d[u]);
+    }
+    const float mref = mb == -INFINITY ? 0.f : mb;
+    const float corr = exp2f(m - mref);
+    l *= corr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= corr;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const float e = exp2f(d[u] - mref);
+      l += e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += e * (float)vv[u][j];
+    }
+    m = mb;
+  }
+  if (wave == 0 && rsel == 0) {  // this token (row p), from registers
+    float x = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x += qr[j] * kr[j];
+    x = lanes_sum<16>(x);
+    const float mb = fmaxf(m, x), corr = exp2f(m - mb), e = exp2f(x - mb);
+    l = l * corr + e;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = acc[j] * corr + e * (float)vn[j];
+    m = mb;
+  }
+  // merge the 4 row slots of the wave, then the 4 waves through LDS
+  float mw = fmaxf(m, __shfl_xor(m, 16));
+  mw = fmaxf(mw, __shfl_xor(mw, 32));
+  const float sc_ = exp2f(m - (mw == -INFINITY ? 0.f : mw));
+  l *= sc_;
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    acc[j] *= sc_;
+    acc[j] += __shfl_xor(acc[j], 16);
+    acc[j] += __shfl_xor(acc[j], 32);
+  }
+  if (rsel == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[wave][sub * 8 + j] = acc[j];
+    if (sub == 0) {
+      part[wave][D] = mw;
+      part[wave][D + 1] = l;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    const float M = fmaxf(fmaxf(part[0][D], part[1][D]), fmaxf(part[2][D], part[3][D]));  // finite: wave 0 holds row p
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = exp2f(part[w][D] - M);
+      num += part[w][threadIdx.x] * f;
+      den += part[w][D + 1] * f;
+    }
+    out[((size_t)b * nh + h) * D + threadIdx.x] = (half_t)(num / den);
+  }
+}
+
 // y[m, 8t + i] = silu(gu[m, 16t + i]) * gu[m, 16t + 8 + i], i < 8: gate and up channels interleaved in blocks of 8, the
 // order the fused gate_up GEMM produces (and consumes directly when its silu_mul epilogue is on); I % 8 == 0
 __global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict__ gu, half_t* __restrict__ y, int I, size_t n8) {
@@ -330,6 +455,14 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
   if (batch <= 0 || head_dim != 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_UNSUPPORTED;
   const size_t lds = (((size_t)cache_len + 3) & ~(size_t)3) * 4 + 4 * 128 * 4 + 128 * 4;
   if (lds > 64 * 1024) return QUICK_ERR_UNSUPPORTED;
+  // single-pass kernel while the launch is latency-bound (+8 % decode tok/s at bs=1, +5 % at bs=8 [r01]); from ~1000
+  // workgroups on the two-pass kernel is 0.5-1 % ahead
+  if (batch * n_heads < 1024) {
+    hipLaunchKernelGGL(decode_rope_attention_flash_kernel, dim3(n_heads, batch), dim3(256), 0, (hipStream_t)hip_stream,
+                       (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, (const long*)pos,
+                       (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads, cache_len, scale);
+    return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(decode_rope_attention_kernel, dim3(n_heads, batch), dim3(256), (unsigned)lds, (hipStream_t)hip_stream,
                      (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, (const long*)pos,
                      (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads, cache_len, scale);

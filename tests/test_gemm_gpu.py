@@ -414,6 +414,35 @@ def test_rmsnorm_prologue_matches_two_launches(qa, device, M, K, N, G):
     assert rel_err(y1.cpu().numpy(), want) <= TOL
 
 
+@pytest.mark.parametrize("B,nh,nkv", [(2, 8, 8), (3, 8, 2), (32, 32, 8)], ids=["mha-single-pass", "gqa-single-pass", "gqa-two-pass"])
+@pytest.mark.parametrize("p", [0, 1, 5, 127, 128, 300])
+def test_rope_attention_kernels_against_torch(qa, device, B, nh, nkv, p):
+    """RoPE + KV append + single-query attention in one launch: the single-pass (online softmax) kernel used for small
+    launches and the two-pass kernel used from ~1000 workgroups, at context lengths around the 128-row batch size."""
+    import torch.nn.functional as F
+    from quick_amd import kernels as K_
+    from quick_amd.decoder import _rope
+    torch.manual_seed(p + B)
+    D, L = 128, 320
+    ang = torch.outer(torch.arange(L, device=device).float(), 1.0 / (10000 ** (torch.arange(0, D, 2, device=device).float() / D)))
+    cos, sin = torch.cat((ang.cos(), ang.cos()), -1).half(), torch.cat((ang.sin(), ang.sin()), -1).half()
+    qkv = torch.randn(B, (nh + 2 * nkv) * D, device=device).half()
+    kc, vc = torch.randn(B, nkv, L, D, device=device).half(), torch.randn(B, nkv, L, D, device=device).half()
+    pos = torch.full((1,), p, dtype=torch.int64, device=device)
+    q, k, v = qkv.split((nh * D, nkv * D, nkv * D), dim=-1)
+    qr = _rope(q.view(B, 1, nh, D).transpose(1, 2), cos[p:p + 1], sin[p:p + 1])
+    kr = _rope(k.view(B, 1, nkv, D).transpose(1, 2), cos[p:p + 1], sin[p:p + 1])
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    kc_ref[:, :, p] = kr[:, :, 0]
+    vc_ref[:, :, p] = v.view(B, nkv, D)
+    ref = F.scaled_dot_product_attention(qr.float(), kc_ref[:, :, :p + 1].float(), vc_ref[:, :, :p + 1].float(), enable_gqa=True)
+    ref = ref.transpose(1, 2).reshape(B, nh * D)
+    o = K_.rope_attention(qkv, cos, sin, pos, kc, vc, torch.empty(B, nh * D, dtype=torch.float16, device=device), nh, nkv, D)
+    torch.testing.assert_close(kc, kc_ref, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(vc, vc_ref, rtol=0, atol=0)
+    assert (o.float() - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-3
+
+
 def test_fused_decode_step_matches_torch_glue(qa, device):
     """HIP glue kernels (RMSNorm, RoPE + KV append, single-query attention, SiLU*mul, residual epilogue) against the
     torch-op decode step on the same synthetic model: same hidden state up to fp16 rounding order."""
