@@ -9,5 +9,6 @@ from .kernels import (dequantize_mi355x, gemm_forward, gemm_forward_cuda_quick, 
                       repack_mi355x_to_cuda)
 from .linear import WQLinear_QUICK  # noqa: F401
 from .fused_utils import QUICK_cat, fuse_qkv_quick  # noqa: F401
+from .quantize import pseudo_quantize_tensor, quantize_linear, quantize_module_linears  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1172,6 +1172,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     p.mt = mt_req ? (mt_req == 2 ? 2 : (mt_req == 8 ? 8 : 4)) : (M <= 32 ? 2 : 4);
     p.waves = waves_req == 16 ? 16 : 8;
     const int wk = p.wn2 ? 4 : p.waves / 4;
+    // 32-token tiles once 64-token tiles would need a 4-way K split to cover the CUs (twice the tiles, half the slices
+    // to reduce): M = 65..128 at N = 4096, 15.5 us instead of 16.5 us at M = 128 [r01]
+    if (!mt_req && p.mt == 4 && (N / 128) * ((M + 63) / 64) * 4 <= 256 && (KT + wk - 1) / wk >= 8) p.mt = 2;
     p.ntiles = (N / 128) * ((M + p.mt * 16 - 1) / (p.mt * 16));
     p.slab_floats = (size_t)4 * 2 * p.mt * 256;
     // one workgroup per CU: split K until the 256 CUs are covered, keeping >= 2 stages per slice

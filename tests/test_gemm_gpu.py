@@ -297,6 +297,21 @@ def test_reference_operator_signature_and_errors(qa, device):
     assert tuple(qa.gemm_forward(xd[:0], *packed).shape) == (0, N)            # empty batch
 
 
+def test_quantize_linear_end_to_end(qa, device):
+    """nn.Linear -> round-to-nearest W4 -> WQLinear_QUICK -> HIP GEMM, against the fake-quantised weight in fp32
+    (the `_apply_quant` hook, quick/awq/quantize/quantizer.py:148-174)."""
+    from quick_amd import pseudo_quantize_tensor, quantize_linear
+    torch.manual_seed(11)
+    lin = torch.nn.Linear(1024, 512, bias=True)
+    x = torch.randn(7, 1024).half()
+    wq = pseudo_quantize_tensor(lin.weight.data.half(), 4, 128)
+    want = x.float() @ wq.float().t() + lin.bias.data.half().float()
+    for dev_first in (False, True):       # quantise on the CPU then move, or quantise on the GPU
+        layer = quantize_linear(lin.to(device) if dev_first else lin.cpu(), 4, 128).to(device)
+        y = layer(x.to(device))
+        assert rel_err(y.cpu().numpy(), want.numpy()) <= TOL
+
+
 def test_runs_on_current_stream_and_is_graph_capturable(qa, device):
     M, K, N, G = 4, 512, 256, 128
     x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=8)

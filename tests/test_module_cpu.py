@@ -143,3 +143,41 @@ def test_quick_kernels_shim_exports_reference_symbol():
     with pytest.raises(RuntimeError, match="Half|float16"):
         quick_kernels.gemm_forward_cuda_quick(x, torch.zeros(32, 64, dtype=torch.int32), torch.zeros(1, 256, dtype=torch.float16),
                                               torch.zeros(1, 32, dtype=torch.int32), 8)
+
+
+# ------------------------------------------------------------------------------------------------
+# quantizer hook-up (quick/awq/quantize/quantizer.py:46-72, 141-174)
+# ------------------------------------------------------------------------------------------------
+def test_pseudo_quantize_and_quantize_linear_reproduce_the_reference_fixture():
+    """tests/golden/quant_k256n256g128.npz holds what the reference's pseudo_quantize_tensor + from_linear made of a
+    seeded weight (gen_golden.py); the same seed through quick_amd.quantize must give the same bits."""
+    import torch
+    from conftest import golden_files, load_golden
+    from quick_amd import pseudo_quantize_tensor, quantize_linear
+    g = load_golden(golden_files("quant_")[0])
+    K, N, G = int(g["K"]), int(g["N"]), int(g["G"])
+    w = (torch.randn(N, K, generator=torch.Generator().manual_seed(400)) * 0.03).half()
+    wq, s, z = pseudo_quantize_tensor(w.clone(), 4, G, get_scale_zp=True)
+    assert np.array_equal(wq.numpy().view(np.uint16), g["weight"].view(np.uint16))
+    assert np.array_equal(s.numpy().view(np.uint16), g["scales_nk"].view(np.uint16))
+    assert np.array_equal(z.numpy().view(np.uint16), g["zeros_nk"].view(np.uint16))
+    lin = torch.nn.Linear(K, N, bias=False)
+    lin.weight.data = w.float()
+    sd = quantize_linear(lin, 4, G).state_dict()          # reference packed order
+    assert np.array_equal(sd["qweight"].numpy(), g["ref_qweight"])
+    assert np.array_equal(sd["qzeros"].numpy(), g["ref_qzeros"])
+    assert np.array_equal(sd["scales"].numpy().view(np.uint16), g["ref_qscales"].view(np.uint16))
+
+
+def test_quantize_module_linears_replaces_and_skips():
+    import torch
+    from quick_amd import WQLinear_QUICK, quantize_module_linears
+    torch.manual_seed(0)
+    m = torch.nn.ModuleDict({"attn": torch.nn.ModuleDict({"q_proj": torch.nn.Linear(256, 128), "o_proj": torch.nn.Linear(128, 256, bias=False)}),
+                             "lm_head": torch.nn.Linear(256, 128, bias=False)})
+    done = quantize_module_linears(m, 4, 128, modules_to_not_convert=("lm_head",))
+    assert sorted(done) == ["attn.o_proj", "attn.q_proj"]
+    assert isinstance(m["attn"]["q_proj"], WQLinear_QUICK) and m["attn"]["q_proj"].bias is not None
+    assert isinstance(m["lm_head"], torch.nn.Linear)
+    with pytest.raises(ValueError):
+        quantize_module_linears(torch.nn.ModuleDict({"x": torch.nn.Linear(192, 128)}), 4, 128)
