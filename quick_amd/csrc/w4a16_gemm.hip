@@ -102,23 +102,50 @@ struct SkinnyChunk {
   half8_t xf[XLDS ? 1 : U][XLDS ? 1 : 4];
 };
 
+// Weights and group constants come in through buffer loads: address = descriptor base + per-lane byte offset (a launch
+// constant VGPR) + a wave-uniform byte offset in an SGPR -- no 64-bit address arithmetic per load (it was ~28 scalar and
+// ~10 vector instructions per 1 KiB weight tile).  Offsets are 32-bit: tensors up to 4 GiB.
+struct SkinnyBufs {
+  __amdgpu_buffer_rsrc_t w, s, z;
+  unsigned w_voff, s_voff, z_voff;  // lane * 16;  2 * (n16 & ~1);  4 * (n16 >> 3)
+  unsigned wstride_bytes;           // between consecutive channel tiles
+  unsigned s_row, z_row;            // bytes per group row of scales / zeros
+};
+__device__ __forceinline__ SkinnyBufs skinny_bufs(const GemmArgs& a, int lane) {
+  SkinnyBufs b;
+  const unsigned groups = (unsigned)(a.K / a.G);
+  b.w = __builtin_amdgcn_make_buffer_rsrc((void*)a.QW, 0, (unsigned)((size_t)a.K * a.N / 2), 0x00020000);
+  b.s = __builtin_amdgcn_make_buffer_rsrc((void*)a.S, 0, groups * (unsigned)a.N * 4u, 0x00020000);
+  b.z = __builtin_amdgcn_make_buffer_rsrc((void*)a.QZ, 0, groups * (unsigned)a.N, 0x00020000);
+  b.w_voff = (unsigned)lane * 16u;
+  b.s_voff = 2u * (unsigned)(lane & 14);
+  b.z_voff = 4u * (unsigned)((lane & 15) >> 3);
+  b.wstride_bytes = (unsigned)(a.K >> 7) * 1024u;
+  b.s_row = (unsigned)a.N * 4u;
+  b.z_row = (unsigned)a.N;
+  return b;
+}
+
+// chunk of U k-tiles starting at kt of channel block `cb` (in units of 16 channels: block index * NTW)
 template <int NTW, int GM, int U, bool XLDS>
-__device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS>& c, int kt, int kt_last,
-                                            const u32x4* __restrict__ wp, size_t wstride, const half_t* xp,
-                                            const GemmArgs& a, int n) {
+__device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS>& c, int kt, int kt_last, const SkinnyBufs& b,
+                                            int cb, const half_t* xp, const GemmArgs& a) {
   constexpr int NG = groups_per_tile<GM>();
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) c.w[u][j] = wp[j * wstride + (size_t)min(kt + u, kt_last) * 64];  // past the end: replay
+    for (int j = 0; j < NTW; ++j)  // past the end: replay
+      c.w[u][j] = __builtin_amdgcn_raw_buffer_load_b128(b.w, b.w_voff, (unsigned)(cb + j) * b.wstride_bytes + (unsigned)min(kt + u, kt_last) * 1024u, 0);
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
-      for (int i = 0; i < NG; ++i)
-        c.raw[u][j][i] = load_group_raw(a.S, a.QZ, group_index<GM>(min(kt + u, kt_last), i * (4 / NG), a.tpg, a.G),
-                                        n + 16 * j, a.N);
+      for (int i = 0; i < NG; ++i) {
+        const unsigned g = (unsigned)group_index<GM>(min(kt + u, kt_last), i * (4 / NG), a.tpg, a.G);
+        c.raw[u][j][i].s2 = __builtin_amdgcn_raw_buffer_load_b32(b.s, b.s_voff, g * b.s_row + (unsigned)(cb + j) * 32u, 0);
+        c.raw[u][j][i].zq = __builtin_amdgcn_raw_buffer_load_b32(b.z, b.z_voff, g * b.z_row + (unsigned)(cb + j) * 8u, 0);
+      }
   if constexpr (!XLDS) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -356,7 +383,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   const int kt_last = max(kt_end - 1, kt_begin);  // clamp for replayed loads (a wave may own no k-tile at all)
   const LaneSel ls = lane_sel(n16);               // channel n = 16 * tile + n16: n % 8 and n % 2 are those of n16
 
-  const size_t wstride = (size_t)KT * 64;  // u32x4 elements between consecutive channel tiles
+  const SkinnyBufs bufs = skinny_bufs(a, lane);
   const int row = min(mb * 16 + n16, a.M - 1);  // rows >= M replay row M-1; never stored
   const half_t* xp = a.X + (size_t)row * a.K + q * 8;
 
@@ -370,9 +397,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   int parity = 0;
   // The load of the next chunk is issued in a block that always issues it: a guarded load would make hipcc's
   // s_waitcnt pass assume the smaller in-flight count and wait for most of the prefetch before the compute.
-#define QA_SKINNY_LOAD(c)                                                                                          \
-  skinny_load<NTW, GM, U, XLDS>(c, kt_nxt, kt_last, a.QW + (size_t)nb_nxt * NTW * wstride + lane, wstride, xp, a,    \
-                                nb_nxt * (16 * NTW) + n16)
+#define QA_SKINNY_LOAD(c) skinny_load<NTW, GM, U, XLDS>(c, kt_nxt, kt_last, bufs, nb_nxt * NTW, xp, a)
 #define QA_SKINNY_ADVANCE(nb, kt)                                                                                  \
   do {                                                                                                             \
     kt += U;                                                                                                       \
@@ -404,16 +429,15 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   SkinnyChunk<NTW, GM, U, XLDS> cA, cB;
   if constexpr (!PERSIST) {
     // one block per workgroup, x fragments straight from L2
-    const u32x4* wp = a.QW + (size_t)blockIdx.x * NTW * wstride + lane;
-    const int n = blockIdx.x * (16 * NTW) + n16;
-    if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt_begin, kt_end - 1, wp, wstride, xp, a, n);
+    const int cb = blockIdx.x * NTW;
+    if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt_begin, kt_end - 1, bufs, cb, xp, a);
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
-      if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS>(cB, kt + U, kt_end - 1, wp, wstride, xp, a, n);
+      if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS>(cB, kt + U, kt_end - 1, bufs, cb, xp, a);
       __builtin_amdgcn_sched_barrier(0);
       skinny_compute<NTW, GM, U, XLDS>(cA, kt, kt_end, nullptr, ls, acc);
       if (kt + U >= kt_end) break;
-      if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt + 2 * U, kt_end - 1, wp, wstride, xp, a, n);
+      if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt + 2 * U, kt_end - 1, bufs, cb, xp, a);
       __builtin_amdgcn_sched_barrier(0);
       skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, ls, acc);
     }
