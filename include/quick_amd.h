@@ -68,9 +68,10 @@ const char* quick_amd_last_error(void);
  *
  * workspace: device scratch of at least quick_w4a16_workspace_bytes(...) bytes (may be NULL when
  * that function returns 0).  It must stay valid until the work enqueued on `hip_stream` completes,
- * must be ZERO-FILLED before its first use, and is handed back zero-filled where it matters (the
- * arrival counters of the in-kernel split-K reduction reset themselves), so one zeroed buffer can be
- * reused by every later call on the same stream.  Do not share it between streams that run
+ * must be ZERO-FILLED before its first use, and is handed back zero-filled where it matters (its first
+ * 64 KiB are the arrival counters of the in-kernel split-K reduction, which reset themselves; the fp32
+ * partial tiles behind them are overwritten before they are read), so one zeroed buffer can be reused by
+ * every later call on the same stream, whatever its shape.  Do not share it between streams that run
  * concurrently.
  */
 int quick_w4a16_gemm_f16(const void* x, const void* qweight, const void* scales, const void* qzeros,

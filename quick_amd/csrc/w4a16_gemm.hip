@@ -1182,7 +1182,17 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   if (p.kernel == QUICK_KERNEL_SKINNY) {
     const int mblocks = (M + 15) / 16;
     // channel tiles per workgroup ~ token blocks (weights are re-read per token block, x per channel block)
-    p.mt = mt_req ? mt_req : (mblocks <= 1 ? 1 : (mblocks <= 2 ? 2 : 4));
+    int mt_auto = mblocks <= 1 ? 1 : (mblocks <= 2 ? 2 : 4);
+    // M = 9..16 on a large layer: the fragments-from-L2 path reads x once per 16-channel tile -- 4x the weight bytes at
+    // M = 16 -- so share every x fragment among 4 channel tiles (8192 x 57344 at M = 16: 119 -> 78 us, 28672 x 8192:
+    // 65 -> 36 us [r01]).  Small layers keep NTW = 1 (more workgroups); from 1024 channel blocks the deferred-zero path
+    // (x in LDS) is as fast or faster and stays.
+    if (!mt_req && M > 8 && M <= 32 && (long)K * N >= 40L * 1000 * 1000) {  // (M = 17..32: 11008 x 4096 16.6 -> 13.5 us)
+      const bool dz_ok = mblocks == 1 && !no_xlds && !((kernel >> 25) & 1) && N / 16 >= 1024 &&
+                         skinny_lds_bytes(M, G, 1, 8, KT, true, true, true) <= kLdsPerCu;
+      if (!dz_ok) mt_auto = 4;
+    }
+    p.mt = mt_req ? mt_req : mt_auto;
     if (p.mt != 1 && p.mt != 2) p.mt = 4;
     while (p.mt > 1 && (N / 16) % p.mt != 0) p.mt /= 2;
     p.waves = (waves_req == 4 || waves_req == 8 || waves_req == 16) ? waves_req : 8;
@@ -1266,8 +1276,11 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   return p;
 }
 
-// workspace: [ntiles arrival counters, padded to 256 B][ntiles * ksplit fp32 slabs]
-static size_t counters_bytes(const Plan& p) { return (((size_t)p.ntiles * 4 + 255) / 256) * 256; }
+// workspace: [64 KiB of arrival counters, one per output tile][ntiles * ksplit fp32 slabs]
+// The counter region has a FIXED size: the slabs are not handed back zeroed, so a region that grew with the tile count
+// would lay the counters of one launch over the stale partial sums of an earlier, smaller one.
+static constexpr int kMaxSplitTiles = 16384;
+static size_t counters_bytes(const Plan&) { return (size_t)kMaxSplitTiles * 4; }
 static size_t workspace_need(const Plan& p) {
   return p.ksplit > 1 ? counters_bytes(p) + (size_t)p.ntiles * p.ksplit * p.slab_floats * sizeof(float) : 0;
 }
@@ -1405,6 +1418,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
              (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr, (const half_t*)f.ln_w, f.ln_eps};
   if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
   if (p.ksplit > 1) {
+    if (p.ntiles > kMaxSplitTiles) return fail(QUICK_ERR_UNSUPPORTED, "K split over %d output tiles (limit %d)", p.ntiles, kMaxSplitTiles);
     const size_t need = workspace_need(p);
     if (!workspace || workspace_bytes < need)
       return fail(QUICK_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);

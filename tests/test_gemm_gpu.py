@@ -259,7 +259,10 @@ def test_split_k_reduction_is_stable_across_many_launches(qa, device):
     """In-kernel split-K (last arriver reduces): the arrival counters must come back to zero after every launch and the
     result must not depend on which slice arrives last -- hammer it, alternating shapes that share the workspace."""
     cases = []
-    for M, K, N, G in ((64, 4096, 1024, 128), (40, 2048, 512, 128), (8, 4096, 256, 128), (130, 2048, 256, 64)):
+    # (4, 4096, 2048): 128 tiles -- more arrival counters than the other cases; a counter region sized by the tile count
+    # once put them on top of an earlier launch's partial sums
+    for M, K, N, G in ((64, 4096, 1024, 128), (40, 2048, 512, 128), (8, 4096, 256, 128), (130, 2048, 256, 64), (4, 4096, 2048, 128),
+                       (16, 8192, 4096, 128)):
         x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + N)
         cases.append((_dev(x, device), _pack_dev(iw, s, z, device), oracle.w4a16_forward(x, iw, s, z, G)))
     first = [None] * len(cases)

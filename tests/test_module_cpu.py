@@ -133,7 +133,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert rc == 4
     assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 4096, 128, 8) == 0
     # N = 1024 at M = 1: 64 channel tiles x 4 K slices, one 1 KiB fp32 slab each, behind 256 B of arrival counters
-    assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 1024, 128, 8) == 256 + 64 * 4 * 256 * 4
+    assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 1024, 128, 8) == 65536 + 64 * 4 * 256 * 4
 
 
 def test_quick_kernels_shim_exports_reference_symbol():
