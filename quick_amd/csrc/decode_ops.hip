@@ -401,6 +401,162 @@ __global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
   }
 }
 
+// Grouped-query form of the single-pass kernel: one workgroup per (sequence, KV head) serves all GROUP query heads of
+// that KV head from ONE sweep over its K and V rows.  With one workgroup per query head every head of a group re-reads
+// the same cache rows through L2 and the launch is bound by that traffic, not by HBM: Mistral-7B shapes (32 query / 8 KV
+// heads) at bs=64, 190 positions took 33 us per layer for 50 MB of cache [r01, tools/time_attention.py].
+template <int GROUP, int UNR>
+__global__ __launch_bounds__(256, 2) void decode_rope_attention_gqa_kernel(
+    const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t, const half_t* __restrict__ sin_t,
+    const long* __restrict__ pos, half_t* __restrict__ k_cache, half_t* __restrict__ v_cache, half_t* __restrict__ out,
+    int nh, int nkv, int L, float scale) {
+  constexpr int D = 128;
+  __shared__ float part[4][GROUP][D + 2];  // per wave and query head: 128 output dims, running max, running sum
+  const int b = blockIdx.y, kvh = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 15, rsel = lane >> 4;
+  const half_t* row = qkv + (size_t)b * (nh + 2 * nkv) * D;
+  const half_t* kp = k_cache + ((size_t)b * nkv + kvh) * L * D + sub * 8;
+  const half_t* vp = v_cache + ((size_t)b * nkv + kvh) * L * D + sub * 8;
+  half8_t qraw[GROUP];
+#pragma unroll
+  for (int g = 0; g < GROUP; ++g) qraw[g] = *(const half8_t*)(row + (size_t)(kvh * GROUP + g) * D + sub * 8);
+  const half8_t kraw = *(const half8_t*)(row + (size_t)(nh + kvh) * D + sub * 8);
+  const half8_t vn = *(const half8_t*)(row + (size_t)(nh + nkv + kvh) * D + sub * 8);
+  const int p = (int)pos[0];  // cache rows 0..p-1 are attended from memory, row p (this token) from registers
+
+  const float LOG2E = 1.44269504088896f;
+  float m[GROUP], l[GROUP], acc[GROUP][8], qr[GROUP][8], kr[8];
+#pragma unroll
+  for (int g = 0; g < GROUP; ++g) {
+    m[g] = -INFINITY;
+    l[g] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+  }
+  bool roped = false;
+  for (int tb = wave * 4; tb < p || !roped; tb += 16 * UNR) {  // wave-uniform trip count
+    const int t0 = tb + rsel;
+    half8_t kv[UNR], vv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) kv[u] = *(const half8_t*)(kp + (size_t)min(t0 + 16 * u, max(p - 1, 0)) * D);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) vv[u] = *(const half8_t*)(vp + (size_t)min(t0 + 16 * u, max(p - 1, 0)) * D);
+    if (!roped) {  // first trip: rotate the q heads and the new k while the cache rows are in flight
+      const half8_t cs = *(const half8_t*)(cos_t + (size_t)p * D + sub * 8), sn = *(const half8_t*)(sin_t + (size_t)p * D + sub * 8);
+      const float sign = sub < 8 ? -1.f : 1.f;  // rotate_half: dims 0..63 pair with -x[i+64], dims 64..127 with +x[i-64]
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float kj = (float)kraw[j], kpn = __shfl_xor(kj, 8);  // lane sub^8 of the same row slot holds the paired dims
+        kr[j] = (float)(half_t)((float)(half_t)(kj * (float)cs[j]) + (float)(half_t)(sign * kpn * (float)sn[j]));
+#pragma unroll
+        for (int g = 0; g < GROUP; ++g) {
+          const float qj = (float)qraw[g][j], qp = __shfl_xor(qj, 8);
+          qr[g][j] = (float)(half_t)((float)(half_t)(qj * (float)cs[j]) + (float)(half_t)(sign * qp * (float)sn[j])) * (scale * LOG2E);
+        }
+      }
+      if (threadIdx.x < 16) {  // append to the caches (position p is not read by anyone in this launch)
+        half8_t kh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kh[j] = (half_t)kr[j];
+        *(half8_t*)(k_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = kh;
+        *(half8_t*)(v_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = vn;
+      }
+      roped = true;
+    }
+    // scores in the log2 domain (q carries scale * log2 e): UNR rows of this slot x GROUP heads; every cache row is
+    // converted to fp32 once for all heads
+    float d[GROUP][UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float kf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kf[j] = (float)kv[u][j];
+      const bool valid = t0 + 16 * u < p;
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g) {
+        float x = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x += qr[g][j] * kf[j];
+        x = lanes_sum<16>(x);
+        d[g][u] = valid ? x : -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < GROUP; ++g) {
+      float mb = m[g];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) mb = fmaxf(mb, d[g][u]);
+      const float mref = mb == -INFINITY ? 0.f : mb;
+      const float corr = exp2f(m[g] - mref);
+      l[g] *= corr;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[g][j] *= corr;
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        d[g][u] = exp2f(d[g][u] - mref);
+        l[g] += d[g][u];
+      }
+      m[g] = mb;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float vf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vf[j] = (float)vv[u][j];
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] += d[g][u] * vf[j];
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < GROUP; ++g) {
+    if (wave == 0 && rsel == 0) {  // this token (row p), from registers
+      float x = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x += qr[g][j] * kr[j];
+      x = lanes_sum<16>(x);
+      const float mb = fmaxf(m[g], x), corr = exp2f(m[g] - mb), e = exp2f(x - mb);
+      l[g] = l[g] * corr + e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[g][j] = acc[g][j] * corr + e * (float)vn[j];
+      m[g] = mb;
+    }
+    // merge the 4 row slots of the wave, then the 4 waves through LDS
+    float mw = fmaxf(m[g], __shfl_xor(m[g], 16));
+    mw = fmaxf(mw, __shfl_xor(mw, 32));
+    const float sc_ = exp2f(m[g] - (mw == -INFINITY ? 0.f : mw));
+    float lw = l[g] * sc_;
+    lw += __shfl_xor(lw, 16);
+    lw += __shfl_xor(lw, 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = acc[g][j] * sc_;
+      a += __shfl_xor(a, 16);
+      a += __shfl_xor(a, 32);
+      if (rsel == 0) part[wave][g][sub * 8 + j] = a;
+    }
+    if (lane == 0) {
+      part[wave][g][D] = mw;
+      part[wave][g][D + 1] = lw;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < GROUP * D; i += 256) {
+    const int g = i / D, dd = i % D;
+    const float M = fmaxf(fmaxf(part[0][g][D], part[1][g][D]), fmaxf(part[2][g][D], part[3][g][D]));  // finite: row p
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = exp2f(part[w][g][D] - M);
+      num += part[w][g][dd] * f;
+      den += part[w][g][D + 1] * f;
+    }
+    out[((size_t)b * nh + kvh * GROUP + g) * D + dd] = (half_t)(num / den);
+  }
+}
+
 // y[m, 8t + i] = silu(gu[m, 16t + i]) * gu[m, 16t + 8 + i], i < 8: gate and up channels interleaved in blocks of 8, the
 // order the fused gate_up GEMM produces (and consumes directly when its silu_mul epilogue is on); I % 8 == 0
 __global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict__ gu, half_t* __restrict__ y, int I, size_t n8) {
@@ -455,6 +611,22 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
   if (batch <= 0 || head_dim != 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_UNSUPPORTED;
   const size_t lds = (((size_t)cache_len + 3) & ~(size_t)3) * 4 + 4 * 128 * 4 + 128 * 4;
   if (lds > 64 * 1024) return QUICK_ERR_UNSUPPORTED;
+#define QA_GQA(GROUP, UNR)                                                                                         \
+  hipLaunchKernelGGL((decode_rope_attention_gqa_kernel<GROUP, UNR>), dim3(n_kv_heads, batch), dim3(256), 0,        \
+                     (hipStream_t)hip_stream, (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, \
+                     (const long*)pos, (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads,       \
+                     cache_len, scale)
+  // grouped-query models with enough (sequence, KV head) pairs to fill the chip: one sweep over the cache per KV head
+  const int group = n_heads / n_kv_heads;
+  // (measured [r01]: 32 query / 8 KV heads, bs=64, 190 positions: 21.5 us against 32.6 us with a workgroup per query head;
+  // with fewer than ~256 workgroups -- or 8 heads per group below ~512 -- the per-head kernels are ahead)
+  if (group > 1 && (group == 2 || group == 4 || group == 8) && batch * n_kv_heads >= (group == 8 ? 512 : 256)) {
+    if (group == 2) QA_GQA(2, 8);
+    else if (group == 4) QA_GQA(4, 8);
+    else QA_GQA(8, 4);
+    return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+  }
+#undef QA_GQA
   // single-pass kernel while the launch is latency-bound (+8 % decode tok/s at bs=1, +5 % at bs=8 [r01]); from ~1000
   // workgroups on the two-pass kernel is 0.5-1 % ahead
   if (batch * n_heads < 1024) {
