@@ -1191,9 +1191,10 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
       const bool dz_ok = mblocks == 1 && !no_xlds && !((kernel >> 25) & 1) && N / 16 >= 1024 &&
                          skinny_lds_bytes(M, G, 1, 8, KT, true, true, true) <= kLdsPerCu;
       if (!dz_ok) mt_auto = 4;
-    } else if (!mt_req && M >= 6 && M <= 8 && K >= 8192 && N >= 8192 && N / 16 < 1024) {
-      mt_auto = 4;  // the x copy of the deferred-zero path leaves one workgroup per CU here: at M = 8, 8192 x 10240
-    }               // 18.7 -> 16.6 us, 28672 x 8192 49 -> 34 us; from 1024 blocks (8192 x 57344) deferred-zero stays ahead
+    } else if (!mt_req && M >= 6 && M <= 8 && N >= 8192 && N / 16 < 1024 && (size_t)M * (K * 2 + 16) > (size_t)64 * 1024) {
+      // (only where the 4-tile kernel takes its fragments straight from L2: its LDS-copy flavour is slower, M = 6, 7 at K = 4096)
+      mt_auto = 4;  // at M = 8: 4096 x 12288 11.0 -> 10.3 us, 8192 x 10240 18.7 -> 16.6 us, 28672 x 8192 49 -> 34 us; from
+    }               // 1024 blocks (4096 x 22016, 8192 x 57344) the deferred-zero path stays ahead, and so it does at M <= 4
     p.mt = mt_req ? mt_req : mt_auto;
     if (p.mt != 1 && p.mt != 2) p.mt = 4;
     while (p.mt > 1 && (N / 16) % p.mt != 0) p.mt /= 2;
