@@ -244,6 +244,57 @@ __device__ __forceinline__ void skinny_compute_dz(const SkinnyChunk<NTW, GM, U, 
   }
 }
 
+// Deferred-zero compute WITHOUT the LDS copy of x (fragments straight from L2, any M <= 16 x NTW tiles): the unit sums
+// A = sum_k x and C = sum_k b_k x come out of the matrix core too -- one extra MFMA per k-step, shared by the NTW channel
+// tiles, with a CONSTANT B operand whose even columns are all ones and whose odd columns hold b_k (1024 / 64 in
+// biased8's order) -- so an accumulator lane ends up with A (even channel lane) or C (odd channel lane) of its 4 tokens
+// and gets the other from its neighbour with one DPP move.  ~12 VALU per unit per wave on top of 5 per packed dword and
+// ~12 per (unit, channel tile); no table, no LDS, no per-workgroup prologue.
+template <int NTW, int GM, int U>
+__device__ __forceinline__ void skinny_compute_dzf(const SkinnyChunk<NTW, GM, U, false>& c, int kt, int kt_end,
+                                                   const LaneSel& ls, half8_t bconst, bool odd, floatx4 (&acc)[NTW]) {
+  constexpr int NG = groups_per_tile<GM>();  // units per 128-k tile
+  constexpr int TPU = 4 / NG;                // k-steps per unit
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (kt + u < kt_end) {  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        floatx4 sm = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = i * TPU; t < (i + 1) * TPU; ++t) sm = mfma16(c.xf[u][t], bconst, sm);
+        floatx4 xa, nc;  // A and -C of this lane's 4 tokens
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mine = sm[r];  // (a copy: __builtin_bit_cast of the vector element itself reads element 0)
+          const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0xB1, 0xf, 0xf, false));
+          xa[r] = odd ? other : mine;
+          nc[r] = -(odd ? mine : other);
+        }
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          floatx4 g = nc;
+#pragma unroll
+          for (int t = i * TPU; t < (i + 1) * TPU; ++t) g = mfma16(c.xf[u][t], biased8(c.w[u][j][t]), g);
+          const float s = (float)as_h2(__builtin_amdgcn_perm(c.raw[u][j][i].s2, c.raw[u][j][i].s2, ls.sperm))[0];
+          const float z = (float)__builtin_amdgcn_ubfe(c.raw[u][j][i].zq, ls.zshift, 4u);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-z, xa[r], g[r]), acc[j][r]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        asm volatile("" ::"v"(c.w[u][j]));
+#pragma unroll
+        for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(c.raw[u][j][i].s2), "v"(c.raw[u][j][i].zq));
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(c.xf[u][t]));
+    }
+  }
+}
+
 // Finishes the channel block `nb`: the waves' K partials meet in LDS (buffer `red`), wave j < NTW adds them for
 // channel tile j, joins the other K slices if there are any, applies the epilogue and stores.  Returns with `acc`
 // zeroed for the next block.  One workgroup barrier (two more when K is split across workgroups).
@@ -364,7 +415,6 @@ template <int NTW, int WAVES, int GM, bool XLDS, bool DZ>
 __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
   constexpr bool PERSIST = XLDS;
   static_assert(WAVES >= NTW, "the final reduction assigns one channel tile per wave");
-  static_assert(XLDS || !DZ, "the deferred-zero path tabulates x while copying it to LDS");
   constexpr int U = XLDS ? (NTW == 1 ? 4 : 2) : (NTW <= 2 ? 2 : 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nblocks = a.N / (16 * NTW);
@@ -407,8 +457,8 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     }                                                                                                              \
   } while (0)
 #define QA_SKINNY_COMPUTE(ccomp)                                                                                   \
-  if constexpr (DZ) skinny_compute_dz<NTW, GM, U>(ccomp, kt_cur, kt_end, xl, tab, ls, acc);                        \
-  else skinny_compute<NTW, GM, U, XLDS>(ccomp, kt_cur, kt_end, xl, ls, acc);                                       \
+  if constexpr (DZ && XLDS) skinny_compute_dz<NTW, GM, U>(ccomp, kt_cur, kt_end, xl, tab, ls, acc);                \
+  else if constexpr (!DZ) skinny_compute<NTW, GM, U, XLDS>(ccomp, kt_cur, kt_end, xl, ls, acc);                    \
   if (kt_cur + U >= kt_end) {                                                                                      \
     skinny_finish<NTW, WAVES, DZ>(a, acc, red + parity * (WAVES * NTW * 64), smem, nb_cur, nblocks, mb, ks, lane,  \
                                   wave);                                                                           \
@@ -430,16 +480,22 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   if constexpr (!PERSIST) {
     // one block per workgroup, x fragments straight from L2
     const int cb = blockIdx.x * NTW;
+    // B operand of the sum MFMAs (deferred-zero flavour): column = lane & 15; even columns ones, odd columns b_k
+    const u32x4 bc_bits = (lane & 1) ? u32x4{0x64006400u, 0x54005400u, 0x64006400u, 0x54005400u}
+                                     : u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+    const half8_t bconst = __builtin_bit_cast(half8_t, bc_bits);
     if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt_begin, kt_end - 1, bufs, cb, xp, a);
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
       if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS>(cB, kt + U, kt_end - 1, bufs, cb, xp, a);
       __builtin_amdgcn_sched_barrier(0);
-      skinny_compute<NTW, GM, U, XLDS>(cA, kt, kt_end, nullptr, ls, acc);
+      if constexpr (DZ) skinny_compute_dzf<NTW, GM, U>(cA, kt, kt_end, ls, bconst, (lane & 1) != 0, acc);
+      else skinny_compute<NTW, GM, U, XLDS>(cA, kt, kt_end, nullptr, ls, acc);
       if (kt + U >= kt_end) break;
       if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt + 2 * U, kt_end - 1, bufs, cb, xp, a);
       __builtin_amdgcn_sched_barrier(0);
-      skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, ls, acc);
+      if constexpr (DZ) skinny_compute_dzf<NTW, GM, U>(cB, kt + U, kt_end, ls, bconst, (lane & 1) != 0, acc);
+      else skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, ls, acc);
     }
     skinny_finish<NTW, WAVES, DZ>(a, acc, red, smem, blockIdx.x, nblocks, mb, ks, lane, wave);
     return;
@@ -1122,7 +1178,7 @@ struct Plan {
   int waves;   // skinny: waves per workgroup
   bool xlds;   // skinny: x through an LDS copy
   int grid_x;  // skinny: workgroups along the channel blocks; fewer than the blocks = persistent workgroups
-  bool dz;     // skinny: deferred-zero compute (needs xlds)
+  bool dz;     // skinny: deferred-zero compute; with xlds the table flavour (NTW = 1), without the fragment flavour
   int ksplit;  // K slices across workgroups, reduced in-kernel by the last arriver
   int ntiles;  // output tiles (one arrival counter each)
   size_t slab_floats;  // fp32 elements of one partial tile
@@ -1265,7 +1321,13 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
         if (!flip && p.ksplit == 1 && rounds >= 2) p.grid_x = (nblocks + rounds - 1) / rounds;
       }
     }
-    if (!p.dz) {
+    if (!p.dz && !exact && !((kernel >> 28) & 1) && M <= 16 && p.mt >= 2 && G % 128 == 0 &&  // (G < 128: 4 units per tile, spills)
+        (no_xlds || (size_t)std::min(M, 16) * (p.kt_per_split * 256 + 16) > (size_t)64 * 1024)) {
+      // fragment flavour of the deferred-zero path: several channel tiles per workgroup, x fragments straight from L2,
+      // the unit sums from one extra MFMA per k-step (kernel bit 28 forbids it)
+      p.dz = true;
+      p.xlds = false;
+    } else if (!p.dz) {
       // exact path: x through LDS while the copy is small (64 KiB), else fragments straight from L2; persistent
       // launches measured within +-5 % of one block per workgroup [r01] and are off unless asked for
       p.xlds = !no_xlds && M <= 16 && (size_t)std::min(M, 16) * (p.kt_per_split * 256 + 16) <= (size_t)64 * 1024;
@@ -1321,6 +1383,12 @@ static void launch_skinny(const Plan& p, const GemmArgs& a, const Launch& L) {
       if (p.waves == 4) launch_skinny_gm<1, 4, true, true>(p, a, L);
       else if (p.waves == 16) launch_skinny_gm<1, 16, true, true>(p, a, L);
       else launch_skinny_gm<1, 8, true, true>(p, a, L);
+      return;
+    }
+  }
+  if constexpr (NTW >= 2) {
+    if (p.dz && !p.xlds) {
+      launch_skinny_gm<NTW, 8, false, true>(p, a, L);
       return;
     }
   }
@@ -1415,7 +1483,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   const Plan p = make_plan(M, K, N, G, kernel, grid_split_k);
   if (f.silu_mul && (f.bias || f.residual)) return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual");
   if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
-  if (f.ln_w && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1))
+  if (f.ln_w && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.xlds && p.ksplit == 1))
     return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
              (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr, (const half_t*)f.ln_w, f.ln_eps};
@@ -1495,7 +1563,7 @@ int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size) {
   // the deferred-zero skinny kernel copies (and tabulates) x per workgroup anyway: normalising on the way costs a
   // second pass over LDS, not a launch
   const Plan p = make_plan(M, K, N, group_size, QUICK_KERNEL_AUTO, 0);
-  return p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1;
+  return p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.xlds && p.ksplit == 1;
 }
 
 int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const void* const* scales,

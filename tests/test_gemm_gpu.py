@@ -149,6 +149,25 @@ def test_deferred_zero_matches_exact_kernel(qa, device, M, K, N, G):
     assert rel_err(ydz, yex) <= 1e-3
 
 
+@pytest.mark.parametrize("M,K,N,G", [(16, 4096, 12288, 128), (12, 8192, 8192, 128), (8, 4096, 12288, 64), (9, 4096, 12288, 32),
+                                     (24, 11008, 4096, 128)])
+def test_fragment_deferred_zero_matches_exact_kernel(qa, device, M, K, N, G):
+    """M = 6..32 on large layers: 4 channel tiles per workgroup, x fragments straight from L2, the unit sums from an extra
+    MFMA per k-step (no LDS table).  Against the same launch shape with exact per-weight dequantisation (bit 25) and the
+    oracle; per-row, so that a token-dependent slip cannot hide behind the matrix maximum."""
+    from quick_amd import kernels as K_
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=5 * M + K + N)
+    want = oracle.w4a16_forward(x, iw, s, z, G).astype(np.float32)
+    packed = _pack_dev(iw, s, z, device)
+    assert not K_.can_fuse_rmsnorm(M, K, N, G)          # no x copy, no prologue on this path
+    ydz = qa.gemm_forward(_dev(x, device), *packed).cpu().numpy().astype(np.float32)
+    yex = qa.gemm_forward(_dev(x, device), *packed, kernel_id=1 << 25).cpu().numpy().astype(np.float32)
+    scale = np.abs(want).max()
+    assert (np.abs(ydz - want).max(axis=1) <= TOL * scale).all()
+    assert (np.abs(yex - want).max(axis=1) <= TOL * scale).all()
+    assert rel_err(ydz, yex) <= 1e-3
+
+
 def test_deferred_zero_with_activation_outliers(qa, device):
     """Massive activations (a few |x| ~ 2000 among |x| ~ 1) put 1024 * x into the fp32 accumulator before the group's
     bias term is removed; the cancellation error has to stay far below the tolerance."""
@@ -411,7 +430,7 @@ def test_decode_glue_kernels_against_torch(qa, device):
                 qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw)
 
 
-@pytest.mark.parametrize("M,K,N,G", [(1, 4096, 12288, 128), (1, 4096, 4096, 128), (8, 4096, 11008, 128), (16, 1024, 12288, 64),
+@pytest.mark.parametrize("M,K,N,G", [(1, 4096, 12288, 128), (1, 4096, 4096, 128), (8, 4096, 22016, 128), (16, 1024, 12288, 64),
                                      (3, 11008, 12288, 128)])
 def test_rmsnorm_prologue_matches_two_launches(qa, device, M, K, N, G):
     """gemm(rmsnorm(x) * w) in one launch: the prologue reproduces quick_rmsnorm_f16's rounding points, so the only
