@@ -1321,8 +1321,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
         if (!flip && p.ksplit == 1 && rounds >= 2) p.grid_x = (nblocks + rounds - 1) / rounds;
       }
     }
-    if (!p.dz && !exact && !((kernel >> 28) & 1) && M <= 16 && p.mt >= 2 && G % 128 == 0 &&  // (G < 128: 4 units per tile, spills)
-        (no_xlds || (size_t)std::min(M, 16) * (p.kt_per_split * 256 + 16) > (size_t)64 * 1024)) {
+    if (!p.dz && !exact && !((kernel >> 28) & 1) && p.mt >= 2 && G % 128 == 0 &&  // (G < 128: 4 units per tile, spills)
+        (no_xlds || M > 16 || (size_t)std::min(M, 16) * (p.kt_per_split * 256 + 16) > (size_t)64 * 1024)) {
       // fragment flavour of the deferred-zero path: several channel tiles per workgroup, x fragments straight from L2,
       // the unit sums from one extra MFMA per k-step (kernel bit 28 forbids it)
       p.dz = true;
