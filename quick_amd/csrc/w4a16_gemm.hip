@@ -1388,7 +1388,8 @@ static void launch_skinny(const Plan& p, const GemmArgs& a, const Launch& L) {
   }
   if constexpr (NTW >= 2) {
     if (p.dz && !p.xlds) {
-      launch_skinny_gm<NTW, 8, false, true>(p, a, L);
+      if (p.waves == 4) launch_skinny_gm<NTW, 4, false, true>(p, a, L);
+      else launch_skinny_gm<NTW, 8, false, true>(p, a, L);
       return;
     }
   }
