@@ -426,6 +426,11 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   const int wave = uniform(threadIdx.x >> 6);
   const int n16 = lane & 15, q = lane >> 4;
   const int mb = blockIdx.y, ks = blockIdx.z;
+  // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin, and neighbouring channel blocks share the
+  // 128-byte lines of their group constants (4 blocks per line of scales, 16 per line of zero points) -- give every XCD
+  // a contiguous run of blocks, so that its L2 fetches each of those lines once instead of all eight fetching it.
+  const int gx = (int)gridDim.x;
+  const int bx = (gx & 7) == 0 ? ((int)blockIdx.x & 7) * (gx >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
   const int KT = a.K >> 7;
   const int wg_begin = ks * a.kt_per_split, wg_end = min(KT, wg_begin + a.kt_per_split);
   const int cnt = wg_end - wg_begin;
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   for (int j = 0; j < NTW; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   // (block, k-tile) of the chunk being computed / of the chunk being loaded; both wave-uniform
-  int nb_cur = blockIdx.x, kt_cur = kt_begin;
+  int nb_cur = bx, kt_cur = kt_begin;
   int nb_nxt = nb_cur, kt_nxt = kt_cur;
   int parity = 0;
   // The load of the next chunk is issued in a block that always issues it: a guarded load would make hipcc's
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   SkinnyChunk<NTW, GM, U, XLDS> cA, cB;
   if constexpr (!PERSIST) {
     // one block per workgroup, x fragments straight from L2
-    const int cb = blockIdx.x * NTW;
+    const int cb = bx * NTW;
     // B operand of the sum MFMAs (deferred-zero flavour): column = lane & 15; even columns ones, odd columns b_k
     const u32x4 bc_bits = (lane & 1) ? u32x4{0x64006400u, 0x54005400u, 0x64006400u, 0x54005400u}
                                      : u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
       if constexpr (DZ) skinny_compute_dzf<NTW, GM, U>(cB, kt + U, kt_end, ls, bconst, (lane & 1) != 0, acc);
       else skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, ls, acc);
     }
-    skinny_finish<NTW, WAVES, DZ>(a, acc, red, smem, blockIdx.x, nblocks, mb, ks, lane, wave);
+    skinny_finish<NTW, WAVES, DZ>(a, acc, red, smem, bx, nblocks, mb, ks, lane, wave);
     return;
   }
   QA_SKINNY_LOAD(cA);  // HBM requests first
@@ -1318,7 +1323,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
       const bool balanced = (double)nblocks >= 0.8 * rounds * 256 * c;
       if (M <= 2 || ((kernel >> 26) & 1) || (rounds >= 2 && balanced && p.ksplit == 1)) {  // bit 26: tests force the path
         p.dz = p.xlds = true;
-        if (!flip && p.ksplit == 1 && rounds >= 2) p.grid_x = (nblocks + rounds - 1) / rounds;
+        if (!flip && p.ksplit == 1 && rounds >= 2) p.grid_x = std::min(nblocks, ((nblocks + rounds - 1) / rounds + 7) & ~7);
       }
     }
     if (!p.dz && !exact && !((kernel >> 28) & 1) && p.mt >= 2 && G % 128 == 0 &&  // (G < 128: 4 units per tile, spills)
