@@ -12,6 +12,7 @@ Cache, so small-M numbers are HBM numbers, not cache numbers.  Rank 0 prints ONE
   roofline             the GEMM kernel's OWN duration (hipEvent pair bound to each dispatch, the same clock
                        rocprofv3 --kernel-trace reports) against the HBM or MFMA peak
   sweep                the same two measurements for every M of the BASELINE sweep (1, 8, 64, 512)
+  decode_layers        kernel duration and HBM fraction of the Llama-2-7B layer shapes at M=1 (N=1 only)
   cpu_baseline         the reference's CPU path (dequantize_gemm + torch.matmul, restated in oracle/cpu_path.py)
                        timed on the host cores on a bounded sample, N=1 only
 
@@ -48,6 +49,8 @@ def main():
     ap.add_argument("--sweep", default="1,8,64,512", help="comma-separated M values reported in 'sweep'")
     ap.add_argument("--sets", type=int, default=0, help="distinct weight sets cycled through (0 = enough for > 320 MiB)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 skinny, 2 tiled")
+    ap.add_argument("--layers", default="1x4096x12288,1x4096x22016,1x11008x4096",
+                    help="MxKxN shapes (Llama-2-7B fused qkv, gate_up, down at bs=1) timed kernel-only into 'decode_layers'; '' = none")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -191,6 +194,41 @@ def main():
         "roofline": head["roofline"],
         "sweep": [results[m] for m in Ms],
     }
+
+    # ---- decode-layer shapes, kernel duration only (HBM-cold: the weight sets cycled exceed the Infinity Cache)
+    if world == 1 and args.layers:
+        out["decode_layers"] = []
+        for spec in args.layers.split(","):
+            Ml, Kl, Nl = (int(v) for v in spec.lower().split("x"))
+            sb = Kl * Nl // 2 + (Kl // G) * 2 * Nl * 2 + (Kl // G) * (Nl // 4) * 4
+            ns = max(2, -(-(320 << 20) // sb))
+            lsets = []
+            for _ in range(ns):
+                qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (Kl // 4, Nl // 2), dtype=torch.int32, device=dev, generator=gen)
+                sc = torch.zeros((Kl // G, 2 * Nl), dtype=torch.float16, device=dev)
+                sc[:, :Nl] = (torch.rand((Kl // G, Nl), device=dev, generator=gen) * 0.02 + 0.005).half()
+                qz = torch.zeros((Kl // G, Nl // 4), dtype=torch.int32, device=dev)
+                qz[:, :Nl // 8] = torch.randint(-2 ** 31, 2 ** 31 - 1, (Kl // G, Nl // 8), dtype=torch.int32, device=dev, generator=gen)
+                lsets.append((qw, sc, qz))
+            larr = lambda i: (ctypes.c_void_p * ns)(*[st[i].data_ptr() for st in lsets])
+            xl = (torch.randn((Ml, Kl), device=dev, generator=gen) * 0.5).half()
+            yl = torch.empty((Ml, Nl), dtype=torch.float16, device=dev)
+            wsb = lib.quick_w4a16_workspace_bytes_ex(Ml, Kl, Nl, G, args.kernel, 0)
+            wsl = torch.zeros(max(wsb, 1), dtype=torch.uint8, device=dev)
+            it = 60
+            kus = (ctypes.c_float * it)()
+            rc = lib.quick_w4a16_gemm_profile(xl.data_ptr(), larr(0), larr(1), larr(2), ns, yl.data_ptr(), wsl.data_ptr(), wsb,
+                                              Ml, Kl, Nl, G, args.kernel, 0, it, kus, stream.cuda_stream)
+            if rc != 0:
+                raise RuntimeError(_lib.last_error())
+            k_us = float(np.mean(np.asarray(kus[:])[5:]))
+            nb = oracle.algorithmic_bytes(Ml, Kl, Nl, G)
+            ach = nb / (k_us * 1e-6) / 1e9
+            out["decode_layers"].append({"M": Ml, "K": Kl, "N": Nl, "kernel_us": k_us, "weight_sets_cycled": ns,
+                                         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                      "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": nb}})
+            log(f"layer M={Ml} K={Kl} N={Nl}: kernel {k_us:7.2f} us  {ach:7.1f} GB/s = {100 * ach / HBM_PEAK_GBS:.1f}% of HBM peak")
+            del lsets, larr
 
     # ---- the reference's CPU path on the host cores, bounded sample, rank 0 / N=1 only
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
