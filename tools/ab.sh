@@ -12,7 +12,7 @@ for n in $names; do
   while read -r s; do
     [ -z "$s" ] && continue
     set -- $s
-    python bench.py --steps 40 --warmup 5 --cpu-seconds 0 --K $2 --N $3 --sweep $1 --M $1 --sets 8 2>&1 >/dev/null | grep "M=" | sed 's/roofline.*//; s/(cache.*//' | sed "s/^/K=$2 N=$3 /"
+    python bench.py --steps 40 --warmup 5 --cpu-seconds 0 --layers "" --K $2 --N $3 --sweep $1 --M $1 --sets 8 2>&1 >/dev/null | grep "M=" | sed 's/roofline.*//; s/(cache.*//' | sed "s/^/K=$2 N=$3 /"
   done <<< "${AB_SHAPES:-$DEFAULT_SHAPES}"
   python bench_decode.py ${AB_DECODE:---model llama2-7b --bs 1 8} 2>/dev/null | python -c "
 import sys, json
