@@ -90,10 +90,11 @@ int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scal
 size_t quick_w4a16_workspace_bytes_ex(int M, int K, int N, int group_size, int kernel, int grid_split_k);
 
 /* What may be fused around the GEMM (all optional; zero-initialise the struct):
- *   rmsnorm_weight  fp16 [K]: x is RMS-normalised (eps = rmsnorm_eps) and scaled by this weight on its way into the
- *                   kernel, with quick_rmsnorm_f16's rounding points (fp16(fp16(x * rstd) * weight)).  Only where
- *                   quick_w4a16_can_fuse_rmsnorm() says so -- the small-M kernel that holds x whole in LDS --
- *                   QUICK_ERR_UNSUPPORTED otherwise (run quick_rmsnorm_f16 first).
+ *   rmsnorm_weight  fp16 [K]: the GEMM consumes RMSNorm(x) * weight (eps = rmsnorm_eps).  Where the kernel holds x whole
+ *                   in LDS it normalises there with quick_rmsnorm_f16's rounding points (fp16(fp16(x * rstd) * weight));
+ *                   where it takes x fragments straight from L2 it multiplies them by the weight in fp16 and applies
+ *                   1 / rms to the fp32 result.  Only where quick_w4a16_can_fuse_rmsnorm() says so (small-M kernels, K not
+ *                   split across workgroups) -- QUICK_ERR_UNSUPPORTED otherwise (run quick_rmsnorm_f16 first).
  *   bias            fp16 [N]      (replaces the torch add of quick/awq/modules/linear/quick.py:165)
  *   residual        fp16 [M, N], may alias y: the decoder block's `hidden + proj(...)`
  *   silu_mul        output channels are gate/up interleaved in blocks of 8 (16t+i gate, 16t+8+i up, i < 8) and the

@@ -95,11 +95,12 @@ __device__ __forceinline__ bool splitk_arrive(unsigned* counter, int nslices, un
 // by 16 B so the token rows of a fragment read spread over the bank groups) and every B fragment is a
 // ds_read_b128 -- for M == 1 a 4-address broadcast -- instead of a 64-lane global load fetching 64 B per token
 // row, 15/16 of them wasted when M == 1.
-template <int NTW, int GM, int U, bool XLDS>
+template <int NTW, int GM, int U, bool XLDS, bool LN = false>
 struct SkinnyChunk {
   u32x4 w[U][NTW];
   GroupRaw raw[U][NTW][groups_per_tile<GM>()];
   half8_t xf[XLDS ? 1 : U][XLDS ? 1 : 4];
+  half8_t gf[LN ? U : 1][LN ? 4 : 1];  // RMSNorm weight fragments (LN: the norm is applied to the x fragments in registers)
 };
 
 // Weights and group constants come in through buffer loads: address = descriptor base + per-lane byte offset (a launch
@@ -127,9 +128,9 @@ __device__ __forceinline__ SkinnyBufs skinny_bufs(const GemmArgs& a, int lane) {
 }
 
 // chunk of U k-tiles starting at kt of channel block `cb` (in units of 16 channels: block index * NTW)
-template <int NTW, int GM, int U, bool XLDS>
-__device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS>& c, int kt, int kt_last, const SkinnyBufs& b,
-                                            int cb, const half_t* xp, const GemmArgs& a) {
+template <int NTW, int GM, int U, bool XLDS, bool LN = false>
+__device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS, LN>& c, int kt, int kt_last, const SkinnyBufs& b,
+                                            int cb, const half_t* xp, const GemmArgs& a, const half_t* gp = nullptr) {
   constexpr int NG = groups_per_tile<GM>();
 #pragma unroll
   for (int u = 0; u < U; ++u)
@@ -151,6 +152,12 @@ __device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS>& c, in
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int t = 0; t < 4; ++t) c.xf[u][t] = *(const half8_t*)(xp + min(kt + u, kt_last) * 128 + 32 * t);
+  }
+  if constexpr (LN) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c.gf[u][t] = *(const half8_t*)(gp + min(kt + u, kt_last) * 128 + 32 * t);
   }
 }
 
@@ -250,19 +257,38 @@ __device__ __forceinline__ void skinny_compute_dz(const SkinnyChunk<NTW, GM, U, 
 // biased8's order) -- so an accumulator lane ends up with A (even channel lane) or C (odd channel lane) of its 4 tokens
 // and gets the other from its neighbour with one DPP move.  ~12 VALU per unit per wave on top of 5 per packed dword and
 // ~12 per (unit, channel tile); no table, no LDS, no per-workgroup prologue.
-template <int NTW, int GM, int U>
-__device__ __forceinline__ void skinny_compute_dzf(const SkinnyChunk<NTW, GM, U, false>& c, int kt, int kt_end,
-                                                   const LaneSel& ls, half8_t bconst, bool odd, floatx4 (&acc)[NTW]) {
+// LN: RMSNorm folded in -- the x fragments are multiplied by the norm weight in registers (fp16, like the weight multiply of
+// quick_rmsnorm_f16), the squares of the raw x are summed per lane (`ssq`), and the row scale 1/rms is applied to the
+// fp32 result in skinny_finish: gemm(x * w) * rstd instead of gemm(fp16(fp16(x * rstd) * w)).
+template <int NTW, int GM, int U, bool LN = false>
+__device__ __forceinline__ void skinny_compute_dzf(const SkinnyChunk<NTW, GM, U, false, LN>& c, int kt, int kt_end,
+                                                   const LaneSel& ls, half8_t bconst, bool odd, floatx4 (&acc)[NTW],
+                                                   float* ssq = nullptr) {
   constexpr int NG = groups_per_tile<GM>();  // units per 128-k tile
   constexpr int TPU = 4 / NG;                // k-steps per unit
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (kt + u < kt_end) {  // wave-uniform
+      half8_t xs[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if constexpr (LN) {
+          xs[t] = c.xf[u][t] * c.gf[u][t];
+          const u32x4 raw = __builtin_bit_cast(u32x4, c.xf[u][t]);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const uint32_t rd = raw[d];
+            *ssq = __builtin_amdgcn_fdot2(as_h2(rd), as_h2(rd), *ssq, false);
+          }
+        } else {
+          xs[t] = c.xf[u][t];
+        }
+      }
 #pragma unroll
       for (int i = 0; i < NG; ++i) {
         floatx4 sm = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = i * TPU; t < (i + 1) * TPU; ++t) sm = mfma16(c.xf[u][t], bconst, sm);
+        for (int t = i * TPU; t < (i + 1) * TPU; ++t) sm = mfma16(xs[t], bconst, sm);
         floatx4 xa, nc;  // A and -C of this lane's 4 tokens
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -275,7 +301,7 @@ __device__ __forceinline__ void skinny_compute_dzf(const SkinnyChunk<NTW, GM, U,
         for (int j = 0; j < NTW; ++j) {
           floatx4 g = nc;
 #pragma unroll
-          for (int t = i * TPU; t < (i + 1) * TPU; ++t) g = mfma16(c.xf[u][t], biased8(c.w[u][j][t]), g);
+          for (int t = i * TPU; t < (i + 1) * TPU; ++t) g = mfma16(xs[t], biased8(c.w[u][j][t]), g);
           const float s = (float)as_h2(__builtin_amdgcn_perm(c.raw[u][j][i].s2, c.raw[u][j][i].s2, ls.sperm))[0];
           const float z = (float)__builtin_amdgcn_ubfe(c.raw[u][j][i].zq, ls.zshift, 4u);
 #pragma unroll
@@ -291,6 +317,10 @@ __device__ __forceinline__ void skinny_compute_dzf(const SkinnyChunk<NTW, GM, U,
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(c.xf[u][t]));
+      if constexpr (LN) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(c.gf[u][t]));
+      }
     }
   }
 }
@@ -301,10 +331,16 @@ __device__ __forceinline__ void skinny_compute_dzf(const SkinnyChunk<NTW, GM, U,
 // TR: the accumulators come from the deferred-zero path (lane = channel n16, registers = tokens 4q..4q+3) and are
 // written to LDS transposed, so that everything after the barrier sees the usual fragment (lane = token, registers =
 // channels 4q..4q+3).
-template <int NTW, int WAVES, bool TR>
+template <int NTW, int WAVES, bool TR, bool LN = false>
 __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[NTW], floatx4* red, char* smem, int nb,
-                                              int nblocks, int mb, int ks, int lane, int wave) {
+                                              int nblocks, int mb, int ks, int lane, int wave, float ssq = 0.f) {
   const int n16 = lane & 15, q = lane >> 4;
+  float* ssq_lds = (float*)(red + WAVES * NTW * 64);  // LN: [WAVES][16] behind the reduction buffer
+  if constexpr (LN) {  // this wave's sum of squares per token: the 4 k-octet lanes of a token row, then LDS
+    ssq += __shfl_xor(ssq, 16);
+    ssq += __shfl_xor(ssq, 32);
+    if (q == 0) ssq_lds[wave * 16 + n16] = ssq;
+  }
   if constexpr (TR && NTW == 1) {
     if (a.ksplit == 1) {
       // Deferred-zero path, K not split across workgroups: every wave finishes its own 16 / WAVES tokens (lane = one
@@ -371,6 +407,14 @@ __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[
   }
   if (wave >= NTW) return;
   const int m = mb * 16 + n16;
+  if constexpr (LN) {  // lane = token n16: scale its 4 channels by 1 / rms(x[token])
+    float ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) ss += ssq_lds[w * 16 + n16];
+    const float rstd = rsqrtf(ss / (float)a.K + a.ln_eps);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum[r] *= rstd;
+  }
   if (a.silu_mul) {
     floatx4 up;
 #pragma unroll
@@ -411,9 +455,10 @@ __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[
 // Only the XLDS variants can be launched persistent.  The fragments-from-L2 variants keep the plain one-block loop: in
 // the cross-block form hipcc needs 141 instead of 121 VGPRs for NTW = 1 (one workgroup per CU instead of two: -9 % on
 // the Llama-2-70B shapes at M = 16 [r01]).
-template <int NTW, int WAVES, int GM, bool XLDS, bool DZ>
+template <int NTW, int WAVES, int GM, bool XLDS, bool DZ, bool LN = false>
 __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
   constexpr bool PERSIST = XLDS;
+  static_assert(!LN || (DZ && !XLDS && NTW >= 2), "the register-level RMSNorm lives in the fragment deferred-zero flavour");
   static_assert(WAVES >= NTW, "the final reduction assigns one channel tile per wave");
   constexpr int U = XLDS ? (NTW == 1 ? 4 : 2) : (NTW <= 2 ? 2 : 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -452,7 +497,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   int parity = 0;
   // The load of the next chunk is issued in a block that always issues it: a guarded load would make hipcc's
   // s_waitcnt pass assume the smaller in-flight count and wait for most of the prefetch before the compute.
-#define QA_SKINNY_LOAD(c) skinny_load<NTW, GM, U, XLDS>(c, kt_nxt, kt_last, bufs, nb_nxt * NTW, xp, a)
+#define QA_SKINNY_LOAD(c) skinny_load<NTW, GM, U, XLDS, LN>(c, kt_nxt, kt_last, bufs, nb_nxt * NTW, xp, a)
 #define QA_SKINNY_ADVANCE(nb, kt)                                                                                  \
   do {                                                                                                             \
     kt += U;                                                                                                       \
@@ -481,28 +526,30 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   kt_cur = kt_nxt;                                                                                                 \
   QA_SKINNY_ADVANCE(nb_nxt, kt_nxt)
 
-  SkinnyChunk<NTW, GM, U, XLDS> cA, cB;
+  SkinnyChunk<NTW, GM, U, XLDS, LN> cA, cB;
   if constexpr (!PERSIST) {
+    float ssq = 0.f;
+    const half_t* gp = LN ? a.ln_w + q * 8 : nullptr;
     // one block per workgroup, x fragments straight from L2
     const int cb = bx * NTW;
     // B operand of the sum MFMAs (deferred-zero flavour): column = lane & 15; even columns ones, odd columns b_k
     const u32x4 bc_bits = (lane & 1) ? u32x4{0x64006400u, 0x54005400u, 0x64006400u, 0x54005400u}
                                      : u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
     const half8_t bconst = __builtin_bit_cast(half8_t, bc_bits);
-    if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt_begin, kt_end - 1, bufs, cb, xp, a);
+    if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS, LN>(cA, kt_begin, kt_end - 1, bufs, cb, xp, a, gp);
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
-      if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS>(cB, kt + U, kt_end - 1, bufs, cb, xp, a);
+      if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS, LN>(cB, kt + U, kt_end - 1, bufs, cb, xp, a, gp);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DZ) skinny_compute_dzf<NTW, GM, U>(cA, kt, kt_end, ls, bconst, (lane & 1) != 0, acc);
+      if constexpr (DZ) skinny_compute_dzf<NTW, GM, U, LN>(cA, kt, kt_end, ls, bconst, (lane & 1) != 0, acc, &ssq);
       else skinny_compute<NTW, GM, U, XLDS>(cA, kt, kt_end, nullptr, ls, acc);
       if (kt + U >= kt_end) break;
-      if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS>(cA, kt + 2 * U, kt_end - 1, bufs, cb, xp, a);
+      if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS, LN>(cA, kt + 2 * U, kt_end - 1, bufs, cb, xp, a, gp);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DZ) skinny_compute_dzf<NTW, GM, U>(cB, kt + U, kt_end, ls, bconst, (lane & 1) != 0, acc);
+      if constexpr (DZ) skinny_compute_dzf<NTW, GM, U, LN>(cB, kt + U, kt_end, ls, bconst, (lane & 1) != 0, acc, &ssq);
       else skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, ls, acc);
     }
-    skinny_finish<NTW, WAVES, DZ>(a, acc, red, smem, bx, nblocks, mb, ks, lane, wave);
+    skinny_finish<NTW, WAVES, DZ, LN>(a, acc, red, smem, bx, nblocks, mb, ks, lane, wave, ssq);
     return;
   }
   QA_SKINNY_LOAD(cA);  // HBM requests first
@@ -1357,13 +1404,13 @@ static size_t workspace_need(const Plan& p) {
 
 static int group_mode(int G) { return G == 128 ? 0 : (G % 128 == 0 ? 1 : (G == 64 ? 2 : (G == 32 ? 3 : 4))); }
 
-template <int NTW, int WAVES, bool XLDS, bool DZ>
+template <int NTW, int WAVES, bool XLDS, bool DZ, bool LN = false>
 static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) {
   dim3 grid(p.grid_x, (a.M + 15) / 16, p.ksplit), block(WAVES * 64);
-  const size_t lds = skinny_lds_bytes(a.M, a.G, NTW, WAVES, p.kt_per_split, p.grid_x < a.N / (16 * NTW), XLDS, DZ);
+  const size_t lds = skinny_lds_bytes(a.M, a.G, NTW, WAVES, p.kt_per_split, p.grid_x < a.N / (16 * NTW), XLDS, DZ) + (LN ? 1024 : 0);
 #define QA_SKINNY(GMV)                                                                                             \
   do {                                                                                                             \
-    auto kfn = w4a16_skinny_kernel<NTW, WAVES, GMV, XLDS, DZ>;                                                     \
+    auto kfn = w4a16_skinny_kernel<NTW, WAVES, GMV, XLDS, DZ, LN>;                                                 \
     static bool attr_set = false;                                                                                  \
     if (!attr_set) {                                                                                               \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);     \
@@ -1371,12 +1418,17 @@ static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) 
     }                                                                                                              \
     hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)lds, L.st, L.start, L.stop, 0, a);                           \
   } while (0)
-  switch (group_mode(a.G)) {
-    case 0: QA_SKINNY(0); break;
-    case 1: QA_SKINNY(1); break;
-    case 2: QA_SKINNY(2); break;
-    case 3: QA_SKINNY(3); break;
-    default: QA_SKINNY(4); break;
+  if constexpr (LN) {  // only reached with G % 128 == 0
+    if (group_mode(a.G) == 0) QA_SKINNY(0);
+    else QA_SKINNY(1);
+  } else {
+    switch (group_mode(a.G)) {
+      case 0: QA_SKINNY(0); break;
+      case 1: QA_SKINNY(1); break;
+      case 2: QA_SKINNY(2); break;
+      case 3: QA_SKINNY(3); break;
+      default: QA_SKINNY(4); break;
+    }
   }
 #undef QA_SKINNY
 }
@@ -1393,7 +1445,8 @@ static void launch_skinny(const Plan& p, const GemmArgs& a, const Launch& L) {
   }
   if constexpr (NTW >= 2) {
     if (p.dz && !p.xlds) {
-      if (p.waves == 4) launch_skinny_gm<NTW, 4, false, true>(p, a, L);
+      if (a.ln_w) launch_skinny_gm<NTW, 8, false, true, true>(p, a, L);  // RMSNorm on the fragments (run_gemm checked waves == 8)
+      else if (p.waves == 4) launch_skinny_gm<NTW, 4, false, true>(p, a, L);
       else launch_skinny_gm<NTW, 8, false, true>(p, a, L);
       return;
     }
@@ -1489,7 +1542,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   const Plan p = make_plan(M, K, N, G, kernel, grid_split_k);
   if (f.silu_mul && (f.bias || f.residual)) return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual");
   if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
-  if (f.ln_w && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.xlds && p.ksplit == 1))
+  if (f.ln_w && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8))))
     return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
              (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr, (const half_t*)f.ln_w, f.ln_eps};
@@ -1569,7 +1622,7 @@ int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size) {
   // the deferred-zero skinny kernel copies (and tabulates) x per workgroup anyway: normalising on the way costs a
   // second pass over LDS, not a launch
   const Plan p = make_plan(M, K, N, group_size, QUICK_KERNEL_AUTO, 0);
-  return p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.xlds && p.ksplit == 1;
+  return p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8));
 }
 
 int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const void* const* scales,

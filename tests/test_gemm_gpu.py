@@ -159,7 +159,6 @@ def test_fragment_deferred_zero_matches_exact_kernel(qa, device, M, K, N, G):
     x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=5 * M + K + N)
     want = oracle.w4a16_forward(x, iw, s, z, G).astype(np.float32)
     packed = _pack_dev(iw, s, z, device)
-    assert not K_.can_fuse_rmsnorm(M, K, N, G)          # no x copy, no prologue on this path
     ydz = qa.gemm_forward(_dev(x, device), *packed).cpu().numpy().astype(np.float32)
     yex = qa.gemm_forward(_dev(x, device), *packed, kernel_id=1 << 25).cpu().numpy().astype(np.float32)
     scale = np.abs(want).max()
@@ -420,8 +419,8 @@ def test_decode_glue_kernels_against_torch(qa, device):
         assert (y_res.float() - (y.float() + res.float())).abs().max() <= 2e-2
         y_act = qa.gemm_forward(xd, *packed, silu_mul=True)
         close(y_act, K_.silu_mul(y))
-        assert K_.can_fuse_rmsnorm(M, Kd, N, G) == (M == 1)   # the deferred-zero skinny kernel carries the prologue
-        if M == 1:
+        assert K_.can_fuse_rmsnorm(M, Kd, N, G) == (M != 5)   # deferred-zero launches carry the norm: table (M = 1), fragments (M = 40)
+        if M != 5:
             y_ln = qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw)
             y_two = qa.gemm_forward(K_.rmsnorm(xd, lnw), *packed)
             assert rel_err(y_ln.cpu().numpy(), y_two.cpu().numpy()) <= TOL
@@ -431,10 +430,13 @@ def test_decode_glue_kernels_against_torch(qa, device):
 
 
 @pytest.mark.parametrize("M,K,N,G", [(1, 4096, 12288, 128), (1, 4096, 4096, 128), (8, 4096, 22016, 128), (16, 1024, 12288, 64),
-                                     (3, 11008, 12288, 128)])
+                                     (3, 11008, 12288, 128), (16, 4096, 12288, 128), (8, 4096, 12288, 128), (24, 8192, 4096, 128),
+                                     (16, 8192, 10240, 256)])
 def test_rmsnorm_prologue_matches_two_launches(qa, device, M, K, N, G):
-    """gemm(rmsnorm(x) * w) in one launch: the prologue reproduces quick_rmsnorm_f16's rounding points, so the only
-    difference to the two-launch result is the summation order of the squares (an ulp of the row scale)."""
+    """gemm(rmsnorm(x) * w) in one launch.  Table flavour (x in LDS): the prologue reproduces quick_rmsnorm_f16's rounding
+    points, the only difference to the two-launch result is the summation order of the squares.  Fragment flavour (the
+    last four shapes): x * w in fp16 on the fragments, 1 / rms applied to the fp32 result -- other rounding points, same
+    tolerance."""
     from quick_amd import kernels as K_
     x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + K + N)
     packed = _pack_dev(iw, s, z, device)
