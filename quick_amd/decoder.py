@@ -105,15 +105,18 @@ class SyntheticDecoder:
         return sum(l[k].qweight.numel() * 4 for l in self.layers for k in ("qkv", "o", "gate_up", "down"))
 
     @torch.no_grad()
-    def forward(self, tokens, pos, mask):
+    def forward(self, tokens, pos, mask, hip_glue=True):
         """tokens [B, T] int64; pos int64 [T] (positions being written); mask additive [1, 1, T, max_len] or None for
-        causal prefill from position 0.  Returns the next-token ids [B] (argmax of the last position's logits)."""
+        causal prefill from position 0.  Returns the next-token ids [B] (argmax of the last position's logits).
+        ``hip_glue``: RMSNorm through quick_rmsnorm_f16 and the residual adds / SiLU*mul in the GEMM epilogues (what a
+        prefill wants); False = every op around the GEMMs in eager torch (the arithmetic the tests compare against)."""
         cfg, B, T = self.cfg, tokens.shape[0], tokens.shape[1]
         H, nh, nkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
         x = self.embed[tokens]                                        # [B, T, H]
         cos, sin = self.cos.index_select(0, pos), self.sin.index_select(0, pos)
+        norm = (lambda v, w: kernels.rmsnorm(v.reshape(-1, H), w).view(v.shape)) if hip_glue else _rms_norm
         for l in self.layers:
-            h = _rms_norm(x, l["ln1"])
+            h = norm(x, l["ln1"])
             qkv = l["qkv"](h)                                          # W4A16 GEMM, M = B*T
             q, k, v = qkv.split((H, nkv * D, nkv * D), dim=-1)
             q = _rope(q.view(B, T, nh, D).transpose(1, 2), cos, sin)
@@ -125,13 +128,22 @@ class SyntheticDecoder:
                 att = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=nkv != nh)
             else:
                 att = F.scaled_dot_product_attention(q, l["k"], l["v"], attn_mask=mask, enable_gqa=nkv != nh)
-            x = x + l["o"](att.transpose(1, 2).reshape(B, T, H))       # W4A16 GEMM
-            h = _rms_norm(x, l["ln2"])
+            att = att.transpose(1, 2).reshape(B * T, H)
+            if hip_glue:
+                o, gu, dn = l["o"], l["gate_up"], l["down"]
+                x2 = x.reshape(B * T, H).contiguous()
+                kernels.gemm_forward(att, o.qweight, o.scales, o.qzeros, residual=x2, out=x2)        # x += o(att)
+                act = kernels.gemm_forward(kernels.rmsnorm(x2, l["ln2"]), gu.qweight, gu.scales, gu.qzeros, silu_mul=True)
+                kernels.gemm_forward(act, dn.qweight, dn.scales, dn.qzeros, residual=x2, out=x2)     # x += down(silu(gate) * up)
+                x = x2.view(B, T, H)
+                continue
+            x = x + l["o"](att.view(B, T, H))                          # W4A16 GEMM
+            h = norm(x, l["ln2"])
             gu = l["gate_up"](h).view(B, T, cfg.intermediate // 8, 2, 8)   # W4A16 GEMM, N = 2*intermediate,
             gate = gu[..., 0, :].reshape(B, T, cfg.intermediate)           # gate/up channels interleaved in blocks of 8
             up = gu[..., 1, :].reshape(B, T, cfg.intermediate)
             x = x + l["down"](F.silu(gate) * up)                       # W4A16 GEMM
-        logits = _rms_norm(x[:, -1], self.norm) @ self.lm_head.t()
+        logits = norm(x[:, -1], self.norm) @ self.lm_head.t()
         return logits.argmax(-1)
 
 
