@@ -83,11 +83,7 @@ def main():
                                                               torch.from_numpy(z.astype(np.int32)).to(dev)))]
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     for _ in range(n_sets - 1):
-        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 4, N // 2), dtype=torch.int32, device=dev, generator=gen)
-        sc = torch.zeros((K // G, 2 * N), dtype=torch.float16, device=dev)
-        sc[:, :N] = (torch.rand((K // G, N), device=dev, generator=gen) * 0.02 + 0.005).half()
-        qz = torch.zeros((K // G, N // 4), dtype=torch.int32, device=dev)
-        qz[:, :N // 8] = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // G, N // 8), dtype=torch.int32, device=dev, generator=gen)
+        qw, sc, qz = packing.random_mi355x(K, N, G, dev, gen)
         sets.append((qw, sc, qz))
     arr = lambda i: (ctypes.c_void_p * n_sets)(*[st[i].data_ptr() for st in sets])
     qw_arr, sc_arr, qz_arr = arr(0), arr(1), arr(2)
@@ -204,11 +200,7 @@ def main():
             ns = max(2, -(-(320 << 20) // sb))
             lsets = []
             for _ in range(ns):
-                qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (Kl // 4, Nl // 2), dtype=torch.int32, device=dev, generator=gen)
-                sc = torch.zeros((Kl // G, 2 * Nl), dtype=torch.float16, device=dev)
-                sc[:, :Nl] = (torch.rand((Kl // G, Nl), device=dev, generator=gen) * 0.02 + 0.005).half()
-                qz = torch.zeros((Kl // G, Nl // 4), dtype=torch.int32, device=dev)
-                qz[:, :Nl // 8] = torch.randint(-2 ** 31, 2 ** 31 - 1, (Kl // G, Nl // 8), dtype=torch.int32, device=dev, generator=gen)
+                qw, sc, qz = packing.random_mi355x(Kl, Nl, G, dev, gen)
                 lsets.append((qw, sc, qz))
             larr = lambda i: (ctypes.c_void_p * ns)(*[st[i].data_ptr() for st in lsets])
             xl = (torch.randn((Ml, Kl), device=dev, generator=gen) * 0.5).half()

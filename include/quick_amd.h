@@ -51,8 +51,8 @@ const char* quick_amd_last_error(void);
  * y[M, N] (fp16, row-major) = x[M, K] (fp16, row-major, contiguous) @ dequant(qweight, scales, qzeros)
  *
  *   qweight  int32 [K/4, N/2]   4-bit weights, MI355X order (DESIGN.md "Data layout")
- *   scales   fp16  [K/G, 2N]    scales[g, n] in columns 0..N-1
- *   qzeros   int32 [K/G, N/4]   zero point of (g, n) = nibble n%8 of dword n/8 of row g
+ *   scales   fp16  [K/G, 2N]    as uint32 [K/G * N]: word ((n/16) * (K/G) + g) * 16 + n%16 = fp16 scale | zero point << 16
+ *   qzeros   int32 [K/G, N/4]   plain copy of the zero points (nibble n%8 of dword n/8 of row g); not read by the GEMM
  *
  * Dequantised weight = fp16((w - z) * s) exactly as the reference computes it
  * (csrc/dequantize_quick.cuh:15-63 + sub/mul.rn.f16x2 in csrc/gemm_cuda_quick.cu:52-60);

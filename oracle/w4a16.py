@@ -139,20 +139,32 @@ def _mi355x_weight_index(K: int, N: int):
     return idx + np.zeros_like(k + n), nib + np.zeros_like(k + n)
 
 
+def _mi355x_group_word_index(NG: int, N: int) -> np.ndarray:
+    """32-bit word index of the (scale, zero point) pair of (group g, channel n) inside the scales tensor viewed as
+    uint32 [NG * N]: the pairs of one 16-channel block are contiguous over all groups -- ((n/16) * NG + g) * 16 + n%16."""
+    g = np.arange(NG, dtype=np.int64)[:, None]
+    n = np.arange(N, dtype=np.int64)[None, :]
+    return ((n // 16) * NG + g) * 16 + (n % 16)
+
+
 def pack_mi355x(iw: np.ndarray, s: np.ndarray, z: np.ndarray):
     """(iw, s, z) -> (qweight int32 [K/4, N/2], scales fp16 [K/G, 2N], qzeros int32 [K/G, N/4]).
 
-    scales[g, n] = s[g, n] for n < N (columns N..2N-1 are zero: the reference's duplicate slots are
-    not needed -- v_pk_mul_f16 broadcasts one half via op_sel); qzeros[g, n/8] nibble n%8 = z[g, n]
-    in dwords 0..N/8-1 (dwords N/8..N/4-1 zero).
+    The scales tensor holds one 32-bit word per (group, channel): fp16 scale in the low half, zero point (0..15) in the
+    high half, at word ((n/16) * NG + g) * 16 + n%16 -- the reference's 2N halves per group row are exactly that many
+    bytes (its duplicate slots are not needed on gfx950), so the kernels fetch scale and zero point with one load and the
+    constants of a 16-channel block stream contiguously along K.  qzeros keeps a plain copy (nibble n%8 of dword n/8,
+    dwords N/8..N/4-1 zero) that the GEMM kernels do not read.
     """
     K, N = iw.shape
     NG = s.shape[0]
     assert K % 128 == 0 and N % 16 == 0
     idx, nib = _mi355x_weight_index(K, N)
     qweight = _scatter_nibbles(K * N // 8, idx, nib, iw).view(np.int32).reshape(K // 4, N // 2)
-    qscales = np.zeros((NG, 2 * N), dtype=np.float16)
-    qscales[:, :N] = s
+    words = np.zeros(NG * N, dtype=np.uint32)
+    words[_mi355x_group_word_index(NG, N)] = (np.asarray(s, dtype=np.float16).view(np.uint16).astype(np.uint32)
+                                              | ((np.asarray(z).astype(np.uint32) & 15) << 16))
+    qscales = words.view(np.float16).reshape(NG, 2 * N)
     n = np.arange(N)
     qz = np.zeros((NG, N // 4), dtype=np.uint32)
     np.bitwise_or.at(qz, (np.arange(NG)[:, None], (n // 8)[None, :]),
@@ -165,10 +177,10 @@ def unpack_mi355x(qweight: np.ndarray, qscales: np.ndarray, qzeros: np.ndarray):
     idx, nib = _mi355x_weight_index(K, N)
     flat = np.ascontiguousarray(qweight).view(np.uint32).ravel()
     iw = ((flat[idx] >> (4 * nib).astype(np.uint32)) & 15).astype(np.uint8)
-    s = np.ascontiguousarray(qscales[:, :N]).astype(np.float16)
-    n = np.arange(N)
-    qz = np.ascontiguousarray(qzeros).view(np.uint32)
-    z = ((qz[:, n // 8] >> (4 * (n % 8)).astype(np.uint32)[None, :]) & 15).astype(np.uint8)
+    NG = qscales.shape[0]
+    words = np.ascontiguousarray(qscales).view(np.uint32).ravel()[_mi355x_group_word_index(NG, N)]
+    s = (words & 0xffff).astype(np.uint16).view(np.float16)
+    z = ((words >> 16) & 15).astype(np.uint8)
     return iw, s, z
 
 

@@ -66,32 +66,35 @@ __global__ __launch_bounds__(256) void repack_weight_mi355x_to_cuda(const uint32
   atomicOr(out + idx, w << (4 * nib));
 }
 
-// scales / zeros: one thread per (g, n)
+// scales / zeros: one thread per (g, n).  MI355X order: the scales tensor holds one 32-bit word per (g, n) -- fp16 scale |
+// zero point << 16 -- at word ((n/16) * NG + g) * 16 + n%16 (group_word_index, w4a16_common.hpp); qzeros keeps a plain
+// copy of the zero points (nibble n%8 of dword n/8) that the GEMM kernels do not read.
 __global__ __launch_bounds__(256) void repack_sz_cuda_to_mi355x(const half_t* __restrict__ s_in,
                                                                 const uint32_t* __restrict__ z_in,
-                                                                half_t* __restrict__ s_out, uint32_t* __restrict__ z_out,
+                                                                uint32_t* __restrict__ sz_out, uint32_t* __restrict__ z_out,
                                                                 int NG, int N) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)NG * N) return;
   const int g = (int)(i / N), n = (int)(i % N);
   const int x = cuda_order_slot(n, N);
-  s_out[(size_t)g * 2 * N + n] = s_in[(size_t)g * 2 * N + 2 * x];
   const uint32_t z = (z_in[(size_t)g * (N >> 2) + (x >> 2)] >> (4 * (x & 3))) & 15u;
+  const uint32_t sbits = __builtin_bit_cast(unsigned short, s_in[(size_t)g * 2 * N + 2 * x]);
+  sz_out[group_word_index(g, n, NG)] = sbits | (z << 16);
   atomicOr(z_out + (size_t)g * (N >> 2) + (n >> 3), z << (4 * (n & 7)));
 }
 
-__global__ __launch_bounds__(256) void repack_sz_mi355x_to_cuda(const half_t* __restrict__ s_in,
-                                                                const uint32_t* __restrict__ z_in,
+__global__ __launch_bounds__(256) void repack_sz_mi355x_to_cuda(const uint32_t* __restrict__ sz_in,
                                                                 half_t* __restrict__ s_out, uint32_t* __restrict__ z_out,
                                                                 int NG, int N) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)NG * N) return;
   const int g = (int)(i / N), n = (int)(i % N);
   const int x = cuda_order_slot(n, N);
-  const half_t s = s_in[(size_t)g * 2 * N + n];
+  const uint32_t w = sz_in[group_word_index(g, n, NG)];
+  const half_t s = __builtin_bit_cast(half_t, (unsigned short)(w & 0xffffu));
   s_out[(size_t)g * 2 * N + 2 * x] = s;
   s_out[(size_t)g * 2 * N + 2 * x + 1] = s;
-  const uint32_t z = (z_in[(size_t)g * (N >> 2) + (n >> 3)] >> (4 * (n & 7))) & 15u;
+  const uint32_t z = (w >> 16) & 15u;
   atomicOr(z_out + (size_t)g * (N >> 2) + (x >> 2), (z << (4 * (x & 3))) | (z << (4 * (x & 3) + 16)));
 }
 
@@ -113,12 +116,11 @@ int quick_repack_cuda_to_mi355x(const void* qweight_in, const void* scales_in, c
   hipStream_t st = (hipStream_t)hip_stream;
   const int NG = K / group_size;
   const size_t nd = (size_t)K * N / 8;
-  if (hipMemsetAsync(scales_out, 0, (size_t)NG * 2 * N * sizeof(half_t), st) != hipSuccess) return QUICK_ERR_LAUNCH;
   if (hipMemsetAsync(qzeros_out, 0, (size_t)NG * (N / 4) * 4, st) != hipSuccess) return QUICK_ERR_LAUNCH;
   hipLaunchKernelGGL(repack_weight_cuda_to_mi355x, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st,
                      (const uint32_t*)qweight_in, (uint32_t*)qweight_out, K, N);
   hipLaunchKernelGGL(repack_sz_cuda_to_mi355x, dim3((unsigned)(((size_t)NG * N + 255) / 256)), dim3(256), 0, st,
-                     (const half_t*)scales_in, (const uint32_t*)qzeros_in, (half_t*)scales_out, (uint32_t*)qzeros_out, NG, N);
+                     (const half_t*)scales_in, (const uint32_t*)qzeros_in, (uint32_t*)scales_out, (uint32_t*)qzeros_out, NG, N);
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
 }
 
@@ -131,8 +133,9 @@ int quick_repack_mi355x_to_cuda(const void* qweight_in, const void* scales_in, c
   if (hipMemsetAsync(qzeros_out, 0, (size_t)NG * (N / 4) * 4, st) != hipSuccess) return QUICK_ERR_LAUNCH;
   hipLaunchKernelGGL(repack_weight_mi355x_to_cuda, dim3((unsigned)(((size_t)K * N + 255) / 256)), dim3(256), 0, st,
                      (const uint32_t*)qweight_in, (uint32_t*)qweight_out, K, N);
+  (void)qzeros_in;  // the zero points travel in the scales tensor's words
   hipLaunchKernelGGL(repack_sz_mi355x_to_cuda, dim3((unsigned)(((size_t)NG * N + 255) / 256)), dim3(256), 0, st,
-                     (const half_t*)scales_in, (const uint32_t*)qzeros_in, (half_t*)scales_out, (uint32_t*)qzeros_out, NG, N);
+                     (const uint32_t*)scales_in, (half_t*)scales_out, (uint32_t*)qzeros_out, NG, N);
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
 }
 

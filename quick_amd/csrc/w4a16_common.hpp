@@ -93,23 +93,23 @@ __device__ __forceinline__ float lanes_sum(float v) {
   return v;
 }
 
-// Raw group constants as they come out of memory; make_group() is applied at the point of use so that a
-// prefetch of the next k-tile's constants carries no dependent ALU work (which would make the compiler
-// wait for the whole in-order load queue right after issuing it).  Both are plain dword loads: the
-// scale dword holds the scales of channels (n & ~1, n | 1), the zero dword the nibbles of 8 channels.
+// Group constants as they come out of memory: ONE 32-bit word per (group, channel) -- fp16 scale in the low half, zero
+// point (0..15) in the high half -- that a lane fetches for its own channel with a plain dword load.  make_group() is
+// applied at the point of use so that a prefetch of the next k-tile's constants carries no dependent ALU work (which would
+// make the compiler wait for the whole in-order load queue right after issuing it).
 struct GroupRaw {
-  uint32_t s2;  // two fp16 scales, this lane's one selected by LaneSel::sperm
-  uint32_t zq;  // eight zero points, this lane's one selected by LaneSel::zshift
+  uint32_t sz;
 };
 
-// lane constants that pick this lane's channel out of a GroupRaw
-struct LaneSel {
-  uint32_t sperm;   // v_perm_b32 selector replicating the low (even n) or high (odd n) half
-  uint32_t zshift;  // 4 * (n % 8)
-};
-__device__ __forceinline__ LaneSel lane_sel(int n) {
-  return LaneSel{(n & 1) ? 0x03020302u : 0x01000100u, 4u * (uint32_t)(n & 7)};
+// word index of (g, n) in the scales tensor viewed as uint32 [NG * N]: the words of a 16-channel block are contiguous
+// over all groups, so a wave walking along K for fixed channels streams them (64 B per group) next to its weights
+__host__ __device__ __forceinline__ size_t group_word_index(int g, int n, int NG) {
+  return ((size_t)(n >> 4) * NG + g) * 16 + (n & 15);
 }
+
+// kept for the call sites' sake: nothing lane-dependent is needed to pick a lane's constants any more
+struct LaneSel {};
+__device__ __forceinline__ LaneSel lane_sel(int) { return LaneSel{}; }
 
 // group index of k-step t of 128-k tile kt.  GM: 0 -> G == 128, 1 -> G % 128 == 0 (tpg = G / 128),
 // 2 -> G == 64, 3 -> G == 32, 4 -> any other multiple of 32 (runtime division).
@@ -127,19 +127,18 @@ constexpr int groups_per_tile() { return GM <= 1 ? 1 : (GM == 2 ? 2 : 4); }
 template <int GM>
 __device__ __forceinline__ int group_slot(int t) { return GM <= 1 ? 0 : (GM == 2 ? (t >> 1) : t); }
 
-// scales[g, n] (fp16, row pitch 2N) and the zero-point dword of (g, n) (row pitch N/4 dwords).
-__device__ __forceinline__ GroupRaw load_group_raw(const half_t* __restrict__ S, const uint32_t* __restrict__ QZ,
-                                                   int g, int n, int N) {
-  GroupRaw r;
-  r.s2 = *(const uint32_t*)(S + (size_t)g * (2 * N) + (n & ~1));
-  r.zq = QZ[(size_t)g * (N >> 2) + (n >> 3)];
-  return r;
+__device__ __forceinline__ GroupRaw load_group_raw(const half_t* __restrict__ S, const uint32_t* __restrict__ /*QZ*/,
+                                                   int g, int n, int N, int NG) {
+  (void)N;
+  return GroupRaw{((const uint32_t*)S)[group_word_index(g, n, NG)]};
 }
-// 5 VALU: v_perm (scale pair), v_bfe (zero point), v_lshl_or (replicate), 2 v_or (bias constants)
-__device__ __forceinline__ GroupQ make_group(const GroupRaw& r, const LaneSel& ls) {
+__device__ __forceinline__ float group_scale_f32(const GroupRaw& r) { return (float)as_h2(r.sz)[0]; }
+__device__ __forceinline__ float group_zero_f32(const GroupRaw& r) { return (float)(r.sz >> 16); }
+// 4 VALU: v_perm (scale pair), v_lshrrev + v_lshl_or (zero point twice), 2 v_or (bias constants) -- minus what hipcc folds
+__device__ __forceinline__ GroupQ make_group(const GroupRaw& r, const LaneSel&) {
   GroupQ g;
-  g.s2 = as_h2(__builtin_amdgcn_perm(r.s2, r.s2, ls.sperm));
-  const uint32_t z = __builtin_amdgcn_ubfe(r.zq, ls.zshift, 4u);
+  g.s2 = as_h2(__builtin_amdgcn_perm(r.sz, r.sz, 0x01000100u));
+  const uint32_t z = r.sz >> 16;
   const uint32_t zz = z | (z << 16);
   g.nzlo = as_h2(0xE400E400u | zz);
   g.nzhi = as_h2(0xD400D400u | (zz << 4));

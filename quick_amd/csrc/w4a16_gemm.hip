@@ -107,23 +107,20 @@ struct SkinnyChunk {
 // constant VGPR) + a wave-uniform byte offset in an SGPR -- no 64-bit address arithmetic per load (it was ~28 scalar and
 // ~10 vector instructions per 1 KiB weight tile).  Offsets are 32-bit: tensors up to 4 GiB.
 struct SkinnyBufs {
-  __amdgpu_buffer_rsrc_t w, s, z;
-  unsigned w_voff, s_voff, z_voff;  // lane * 16;  2 * (n16 & ~1);  4 * (n16 >> 3)
-  unsigned wstride_bytes;           // between consecutive channel tiles
-  unsigned s_row, z_row;            // bytes per group row of scales / zeros
+  __amdgpu_buffer_rsrc_t w, s;
+  unsigned w_voff, s_voff;  // lane * 16;  4 * n16 (this lane's channel within its 16-channel block)
+  unsigned wstride_bytes;   // between consecutive channel tiles of the weights
+  unsigned sstride_bytes;   // between consecutive channel tiles of the (scale, zero point) words: groups * 64
 };
 __device__ __forceinline__ SkinnyBufs skinny_bufs(const GemmArgs& a, int lane) {
   SkinnyBufs b;
   const unsigned groups = (unsigned)(a.K / a.G);
   b.w = __builtin_amdgcn_make_buffer_rsrc((void*)a.QW, 0, (unsigned)((size_t)a.K * a.N / 2), 0x00020000);
   b.s = __builtin_amdgcn_make_buffer_rsrc((void*)a.S, 0, groups * (unsigned)a.N * 4u, 0x00020000);
-  b.z = __builtin_amdgcn_make_buffer_rsrc((void*)a.QZ, 0, groups * (unsigned)a.N, 0x00020000);
   b.w_voff = (unsigned)lane * 16u;
-  b.s_voff = 2u * (unsigned)(lane & 14);
-  b.z_voff = 4u * (unsigned)((lane & 15) >> 3);
+  b.s_voff = 4u * (unsigned)(lane & 15);
   b.wstride_bytes = (unsigned)(a.K >> 7) * 1024u;
-  b.s_row = (unsigned)a.N * 4u;
-  b.z_row = (unsigned)a.N;
+  b.sstride_bytes = groups * 64u;
   return b;
 }
 
@@ -144,8 +141,7 @@ __device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS, LN>& c
 #pragma unroll
       for (int i = 0; i < NG; ++i) {
         const unsigned g = (unsigned)group_index<GM>(min(kt + u, kt_last), i * (4 / NG), a.tpg, a.G);
-        c.raw[u][j][i].s2 = __builtin_amdgcn_raw_buffer_load_b32(b.s, b.s_voff, g * b.s_row + (unsigned)(cb + j) * 32u, 0);
-        c.raw[u][j][i].zq = __builtin_amdgcn_raw_buffer_load_b32(b.z, b.z_voff, g * b.z_row + (unsigned)(cb + j) * 8u, 0);
+        c.raw[u][j][i].sz = __builtin_amdgcn_raw_buffer_load_b32(b.s, b.s_voff, (unsigned)(cb + j) * b.sstride_bytes + g * 64u, 0);
       }
   if constexpr (!XLDS) {
 #pragma unroll
@@ -188,7 +184,7 @@ __device__ __forceinline__ void skinny_compute(const SkinnyChunk<NTW, GM, U, XLD
       for (int j = 0; j < NTW; ++j) {
         asm volatile("" ::"v"(c.w[u][j]));
 #pragma unroll
-        for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(c.raw[u][j][i].s2), "v"(c.raw[u][j][i].zq));
+        for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(c.raw[u][j][i].sz));
       }
       if constexpr (!XLDS) {
 #pragma unroll
@@ -234,8 +230,7 @@ __device__ __forceinline__ void skinny_compute_dz(const SkinnyChunk<NTW, GM, U, 
         }
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-          const float s = (float)as_h2(__builtin_amdgcn_perm(c.raw[u][j][i].s2, c.raw[u][j][i].s2, ls.sperm))[0];
-          const float z = (float)__builtin_amdgcn_ubfe(c.raw[u][j][i].zq, ls.zshift, 4u);
+          const float s = group_scale_f32(c.raw[u][j][i]), z = group_zero_f32(c.raw[u][j][i]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-z, xa[r], g[j][r]), acc[j][r]);
         }
@@ -245,7 +240,7 @@ __device__ __forceinline__ void skinny_compute_dz(const SkinnyChunk<NTW, GM, U, 
       for (int j = 0; j < NTW; ++j) {
         asm volatile("" ::"v"(c.w[u][j]));
 #pragma unroll
-        for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(c.raw[u][j][i].s2), "v"(c.raw[u][j][i].zq));
+        for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(c.raw[u][j][i].sz));
       }
     }
   }
@@ -302,8 +297,7 @@ __device__ __forceinline__ void skinny_compute_dzf(const SkinnyChunk<NTW, GM, U,
           floatx4 g = nc;
 #pragma unroll
           for (int t = i * TPU; t < (i + 1) * TPU; ++t) g = mfma16(xs[t], biased8(c.w[u][j][t]), g);
-          const float s = (float)as_h2(__builtin_amdgcn_perm(c.raw[u][j][i].s2, c.raw[u][j][i].s2, ls.sperm))[0];
-          const float z = (float)__builtin_amdgcn_ubfe(c.raw[u][j][i].zq, ls.zshift, 4u);
+          const float s = group_scale_f32(c.raw[u][j][i]), z = group_zero_f32(c.raw[u][j][i]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[j][r] = __builtin_fmaf(s, __builtin_fmaf(-z, xa[r], g[r]), acc[j][r]);
         }
@@ -313,7 +307,7 @@ __device__ __forceinline__ void skinny_compute_dzf(const SkinnyChunk<NTW, GM, U,
       for (int j = 0; j < NTW; ++j) {
         asm volatile("" ::"v"(c.w[u][j]));
 #pragma unroll
-        for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(c.raw[u][j][i].s2), "v"(c.raw[u][j][i].zq));
+        for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(c.raw[u][j][i].sz));
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(c.xf[u][t]));
@@ -689,9 +683,9 @@ __device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN, WK, WN>& c,
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
       const int g = group_index<GM>(kt, i * (4 / NG), a.tpg, a.G);
-      const GroupRaw r = load_group_raw(a.S, a.QZ, g, c.ncol[j], a.N);
-      gs[j][i] = r.s2;
-      gz[j][i] = r.zq;
+      const GroupRaw r = load_group_raw(a.S, a.QZ, g, c.ncol[j], a.N, a.K / a.G);
+      gs[j][i] = r.sz;
+      gz[j][i] = 0;  // (the zero point travels in the same word; the second array is kept for the call sites and folds away)
     }
   }
 }
@@ -709,7 +703,7 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK, WN>& c
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < NG; ++i) grp[j][i] = make_group(GroupRaw{gs[j][i], gz[j][i]}, lane_sel(c.ncol[j]));
+    for (int i = 0; i < NG; ++i) grp[j][i] = make_group(GroupRaw{gs[j][i]}, lane_sel(c.ncol[j]));
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     half8_t bf[BMT];
@@ -981,7 +975,7 @@ __device__ __forceinline__ void tiled32_compute(const TiledCtx<BMT, TN, WK>& c, 
   for (int p = 0; p < TN / 2; ++p)
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-      const GroupRaw r{second ? gs[2 * p + 1][i] : gs[2 * p][i], second ? gz[2 * p + 1][i] : gz[2 * p][i]};
+      const GroupRaw r{second ? gs[2 * p + 1][i] : gs[2 * p][i]};
       grp[p][i] = make_group(r, lane_sel(c.ncol[2 * p]));  // n%8 and n%2 are the same for both tiles of a pair
     }
 #pragma unroll
@@ -1205,7 +1199,7 @@ __global__ __launch_bounds__(64) void w4a16_dequant_kernel(const u32x4* __restri
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int k0 = kt * 128 + 32 * t + 8 * q;
-    const GroupQ g = make_group(load_group_raw(S, QZ, k0 / G, n, N), lane_sel(n));
+    const GroupQ g = make_group(load_group_raw(S, QZ, k0 / G, n, N, K / G), lane_sel(n));
     const half8_t af = dequant8(w[t], g);
 #pragma unroll
     for (int j = 0; j < 8; ++j) W[(size_t)(k0 + j) * N + n] = af[j];

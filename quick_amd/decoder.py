@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from . import kernels
+from . import packing
 from .linear import WQLinear_QUICK
 
 
@@ -49,11 +50,7 @@ CONFIGS = {
 def random_wqlinear(K, N, G, device, gen):
     """A WQLinear_QUICK whose buffers are random bits already in MI355X order (timing only)."""
     m = WQLinear_QUICK(4, G, K, N, False, device)
-    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 4, N // 2), dtype=torch.int32, device=device, generator=gen)
-    sc = torch.zeros((K // G, 2 * N), dtype=torch.float16, device=device)
-    sc[:, :N] = (torch.rand((K // G, N), device=device, generator=gen) * 0.004 + 0.001).half()
-    qz = torch.zeros((K // G, N // 4), dtype=torch.int32, device=device)
-    qz[:, :N // 8] = 0x88888888 - 2 ** 32        # zero point 8 everywhere: weights centred on 0
+    qw, sc, qz = packing.random_mi355x(K, N, G, device, gen, zero_point=8, scale_lo=0.001, scale_span=0.004)  # weights centred on 0
     m._set_packed(qw, sc, qz, prepared=True)
     return m
 

@@ -115,16 +115,27 @@ def unpack_cuda_order(qweight, qscales, qzeros):
     return iw, s, z
 
 
+def _mi355x_group_word_pos(NG, N, dev):
+    """32-bit word of the (scale, zero point) pair of (g, n) in the scales tensor viewed as int32 [NG * N]."""
+    g = _arange(NG, dev)[:, None]
+    n = _arange(N, dev)[None, :]
+    return ((n // 16) * NG + g) * 16 + (n % 16)
+
+
 def pack_mi355x(iw, s, z):
-    """-> (qweight, scales, qzeros) in MI355X order (same shapes / dtypes as the reference buffers)."""
+    """-> (qweight, scales, qzeros) in MI355X order (same shapes / dtypes as the reference buffers).  The scales tensor
+    carries one 32-bit word per (group, channel) -- fp16 scale | zero point << 16 -- block-contiguous along K; qzeros
+    keeps a plain copy of the zero points that the GEMM kernels do not read (oracle/w4a16.py::pack_mi355x)."""
     K, N = iw.shape
     _check(K, N, True)
     dev = iw.device
     idx, nib = _mi355x_weight_pos(K, N, dev)
     qweight = _scatter_nibbles(K * N // 8, idx, nib, iw).reshape(K // 4, N // 2)
     NG = s.shape[0]
-    qscales = torch.zeros((NG, 2 * N), dtype=torch.float16, device=dev)
-    qscales[:, :N] = s.to(torch.float16)
+    sbits = s.to(torch.float16).contiguous().view(torch.int16).to(torch.int64) & 0xffff
+    words = torch.zeros(NG * N, dtype=torch.int64, device=dev)
+    words[_mi355x_group_word_pos(NG, N, dev).reshape(-1)] = (sbits | ((z.to(torch.int64) & 15) << 16)).reshape(-1)
+    qscales = _to_i32(words).view(torch.float16).reshape(NG, 2 * N)
     n = _arange(N, dev)
     qz = torch.zeros((NG, N // 4), dtype=torch.int64, device=dev)
     qz.scatter_add_(1, (n // 8)[None, :].expand(NG, N), (z.to(torch.int64) & 15) << (4 * (n % 8))[None, :])
@@ -138,10 +149,30 @@ def unpack_mi355x(qweight, qscales, qzeros):
     idx, nib = _mi355x_weight_pos(K, N, dev)
     flat = _as_u32(qweight.reshape(-1))
     iw = ((flat[idx] >> (4 * nib)) & 15).to(torch.uint8)
-    s = qscales[:, :N].contiguous()
-    n = _arange(N, dev)
-    z = ((_as_u32(qzeros)[:, n // 8] >> (4 * (n % 8))[None, :]) & 15).to(torch.uint8)
+    NG = qscales.shape[0]
+    words = _as_u32(qscales.contiguous().view(torch.int32).reshape(-1))[_mi355x_group_word_pos(NG, N, dev)]
+    s = (words & 0xffff).to(torch.int32).to(torch.int16).view(torch.float16)
+    z = ((words >> 16) & 15).to(torch.uint8)
     return iw, s, z
+
+
+def random_mi355x(K, N, G, device, generator=None, zero_point=None, scale_lo=0.005, scale_span=0.02):
+    """Random packed tensors in MI355X order (benchmarks, synthetic models): uniform 4-bit weights, scales in
+    [scale_lo, scale_lo + scale_span), zero points uniform in 0..15 or the given constant."""
+    NG = K // G
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 4, N // 2), dtype=torch.int32, device=device, generator=generator)
+    s = (torch.rand((NG, N), device=device, generator=generator) * scale_span + scale_lo).half()
+    if zero_point is None:
+        z = torch.randint(0, 16, (NG, N), dtype=torch.int64, device=device, generator=generator)
+    else:
+        z = torch.full((NG, N), int(zero_point), dtype=torch.int64, device=device)
+    sbits = s.view(torch.int16).to(torch.int64) & 0xffff
+    words = torch.zeros(NG * N, dtype=torch.int64, device=device)
+    words[_mi355x_group_word_pos(NG, N, device).reshape(-1)] = (sbits | (z << 16)).reshape(-1)
+    n = _arange(N, device)
+    qz = torch.zeros((NG, N // 4), dtype=torch.int64, device=device)
+    qz.scatter_add_(1, (n // 8)[None, :].expand(NG, N), z << (4 * (n % 8))[None, :])
+    return qw, _to_i32(words).view(torch.float16).reshape(NG, 2 * N), _to_i32(qz)
 
 
 def cuda_to_mi355x(qweight, qscales, qzeros):

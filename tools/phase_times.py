@@ -7,9 +7,8 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 M, K, N, G = 512, 4096, 4096, 128
 x = torch.randn(M, K, device=dev).half()
-qw = torch.randint(-2**31, 2**31 - 1, (K // 4, N // 2), dtype=torch.int32, device=dev)
-sc = torch.rand(K // G, 2 * N, device=dev).half() * 0.02 + 0.005
-qz = torch.randint(-2**31, 2**31 - 1, (K // G, N // 4), dtype=torch.int32, device=dev)
+from quick_amd import packing
+qw, sc, qz = packing.random_mi355x(K, N, G, dev)
 y = torch.empty(M, N, dtype=torch.float16, device=dev)
 ws = torch.zeros(4096 * 8 * 64 // 8, dtype=torch.int64, device=dev)
 kid = 2 + ((16 + (int(sys.argv[1]) if len(sys.argv) > 1 else 0)) << 16)

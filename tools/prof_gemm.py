@@ -13,16 +13,13 @@ ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--sets", type=int, default=38)
 a = ap.parse_args()
 import quick_amd
+from quick_amd import packing
 dev = torch.device("cuda:0")
 K, N, G = a.K, a.N, a.G
 gen = torch.Generator(device=dev).manual_seed(1)
 sets = []
 for _ in range(a.sets):
-    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 4, N // 2), dtype=torch.int32, device=dev, generator=gen)
-    sc = torch.zeros((K // G, 2 * N), dtype=torch.float16, device=dev)
-    sc[:, :N] = (torch.rand((K // G, N), device=dev, generator=gen) * 0.02 + 0.005).half()
-    qz = torch.zeros((K // G, N // 4), dtype=torch.int32, device=dev)
-    qz[:, :N // 8] = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // G, N // 8), dtype=torch.int32, device=dev, generator=gen)
+    qw, sc, qz = packing.random_mi355x(K, N, G, dev, gen)
     sets.append((qw, sc, qz))
 for M in a.M:
     x = torch.randn(M, K, device=dev, generator=gen).half()
