@@ -409,10 +409,11 @@ template <int GROUP, int UNR>
 __global__ __launch_bounds__(256, 2) void decode_rope_attention_gqa_kernel(
     const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t, const half_t* __restrict__ sin_t,
     const long* __restrict__ pos, half_t* __restrict__ k_cache, half_t* __restrict__ v_cache, half_t* __restrict__ out,
-    int nh, int nkv, int L, float scale) {
+    int nh, int nkv, int L, float scale, int gsplit) {
   constexpr int D = 128;
   __shared__ float part[4][GROUP][D + 2];  // per wave and query head: 128 output dims, running max, running sum
-  const int b = blockIdx.y, kvh = blockIdx.x;
+  // gsplit workgroups share a KV head, GROUP query heads each (8 heads per KV head = 2 x 4: the 8-head instantiation spills)
+  const int b = blockIdx.y, kvh = blockIdx.x / gsplit, hbase = kvh * (GROUP * gsplit) + (blockIdx.x % gsplit) * GROUP;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & 15, rsel = lane >> 4;
   const half_t* row = qkv + (size_t)b * (nh + 2 * nkv) * D;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void decode_rope_attention_gqa_kernel(
   const half_t* vp = v_cache + ((size_t)b * nkv + kvh) * L * D + sub * 8;
   half8_t qraw[GROUP];
 #pragma unroll
-  for (int g = 0; g < GROUP; ++g) qraw[g] = *(const half8_t*)(row + (size_t)(kvh * GROUP + g) * D + sub * 8);
+  for (int g = 0; g < GROUP; ++g) qraw[g] = *(const half8_t*)(row + (size_t)(hbase + g) * D + sub * 8);
   const half8_t kraw = *(const half8_t*)(row + (size_t)(nh + kvh) * D + sub * 8);
   const half8_t vn = *(const half8_t*)(row + (size_t)(nh + nkv + kvh) * D + sub * 8);
   const int p = (int)pos[0];  // cache rows 0..p-1 are attended from memory, row p (this token) from registers
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void decode_rope_attention_gqa_kernel(
           qr[g][j] = (float)(half_t)((float)(half_t)(qj * (float)cs[j]) + (float)(half_t)(sign * qp * (float)sn[j])) * (scale * LOG2E);
         }
       }
-      if (threadIdx.x < 16) {  // append to the caches (position p is not read by anyone in this launch)
+      if (threadIdx.x < 16 && blockIdx.x % gsplit == 0) {  // append to the caches (position p is not read in this launch)
         half8_t kh;
 #pragma unroll
         for (int j = 0; j < 8; ++j) kh[j] = (half_t)kr[j];
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void decode_rope_attention_gqa_kernel(
       num += part[w][g][dd] * f;
       den += part[w][g][D + 1] * f;
     }
-    out[((size_t)b * nh + kvh * GROUP + g) * D + dd] = (half_t)(num / den);
+    out[((size_t)b * nh + hbase + g) * D + dd] = (half_t)(num / den);
   }
 }
 
@@ -611,19 +612,19 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
   if (batch <= 0 || head_dim != 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_UNSUPPORTED;
   const size_t lds = (((size_t)cache_len + 3) & ~(size_t)3) * 4 + 4 * 128 * 4 + 128 * 4;
   if (lds > 64 * 1024) return QUICK_ERR_UNSUPPORTED;
-#define QA_GQA(GROUP, UNR)                                                                                         \
-  hipLaunchKernelGGL((decode_rope_attention_gqa_kernel<GROUP, UNR>), dim3(n_kv_heads, batch), dim3(256), 0,        \
+#define QA_GQA(GROUP, UNR, GSPLIT)                                                                                 \
+  hipLaunchKernelGGL((decode_rope_attention_gqa_kernel<GROUP, UNR>), dim3(n_kv_heads * (GSPLIT), batch), dim3(256), 0, \
                      (hipStream_t)hip_stream, (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, \
                      (const long*)pos, (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads,       \
-                     cache_len, scale)
+                     cache_len, scale, GSPLIT)
   // grouped-query models with enough (sequence, KV head) pairs to fill the chip: one sweep over the cache per KV head
-  const int group = n_heads / n_kv_heads;
   // (measured [r01]: 32 query / 8 KV heads, bs=64, 190 positions: 21.5 us against 32.6 us with a workgroup per query head;
-  // with fewer than ~256 workgroups -- or 8 heads per group below ~512 -- the per-head kernels are ahead)
-  if (group > 1 && (group == 2 || group == 4 || group == 8) && batch * n_kv_heads >= (group == 8 ? 512 : 256)) {
-    if (group == 2) QA_GQA(2, 8);
-    else if (group == 4) QA_GQA(4, 8);
-    else QA_GQA(8, 4);
+  // with fewer than ~256 workgroups the per-head kernels are ahead).  8 heads per KV head run as two workgroups of 4.
+  const int group = n_heads / n_kv_heads;
+  if (group > 1 && (group == 2 || group == 4 || group == 8) && batch * n_kv_heads * (group == 8 ? 2 : 1) >= 256) {
+    if (group == 2) QA_GQA(2, 8, 1);
+    else if (group == 4) QA_GQA(4, 8, 1);
+    else QA_GQA(4, 8, 2);
     return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
   }
 #undef QA_GQA
