@@ -621,11 +621,15 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
   // (measured [r01]: 32 query / 8 KV heads, bs=64, 190 positions: 21.5 us against 32.6 us with a workgroup per query head;
   // with fewer than ~256 workgroups the per-head kernels are ahead).  8 heads per KV head run as two workgroups of 4.
   const int group = n_heads / n_kv_heads;
-  if (group > 1 && (group == 2 || group == 4 || group == 8) && batch * n_kv_heads * (group == 8 ? 2 : 1) >= 256) {
-    if (group == 2) QA_GQA(2, 8, 1);
-    else if (group == 4) QA_GQA(4, 8, 1);
-    else QA_GQA(4, 8, 2);
-    return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+  if (group == 2 || group == 4 || group == 8) {
+    const int pairs = batch * n_kv_heads;
+    bool done = true;
+    if (group == 8 && pairs * 2 >= 256) QA_GQA(4, 8, 2);
+    else if (group == 4 && pairs >= 256) QA_GQA(4, 8, 1);
+    else if (group == 4 && pairs * 2 >= 256) QA_GQA(2, 8, 2);  // fewer sequences: two workgroups of 2 heads per KV head
+    else if (group == 2 && pairs >= 256) QA_GQA(2, 8, 1);
+    else done = false;
+    if (done) return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
   }
 #undef QA_GQA
   // single-pass kernel while the launch is latency-bound (+8 % decode tok/s at bs=1, +5 % at bs=8 [r01]); from ~1000
