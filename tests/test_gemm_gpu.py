@@ -99,7 +99,7 @@ SHAPES = [  # (M, K, N, G)
     (1, 128, 128, 128), (1, 512, 256, 128), (2, 512, 256, 32), (7, 1024, 384, 64), (8, 1024, 128, 128),
     (16, 2048, 256, 128), (17, 512, 256, 128), (31, 1024, 384, 128), (33, 512, 128, 64), (64, 1024, 256, 128),
     (65, 512, 256, 128), (100, 640, 384, 32), (128, 1024, 256, 128), (129, 256, 128, 128), (200, 512, 640, 128),
-    (300, 384, 256, 128), (3, 1024, 256, 1024), (40, 512, 256, 256),
+    (300, 384, 256, 128), (3, 1024, 256, 1024), (40, 512, 256, 256), (2048, 256, 256, 128), (4100, 128, 128, 128),
 ]
 
 
