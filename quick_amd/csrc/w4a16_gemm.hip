@@ -1232,6 +1232,7 @@ struct Plan {
   int ablate;  // kernel bits 16-20: ablation variant of the tiled kernel (timing experiments only)
   int xcd_gm;  // tiled: rows of the XCD grid over the tile grid (0 = plain order)
   bool wn2;    // tiled: 2 x 4 wave grid (kernel bit 15)
+  int tch;     // tiled: channels per workgroup tile, 128 or 256
   bool mfma32; // tiled: v_mfma_f32_32x32x16_f16 flavour (kernel bit 13; measured slower than 16x16x32 in r01)
 };
 
@@ -1314,8 +1315,14 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     // 32-token tiles once 64-token tiles would need a 4-way K split to cover the CUs (twice the tiles, half the slices
     // to reduce): M = 65..128 at N = 4096, 15.5 us instead of 16.5 us at M = 128 [r01]
     if (!mt_req && p.mt == 4 && (N / 128) * ((M + 63) / 64) * 4 <= 256 && (KT + wk - 1) / wk >= 8) p.mt = 2;
-    p.ntiles = (N / 128) * ((M + p.mt * 16 - 1) / (p.mt * 16));
-    p.slab_floats = (size_t)4 * 2 * p.mt * 256;
+    // 256-channel tiles (4 channel tiles per wave: one LDS fragment read per four MFMAs instead of two, half the x traffic)
+    // once they still cover the 256 CUs: M = 1024 at N = 4096 59 -> 50 us, M = 8192 x 22016 772 -> 845 TFLOP/s [r01].
+    // Kernel bit 29 forces them, bit 30 forbids them.
+    const bool wide_ok = p.mt == 4 && p.waves == 8 && !p.wn2 && !p.mfma32 && !p.ablate && N % 256 == 0 && !mt_req;
+    const bool wide = ((kernel >> 29) & 1) || (!((kernel >> 30) & 1) && (N / 256) * ((M + 63) / 64) >= 256);
+    p.tch = wide_ok && wide ? 256 : 128;
+    p.ntiles = (N / p.tch) * ((M + p.mt * 16 - 1) / (p.mt * 16));
+    p.slab_floats = (size_t)(p.tch / 16) * p.mt * 256;
     // one workgroup per CU: split K until the 256 CUs are covered, keeping >= 2 stages per slice
     const int nstage = (KT + wk - 1) / wk;
     while (p.ntiles * ks * 2 <= 256 && nstage / (ks * 2) >= 2) ks *= 2;
@@ -1323,7 +1330,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     p.kt_per_split = ((nstage + p.ksplit - 1) / p.ksplit) * wk;  // whole stages
     // XCD-aware tile order: minimise what each XCD's L2 has to fetch, (MB/gm) token blocks of 4*BMT*K bytes plus
     // (NB*gm/8) channel blocks of 64*K bytes
-    const int MBk = (M + p.mt * 16 - 1) / (p.mt * 16), NBk = N / 128;
+    const int MBk = (M + p.mt * 16 - 1) / (p.mt * 16), NBk = N / p.tch;
     long best = -1;
     if (!((kernel >> 14) & 1) && (MBk * NBk) % 8 == 0)
       for (int gm = 1; gm <= 8; gm *= 2) {
@@ -1456,10 +1463,10 @@ static void launch_skinny(const Plan& p, const GemmArgs& a, const Launch& L) {
   }
 }
 
-template <int BMT, int WK, int WN = 4>
+template <int BMT, int WK, int WN = 4, int TCH = 128>
 static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
-  constexpr int TN = 8 / WN;  // 128 channels per workgroup either way
-  dim3 grid((a.N / 128) * ((a.M + BMT * 16 - 1) / (BMT * 16)), p.ksplit), block(64 * WN * WK);
+  constexpr int TN = TCH / 16 / WN;  // channel tiles per wave
+  dim3 grid((a.N / TCH) * ((a.M + BMT * 16 - 1) / (BMT * 16)), p.ksplit), block(64 * WN * WK);
   const unsigned lds = 2 * 4 * WK * BMT * 1024;
 #define QA_TILED_K(GMV, ABLV)                                                                                      \
   do {                                                                                                             \
@@ -1471,7 +1478,7 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
     }                                                                                                              \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
-  if constexpr (BMT == 4 && WN == 4) if (p.ablate && a.G == 128) {  // timing experiments (tools/): results are wrong on purpose
+  if constexpr (BMT == 4 && WN == 4 && TCH == 128) if (p.ablate && a.G == 128) {  // timing experiments (tools/): results are wrong on purpose
     switch (p.ablate) {
       case 1: QA_TILED_K(0, 1); return;
       case 2: QA_TILED_K(0, 2); return;
@@ -1488,7 +1495,7 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
       default: break;
     }
   }
-  if constexpr (WN == 4) if (p.mfma32) {
+  if constexpr (WN == 4 && TCH == 128) if (p.mfma32) {
 #define QA_TILED32_K(GMV)                                                                                          \
   do {                                                                                                             \
     auto kfn = w4a16_tiled32_kernel<BMT, TN, WK, GMV>;                                                             \
@@ -1556,7 +1563,8 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
       default: launch_skinny<4>(p, a, L); break;
     }
   } else {
-    if (p.mt == 4 && p.wn2) launch_tiled<4, 4, 2>(p, a, L);  // 2 waves along N x 4 along K, 64 channels per wave
+    if (p.tch == 256) launch_tiled<4, 2, 4, 256>(p, a, L);    // 64 tokens x 256 channels, 4 channel tiles per wave
+    else if (p.mt == 4 && p.wn2) launch_tiled<4, 4, 2>(p, a, L);  // 2 waves along N x 4 along K, 64 channels per wave
     else if (p.mt == 2) launch_tiled<2, 2>(p, a, L);
     else if (p.mt == 8) launch_tiled<8, 2>(p, a, L);
     else if (p.waves == 8) launch_tiled<4, 2>(p, a, L);

@@ -105,9 +105,10 @@ SHAPES = [  # (M, K, N, G)
 
 TILED_MFMA32 = TILED | (1 << 13)      # experimental 32x32x16 flavour of the tiled kernel
 TILED_16WAVES = TILED | (4 << 8)      # 4 x 4 waves per workgroup
+TILED_WIDE = TILED | (1 << 29)        # 64 x 256 workgroup tiles (the planner's choice once they cover the 256 CUs: large M)
 
 
-@pytest.mark.parametrize("kernel_id", [0, SKINNY_DZ, SKINNY_EXACT, TILED, TILED_MFMA32, TILED_16WAVES])
+@pytest.mark.parametrize("kernel_id", [0, SKINNY_DZ, SKINNY_EXACT, TILED, TILED_MFMA32, TILED_16WAVES, TILED_WIDE])
 @pytest.mark.parametrize("M,K,N,G", SHAPES)
 def test_synthetic_sweep(qa, device, M, K, N, G, kernel_id):
     x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M * 7 + K + N + G)
