@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 D, L = 128, 1024
 ang = torch.outer(torch.arange(L, device=dev).float(), 1.0 / (10000 ** (torch.arange(0, D, 2, device=dev).float() / D)))
 cos, sin = torch.cat((ang.cos(), ang.cos()), -1).half(), torch.cat((ang.sin(), ang.sin()), -1).half()
-for B, nh, nkv in ((1, 32, 32), (64, 32, 32), (64, 32, 8), (16, 32, 8), (16, 64, 8), (64, 64, 8)):
+for B, nh, nkv in [tuple(int(v) for v in a.split('x')) for a in (sys.argv[1:] or ['1x32x32', '64x32x32', '64x32x8', '16x32x8', '16x64x8', '64x64x8'])]:
     layers = 4  # rotate caches so that they are HBM-cold like in a model
     kc = [torch.randn(B, nkv, L, D, device=dev).half() for _ in range(layers)]
     vc = [torch.randn(B, nkv, L, D, device=dev).half() for _ in range(layers)]
