@@ -1264,9 +1264,12 @@ static size_t skinny_lds_bytes(int M, int G, int ntw, int waves, int kt_per_spli
   return b;
 }
 
-// `kernel`: low 4 bits = family (QUICK_KERNEL_*), bits 4-7 = token tiles (0 = auto), bits 8-11 = skinny waves / 4
-// (0 = auto), bit 12 = skinny: forbid the LDS copy of x, bit 25 = skinny: exact per-weight dequantisation instead of
-// the deferred-zero path.  Upper bits are for tests and tuning only.
+// `kernel`: low 4 bits = family (QUICK_KERNEL_*), bits 4-7 = token tiles (tiled) / channel tiles per workgroup (skinny),
+// 0 = auto; bits 8-11 = skinny waves / 4 (0 = auto).  The rest is for tests and tuning:
+//   12 skinny: no LDS copy of x            13 tiled: 32x32x16 MFMA flavour      14 tiled: plain (not XCD-aware) tile order
+//   15 tiled: 2 x 4 wave grid              16-20 tiled: ablation / phase stamps 21 skinny: flip the persistence default
+//   22-24 skinny: persistent slots per CU  25 skinny: exact dequantisation      26 skinny: force the table deferred-zero path
+//   28 skinny: no fragment deferred-zero   29 / 30 tiled: force / forbid 256-channel tiles
 static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) {
   Plan p{};
   const int KT = K / 128;
