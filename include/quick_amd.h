@@ -144,6 +144,11 @@ int quick_rmsnorm_f16(const void* x, const void* weight, void* y, int rows, int 
 int quick_rope_kv_append_f16(const void* qkv, const void* cos_table, const void* sin_table, const void* pos,
                              void* q_out, void* k_cache, void* v_cache, int batch, int n_heads, int n_kv_heads,
                              int head_dim, int cache_len, void* hip_stream);
+/* prefill form: `tokens` consecutive positions *pos0 .. per sequence; qkv [batch * tokens, (nh + 2 nkv) * D];
+ * q_out [batch, nh, tokens, D] */
+int quick_rope_kv_write_f16(const void* qkv, const void* cos_table, const void* sin_table, const void* pos0, void* q_out,
+                            void* k_cache, void* v_cache, int batch, int tokens, int n_heads, int n_kv_heads, int head_dim,
+                            int cache_len, void* hip_stream);
 int quick_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* pos, void* out,
                                int batch, int n_heads, int n_kv_heads, int head_dim, int cache_len, float scale,
                                void* hip_stream);

@@ -26,6 +26,7 @@ _SIGNATURES = {
     "quick_w4a16_can_fuse_rmsnorm": (_I, [_I, _I, _I, _I]),
     "quick_rmsnorm_f16": (_I, [_P, _P, _P, _I, _I, ctypes.c_float, _P]),
     "quick_rope_kv_append_f16": (_I, [_P] * 7 + [_I] * 5 + [_P]),
+    "quick_rope_kv_write_f16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "quick_decode_attention_f16": (_I, [_P] * 5 + [_I] * 5 + [ctypes.c_float, _P]),
     "quick_decode_rope_attention_f16": (_I, [_P] * 7 + [_I] * 5 + [ctypes.c_float, _P]),
     "quick_silu_mul_f16": (_I, [_P, _P, _I, _I, _P]),

@@ -63,6 +63,34 @@ __global__ __launch_bounds__(64) void rope_kv_kernel(const half_t* __restrict__ 
   }
 }
 
+// Prefill form of the kernel above: T consecutive tokens per sequence, positions *pos0 .. *pos0 + T - 1.  qkv [B * T, (nh + 2 nkv) * D]
+// (row b * T + t); q goes to q_out [B, nh, T, D] (the layout attention wants), k and v to the caches at their positions.
+__global__ __launch_bounds__(64) void rope_kv_prefill_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t,
+                                                             const half_t* __restrict__ sin_t, const long* __restrict__ pos0,
+                                                             half_t* __restrict__ q_out, half_t* __restrict__ k_cache,
+                                                             half_t* __restrict__ v_cache, int T, int nh, int nkv, int D, int L) {
+  const int bt = blockIdx.y, b = bt / T, t = bt % T, slot = blockIdx.x;
+  const long p = pos0[0] + t;
+  const half_t* src = qkv + (size_t)bt * (nh + 2 * nkv) * D + (size_t)slot * D;
+  const int i = threadIdx.x;
+  if (i >= D / 2) return;
+  if (slot < nh + nkv) {
+    const float x0 = (float)src[i], x1 = (float)src[i + D / 2];
+    const float c0 = (float)cos_t[p * D + i], s0 = (float)sin_t[p * D + i];
+    const float c1 = (float)cos_t[p * D + i + D / 2], s1 = (float)sin_t[p * D + i + D / 2];
+    const half_t r0 = (half_t)((float)(half_t)(x0 * c0) + (float)(half_t)(-x1 * s0));
+    const half_t r1 = (half_t)((float)(half_t)(x1 * c1) + (float)(half_t)(x0 * s1));
+    half_t* dst = slot < nh ? q_out + (((size_t)b * nh + slot) * T + t) * D
+                            : k_cache + (((size_t)b * nkv + (slot - nh)) * L + p) * D;
+    dst[i] = r0;
+    dst[i + D / 2] = r1;
+  } else {
+    half_t* dst = v_cache + (((size_t)b * nkv + (slot - nh - nkv)) * L + p) * D;
+    dst[i] = src[i];
+    dst[i + D / 2] = src[i + D / 2];
+  }
+}
+
 // Single-query attention over positions 0..*pos (inclusive), GQA aware.  One 256-thread workgroup per
 // (sequence, query head); D == 128.  Scores in fp32, two passes over K then V from HBM/L2 (the cache of one head at a
 // few hundred positions is tens of KB).  out [B, nh * D].
@@ -591,6 +619,17 @@ int quick_rope_kv_append_f16(const void* qkv, const void* cos_table, const void*
   hipLaunchKernelGGL(rope_kv_kernel, dim3(n_heads + 2 * n_kv_heads, batch), dim3(64), 0, (hipStream_t)hip_stream,
                      (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, (const long*)pos,
                      (half_t*)q_out, (half_t*)k_cache, (half_t*)v_cache, n_heads, n_kv_heads, head_dim, cache_len);
+  return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+}
+
+int quick_rope_kv_write_f16(const void* qkv, const void* cos_table, const void* sin_table, const void* pos0, void* q_out,
+                            void* k_cache, void* v_cache, int batch, int tokens, int n_heads, int n_kv_heads, int head_dim,
+                            int cache_len, void* hip_stream) {
+  if (batch <= 0 || tokens <= 0 || head_dim % 2 != 0 || head_dim > 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_INVALID_ARGUMENT;
+  if ((long)batch * tokens > 65535) return QUICK_ERR_UNSUPPORTED;  // grid.y
+  hipLaunchKernelGGL(rope_kv_prefill_kernel, dim3(n_heads + 2 * n_kv_heads, batch * tokens), dim3(64), 0, (hipStream_t)hip_stream,
+                     (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, (const long*)pos0, (half_t*)q_out,
+                     (half_t*)k_cache, (half_t*)v_cache, tokens, n_heads, n_kv_heads, head_dim, cache_len);
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
 }
 

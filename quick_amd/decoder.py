@@ -112,9 +112,23 @@ class SyntheticDecoder:
         x = self.embed[tokens]                                        # [B, T, H]
         cos, sin = self.cos.index_select(0, pos), self.sin.index_select(0, pos)
         norm = (lambda v, w: kernels.rmsnorm(v.reshape(-1, H), w).view(v.shape)) if hip_glue else _rms_norm
+        p0 = int(pos[0]) if (hip_glue and mask is None) else 0   # one host read per prefill, not per layer
         for l in self.layers:
             h = norm(x, l["ln1"])
             qkv = l["qkv"](h)                                          # W4A16 GEMM, M = B*T
+            if hip_glue and mask is None and B * T <= 65535:           # prefill: RoPE + cache write in one launch
+                q = torch.empty((B, nh, T, D), dtype=torch.float16, device=x.device)
+                kernels.rope_kv_write(qkv.reshape(B * T, -1), self.cos, self.sin, pos[:1], q, l["k"], l["v"], T, nh, nkv, D)
+                att = F.scaled_dot_product_attention(q, l["k"][:, :, p0:p0 + T], l["v"][:, :, p0:p0 + T], is_causal=True,
+                                                     enable_gqa=nkv != nh)
+                att = att.transpose(1, 2).reshape(B * T, H)
+                o, gu, dn = l["o"], l["gate_up"], l["down"]
+                x2 = x.reshape(B * T, H).contiguous()
+                kernels.gemm_forward(att, o.qweight, o.scales, o.qzeros, residual=x2, out=x2)
+                act = kernels.gemm_forward(kernels.rmsnorm(x2, l["ln2"]), gu.qweight, gu.scales, gu.qzeros, silu_mul=True)
+                kernels.gemm_forward(act, dn.qweight, dn.scales, dn.qzeros, residual=x2, out=x2)
+                x = x2.view(B, T, H)
+                continue
             q, k, v = qkv.split((H, nkv * D, nkv * D), dim=-1)
             q = _rope(q.view(B, T, nh, D).transpose(1, 2), cos, sin)
             k = _rope(k.view(B, T, nkv, D).transpose(1, 2), cos, sin)

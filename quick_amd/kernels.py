@@ -171,6 +171,18 @@ def rope_kv_append(qkv, cos_table, sin_table, pos, q_out, k_cache, v_cache, n_he
     return q_out
 
 
+def rope_kv_write(qkv, cos_table, sin_table, pos0, q_out, k_cache, v_cache, tokens, n_heads, n_kv_heads, head_dim):
+    """Prefill: qkv [B * T, (nh + 2 nkv) D] -> rotated q in q_out [B, nh, T, D], rotated k and v into the caches at
+    positions *pos0 .. *pos0 + T - 1."""
+    lib = _lib.load()
+    rc = lib.quick_rope_kv_write_f16(qkv.data_ptr(), cos_table.data_ptr(), sin_table.data_ptr(), pos0.data_ptr(), q_out.data_ptr(),
+                                     k_cache.data_ptr(), v_cache.data_ptr(), qkv.shape[0] // tokens, tokens, n_heads, n_kv_heads,
+                                     head_dim, k_cache.shape[2], _stream())
+    if rc != _OK:
+        raise RuntimeError(f"quick_rope_kv_write_f16 failed ({rc})")
+    return q_out
+
+
 def decode_attention(q, k_cache, v_cache, pos, out, n_heads, n_kv_heads, head_dim):
     """Single-query attention over cache positions 0..*pos; q [B, nh, D] -> out [B, nh * D]."""
     lib = _lib.load()

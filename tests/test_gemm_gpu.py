@@ -485,6 +485,28 @@ def test_rope_attention_kernels_against_torch(qa, device, B, nh, nkv, p):
     assert (o.float() - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-3
 
 
+def test_prefill_rope_kv_write_against_torch(qa, device):
+    """Prefill RoPE + cache write in one launch (T tokens per sequence from position *pos0) against the torch ops."""
+    from quick_amd import kernels as K_
+    from quick_amd.decoder import _rope
+    torch.manual_seed(2)
+    B, T, nh, nkv, D, L, p0 = 3, 37, 8, 2, 128, 96, 5
+    ang = torch.outer(torch.arange(L, device=device).float(), 1.0 / (10000 ** (torch.arange(0, D, 2, device=device).float() / D)))
+    cos, sin = torch.cat((ang.cos(), ang.cos()), -1).half(), torch.cat((ang.sin(), ang.sin()), -1).half()
+    qkv = torch.randn(B * T, (nh + 2 * nkv) * D, device=device).half()
+    kc = torch.zeros(B, nkv, L, D, dtype=torch.float16, device=device)
+    vc = torch.zeros_like(kc)
+    q_out = torch.empty(B, nh, T, D, dtype=torch.float16, device=device)
+    K_.rope_kv_write(qkv, cos, sin, torch.full((1,), p0, dtype=torch.int64, device=device), q_out, kc, vc, T, nh, nkv, D)
+    q, k, v = qkv.view(B, T, -1).split((nh * D, nkv * D, nkv * D), dim=-1)
+    qr = _rope(q.view(B, T, nh, D).transpose(1, 2), cos[p0:p0 + T], sin[p0:p0 + T])
+    kr = _rope(k.view(B, T, nkv, D).transpose(1, 2), cos[p0:p0 + T], sin[p0:p0 + T])
+    torch.testing.assert_close(q_out, qr, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(kc[:, :, p0:p0 + T], kr, rtol=2e-3, atol=2e-3)
+    assert torch.equal(vc[:, :, p0:p0 + T], v.view(B, T, nkv, D).transpose(1, 2))
+    assert kc[:, :, :p0].abs().max() == 0 and kc[:, :, p0 + T:].abs().max() == 0
+
+
 def test_fused_decode_step_matches_torch_glue(qa, device):
     """HIP glue kernels (RMSNorm, RoPE + KV append, single-query attention, SiLU*mul, residual epilogue) against the
     torch-op decode step on the same synthetic model: same hidden state up to fp16 rounding order."""
