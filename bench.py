@@ -37,6 +37,29 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+
+def pmc_traffic(M, K, N, G, kernel):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 counter pass for this shape
+    (profiles/rNN_pmc_m<M>_*.txt, written by tools/prof_passes.sh on K=N=4096, g=128, planner's kernel): counters
+    need their own rocprofv3 run, so this is read back rather than collected inside the timed run.  Bytes =
+    2 * FETCH_SIZE KiB (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE KiB."""
+    import glob
+    import os
+    if (K, N, G, kernel) != (4096, 4096, 128, 0):
+        return None, None
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_m{M}_*.txt")))
+    if not files:
+        return None, None
+    vals = {}
+    for line in open(files[-1]):
+        f = line.split()
+        if len(f) >= 2 and f[0] in ("FETCH_SIZE", "WRITE_SIZE") and f[0] not in vals:
+            vals[f[0]] = float(f[1])
+    if "FETCH_SIZE" not in vals:
+        return None, None
+    return (2.0 * vals["FETCH_SIZE"] + vals.get("WRITE_SIZE", 0.0)) * 1024.0, "profiles/" + os.path.basename(files[-1])
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +176,7 @@ def main():
         else:
             roof = {"bound": "mfma", "achieved": flops / (k_us * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(M, K, N, G, args.kernel)
         roof.update({"kernel_us": k_us, "kernel_us_cache_resident": k_us_hot, "algorithmic_bytes": nbytes, "flops": flops,
                      })
         return {"M": M, "ms_per_step": ms_step, "tops": flops / (ms_step * 1e-3) / 1e12, "tops_kernel_only": flops / (k_us * 1e-6) / 1e12,
