@@ -698,7 +698,15 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK, WN>& c
                                               const uint32_t (&gz)[TN][groups_per_tile<GM>()],
                                               floatx4 (&acc)[TN][BMT]) {
   constexpr int NG = groups_per_tile<GM>();
-  if (c.kt_lo + WK * s + c.wk >= c.kt_hi) return;  // wave-uniform: a ragged last stage has no tile for this wave
+  if (c.kt_lo + WK * s + c.wk >= c.kt_hi) {  // wave-uniform: a ragged last stage has no tile for this wave
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {  // "use" the loads so that both paths leave the same ones pending (see the K loop)
+      asm volatile("" ::"v"(w[j]));
+#pragma unroll
+      for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(gs[j][i]));
+    }
+    return;
+  }
   GroupQ grp[TN][NG];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
@@ -735,6 +743,9 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK, WN>& c
 // LDS[cur] with weights[s%2] ; issue weights(s+2) into the set just freed ; barrier }.
 // Loads past the last stage are NOT guarded: they replay the last tile (clamped index) and are never consumed -- a
 // guard would merge "issued" and "not issued" paths and make hipcc drain the whole load queue at every consumer.
+// For the same reason the unrolled pair has no early exit: with an odd stage count the second half replays a stage
+// (stores it, skips its compute) -- an `if (s >= nstage) break` gives the waitcnt pass a path from one half-iteration
+// straight into the same half again, on which the weights just requested look like the ones about to be used.
 template <int BMT, int TN, int WK, int GM, int ABL = 0, int WN = 4>
 __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArgs a) {
   constexpr int XPW = 4 * BMT / WN;
@@ -790,17 +801,31 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArg
 #pragma unroll
     for (int mt = 0; mt < BMT; ++mt) acc[j][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
+  unsigned long long t_entry = 0, r_entry = 0;
+  if constexpr (ABL & 16) {
+    t_entry = __builtin_amdgcn_s_memtime();
+    r_entry = __builtin_amdgcn_s_memrealtime();
+  }
   u32x4 xr[XPW];
   u32x4 w[2][TN];
   uint32_t gs[2][TN][NG], gz[2][TN][NG];
   const int rd = wk * (4 * BMT * 1024) + lane * 16;  // this wave reads its k-tile's part of a stage
 
   if (nstage > 0) {
-    tiled_load_w<BMT, TN, WK, GM, WN>(c, a, 0, w[0], gs[0], gz[0]);
+    // Issue order = the K loop's steady state (x(s+1) then w(s+1) in flight at the top of iteration s), and pinned:
+    // hipcc's waitcnt pass merges the prologue's view of "which loads are still in flight" into every iteration, so a
+    // prologue that ends on x loads (or lets the scheduler sink a scale load below them) turns the loop's
+    // s_waitcnt vmcnt(7..4) into vmcnt(3..0) -- a full drain of the weight prefetch once per stage [r01: -4 %].
     tiled_load_x<BMT, TN, WK, WN>(c, 0, xr);
-    tiled_load_w<BMT, TN, WK, GM, WN>(c, a, 1, w[1], gs[1], gz[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    tiled_load_w<BMT, TN, WK, GM, WN>(c, a, 0, w[0], gs[0], gz[0]);
+    __builtin_amdgcn_sched_barrier(0);
     tiled_store_x<BMT, TN, WK, WN>(c, smem, lane, xr);
+    __builtin_amdgcn_sched_barrier(0);
     tiled_load_x<BMT, TN, WK, WN>(c, 1, xr);
+    __builtin_amdgcn_sched_barrier(0);
+    tiled_load_w<BMT, TN, WK, GM, WN>(c, a, 1, w[1], gs[1], gz[1]);
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
 
@@ -814,11 +839,11 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArg
     t_prev = t_now;                                              \
   }
   if constexpr (ABL & 16) t_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_loop = t_prev;
   for (int s0 = 0; s0 < nstage; s0 += 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int s = s0 + u;
-      if (s >= nstage) goto k_loop_done;
+      const int s = s0 + u;  // (s == nstage for odd nstage: a replayed stage whose compute is skipped)
       char* const cur = smem + u * STAGE_BYTES;
       char* const nxt = smem + (u ^ 1) * STAGE_BYTES;
       if constexpr (!(ABL & 2)) tiled_store_x<BMT, TN, WK, WN>(c, nxt, lane, xr);  // stage s+1 (a replay at the very end)
@@ -833,13 +858,15 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArg
       QA_STAMP(4)
     }
   }
-k_loop_done:
   if constexpr (ABL & 16) {
     if (lane == 0 && a.dbg) {
       unsigned long long* o = a.dbg + ((size_t)blockIdx.x * (WN * WK) + wave) * 8;
 #pragma unroll
       for (int i = 0; i < 5; ++i) o[i] = ph[i];
-      o[5] = nstage;
+      o[5] = (unsigned long long)nstage | (r_entry << 8);  // (+ when the wave started, 100 MHz ticks)
+      o[6] = t_loop - t_entry;  // prologue (first loads) in shader cycles
+      // shader cycles and 100 MHz ticks from entry to the end of the K loop: the clock the kernel actually ran at
+      o[7] = ((__builtin_amdgcn_s_memtime() - t_entry) << 24) | ((__builtin_amdgcn_s_memrealtime() - r_entry) & 0xffffff);
     }
   }
 #undef QA_STAMP
@@ -967,7 +994,15 @@ __device__ __forceinline__ void tiled32_compute(const TiledCtx<BMT, TN, WK>& c, 
                                                 const uint32_t (&gz)[TN][groups_per_tile<GM>()],
                                                 floatx16 (&acc)[TN / 2][BMT / 2], int lane) {
   constexpr int NG = groups_per_tile<GM>();
-  if (c.kt_lo + WK * s + c.wk >= c.kt_hi) return;  // wave-uniform: a ragged last stage has no tile for this wave
+  if (c.kt_lo + WK * s + c.wk >= c.kt_hi) {  // wave-uniform: a ragged last stage has no tile for this wave
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {  // "use" the loads so that both paths leave the same ones pending (see the K loop)
+      asm volatile("" ::"v"(w[j]));
+#pragma unroll
+      for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(gs[j][i]));
+    }
+    return;
+  }
   // after the lane shuffle, lanes 16-31 and 48-63 hold the second tile of a pair: pick that tile's constants there
   const bool second = (lane >> 4) & 1;
   GroupQ grp[TN / 2][NG];

@@ -18,7 +18,8 @@ for _ in range(3):
     assert rc == 0, _lib.last_error()
 torch.cuda.synchronize()
 d = ws.cpu().numpy().reshape(-1, 8)[: 256 * 8].reshape(256, 8, 8).astype(np.float64)
-nst = d[0, 0, 5]
+raw = ws.cpu().numpy().reshape(-1, 8)[: 256 * 8]
+nst = float(int(raw[0, 5]) & 255)
 names = ["x regs->LDS (vmcnt wait + ds_write)", "issue x loads", "compute (ds_read + dequant + mfma)", "issue w loads", "barrier"]
 tot = d[:, :, :5].sum(axis=2).mean()
 print(f"stages {nst:.0f}; mean cycles per wave in the K loop {tot:.0f} (s_memtime ticks = shader cycles)")
@@ -28,3 +29,12 @@ for i, n in enumerate(names):
 for wk in (0, 1):
     v = d[:, 4 * wk:4 * wk + 4, :5].mean(axis=(0, 1)) / nst
     print(f"  waves wk={wk}: " + "  ".join(f"{x:.0f}" for x in v))
+pro = d[:, :, 6].mean()
+cyc = (d[:, :, 7].astype(np.int64) >> 24).astype(np.float64).mean() if False else np.mean([int(v) >> 24 for v in ws.cpu().numpy().reshape(-1, 8)[: 256 * 8, 7]])
+rt = np.mean([int(v) & 0xffffff for v in ws.cpu().numpy().reshape(-1, 8)[: 256 * 8, 7]])
+print(f"prologue {pro:.0f} cycles; entry -> end of K loop {cyc:.0f} shader cycles = {rt:.1f} ticks of 100 MHz -> {cyc / (rt * 10):.2f} GHz")
+raw = ws.cpu().numpy().reshape(-1, 8)[: 256 * 8]
+st = np.array([int(v) >> 8 for v in raw[:, 5]], dtype=np.float64)
+en = st + np.array([int(v) & 0xffffff for v in raw[:, 7]], dtype=np.float64)
+print(f"wave start spread {(st.max() - st.min()) / 100:.2f} us; first start -> last K-loop end {(en.max() - st.min()) / 100:.2f} us; "
+      f"per-wave entry -> loop end min/mean/max {(en - st).min() / 100:.2f}/{(en - st).mean() / 100:.2f}/{(en - st).max() / 100:.2f} us")
