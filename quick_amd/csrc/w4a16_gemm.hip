@@ -1353,11 +1353,21 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     // 32-token tiles once 64-token tiles would need a 4-way K split to cover the CUs (twice the tiles, half the slices
     // to reduce): M = 65..128 at N = 4096, 15.5 us instead of 16.5 us at M = 128 [r01]
     if (!mt_req && p.mt == 4 && (N / 128) * ((M + 63) / 64) * 4 <= 256 && (KT + wk - 1) / wk >= 8) p.mt = 2;
-    // 256-channel tiles (4 channel tiles per wave: one LDS fragment read per four MFMAs instead of two, half the x traffic)
-    // once they still cover the 256 CUs: M = 1024 at N = 4096 59 -> 50 us, M = 8192 x 22016 772 -> 845 TFLOP/s [r01].
+    // 256-channel tiles (4 channel tiles per wave: one LDS fragment read per four MFMAs instead of two, 2/3 of the L2 -> CU
+    // bytes per MAC): M = 1024 at N = 4096 59 -> 50 us, M = 8192 x 22016 772 -> 845 TFLOP/s [r01].  Whether they pay is a
+    // matter of how the tiles quantise onto the 256 CUs.  In units of one 128-channel tile alone on its CU: two
+    // co-resident 128-channel tiles take ~1.65, a 256-channel tile ~1.5; W wide tiles run in ceil(W / 256) rounds, the
+    // 2W narrow ones in full rounds of 512 plus a remainder that runs one or two per CU.  Up to 128 wide tiles they
+    // would need a K split and lose (M = 512 at N = 4096: 33.7 against 31.1 us); 129..256 win by 8-10 % (M = 576..960 at
+    // N = 4096, 256 x 12288, 128 x 22016, M = 384..512 at K = N = 8192); just above a multiple of 256 the second, nearly
+    // empty round loses (192 x 22016: 80 against 70 us; 512 x 11008: 84 against 75) [r01 sweep, one session].
     // Kernel bit 29 forces them, bit 30 forbids them.
     const bool wide_ok = p.mt == 4 && p.waves == 8 && !p.wn2 && !p.mfma32 && !p.ablate && N % 256 == 0 && !mt_req;
-    const bool wide = ((kernel >> 29) & 1) || (!((kernel >> 30) & 1) && (N / 256) * ((M + 63) / 64) >= 256);
+    const long wtiles = (long)(N / 256) * ((M + 63) / 64);
+    const long nfull = 2 * wtiles / 512, nrem = 2 * wtiles % 512;
+    const double narrow_cost = 1.65 * nfull + (nrem == 0 ? 0.0 : (nrem <= 256 ? 1.0 : 1.65));
+    const double wide_cost = 1.5 * ((wtiles + 255) / 256);
+    const bool wide = ((kernel >> 29) & 1) || (!((kernel >> 30) & 1) && wtiles > 128 && wide_cost < narrow_cost);
     p.tch = wide_ok && wide ? 256 : 128;
     p.ntiles = (N / p.tch) * ((M + p.mt * 16 - 1) / (p.mt * 16));
     p.slab_floats = (size_t)(p.tch / 16) * p.mt * 256;
