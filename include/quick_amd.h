@@ -113,6 +113,13 @@ int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* s
                                int M, int K, int N, int group_size, int kernel, int grid_split_k, void* hip_stream);
 int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size);
 
+/* What a launch of this shape will run, as one line of text (host-only, no GPU needed): kernel family, tile shape,
+ * grid, K split and workspace, e.g. "tiled tokens=64 channels=128 waves=8 grid=256x1 ksplit=1 xcd_rows=2 workspace=0" or
+ * "skinny ntw=1 waves=8 x=lds dequant=deferred-zero-table grid=256x1x1 ksplit=1 workspace=0".  For logs and for tests of
+ * the shape heuristics; the wording may grow fields, the leading family word will not change.  `kernel` and
+ * `grid_split_k` as in quick_w4a16_gemm_f16_ex (0 = auto).  (No counterpart in the reference: its kernel has one shape.) */
+int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, int grid_split_k, char* text, size_t text_bytes);
+
 /*
  * Measurement aid (bench.py): enqueue the GEMM `iters` times on `hip_stream`, cycling through `n_sets`
  * weight sets (host arrays of device pointers) so that consecutive launches do not hit in the 256 MiB

@@ -24,6 +24,7 @@ _SIGNATURES = {
     "quick_w4a16_gemm_profile": (_I, [_P, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "quick_w4a16_gemm_f16_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     "quick_w4a16_can_fuse_rmsnorm": (_I, [_I, _I, _I, _I]),
+    "quick_w4a16_plan_describe": (_I, [_I, _I, _I, _I, _I, _I, ctypes.c_char_p, _Z]),
     "quick_rmsnorm_f16": (_I, [_P, _P, _P, _I, _I, ctypes.c_float, _P]),
     "quick_rope_kv_append_f16": (_I, [_P] * 7 + [_I] * 5 + [_P]),
     "quick_rope_kv_write_f16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -1675,6 +1675,21 @@ int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size) {
   return p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8));
 }
 
+int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, int grid_split_k, char* text, size_t text_bytes) {
+  const int rc = check_shapes(M, K, N, group_size);
+  if (rc != QUICK_OK) return rc;
+  if (!text || text_bytes == 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "no text buffer");
+  const Plan p = make_plan(M, K, N, group_size, kernel, grid_split_k);
+  if (p.kernel == QUICK_KERNEL_SKINNY)
+    snprintf(text, text_bytes, "skinny ntw=%d waves=%d x=%s dequant=%s grid=%dx%dx%d ksplit=%d workspace=%zu", p.mt, p.waves,
+             p.xlds ? "lds" : "l2", p.dz ? (p.xlds ? "deferred-zero-table" : "deferred-zero-fragment") : "exact", p.grid_x,
+             (M + 15) / 16, p.ksplit, p.ksplit, workspace_need(p));
+  else
+    snprintf(text, text_bytes, "tiled tokens=%d channels=%d waves=%d grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.mt * 16,
+             p.tch, p.wn2 ? 8 : p.waves, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
+  return QUICK_OK;
+}
+
 int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const void* const* scales,
                              const void* const* qzeros, int n_sets, void* y, void* workspace, size_t workspace_bytes,
                              int M, int K, int N, int group_size, int kernel, int grid_split_k, int iters,

@@ -53,6 +53,16 @@ def can_fuse_rmsnorm(M, K, N, G):
     return bool(_lib.load().quick_w4a16_can_fuse_rmsnorm(M, K, N, G))
 
 
+def plan_describe(M, K, N, G, kernel_id=KERNEL_AUTO, grid_split_k=0):
+    """One line saying what a launch of this shape runs (quick_w4a16_plan_describe; host-only, no GPU needed)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(256)
+    rc = _lib.load().quick_w4a16_plan_describe(M, K, N, G, kernel_id, grid_split_k, buf, len(buf))
+    if rc != _OK:
+        _raise(rc)
+    return buf.value.decode()
+
+
 def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=KERNEL_AUTO, grid_split_k=0, residual=None,
                  out=None, rmsnorm_weight=None, rmsnorm_eps=1e-5, silu_mul=False):
     """y [M, N] fp16 = in_feats [M, K] @ dequant(kernel, scaling_factors, zeros) (+ bias) (+ residual), MI355X-order

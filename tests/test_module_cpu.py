@@ -136,6 +136,39 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 1024, 128, 8) == 65536 + 64 * 4 * 256 * 4
 
 
+def test_plan_describe_pins_the_shape_heuristics():
+    """quick_w4a16_plan_describe is host-only; the expectations are the r01 measurements quoted in make_plan()."""
+    from quick_amd import kernels
+
+    def plan(M, K, N, G=128, **kw):
+        return kernels.plan_describe(M, K, N, G, **kw)
+
+    # decode shapes: one token -> deferred-zero table kernel, persistent over the channel blocks when there are many
+    assert plan(1, 4096, 4096).startswith("skinny ntw=1 waves=8 x=lds dequant=deferred-zero-table grid=256x1x1")
+    assert "grid=464x1x1" in plan(1, 4096, 22016)          # 1376 blocks in 3 rounds of <= 464
+    assert "dequant=exact" in plan(8, 4096, 4096)            # one block per workgroup: the table does not pay
+    assert plan(64, 4096, 4096).startswith("skinny ntw=4") and "deferred-zero-fragment" in plan(64, 4096, 4096)
+    assert plan(65, 4096, 4096).startswith("tiled")
+    assert plan(32, 4096, 8192).startswith("tiled")          # >= 64 tiles of 128 channels: no K split needed
+    # K split until the 256 CUs are covered; the workspace is what workspace_bytes_ex says
+    p = plan(128, 4096, 4096)
+    assert "tokens=32 channels=128" in p and "ksplit=2" in p
+    assert p.endswith(f"workspace={_lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, 0, 0)}")
+    # 256-channel tiles by how the tiles quantise onto 256 CUs
+    assert "channels=128" in plan(512, 4096, 4096)           # 128 wide tiles would need a K split
+    assert "channels=256" in plan(576, 4096, 4096)           # 144 wide tiles in one round beat 288 narrow ones
+    assert "channels=256" in plan(1024, 4096, 4096)
+    assert "channels=128" in plan(192, 4096, 22016)          # 258 wide tiles = a second, nearly empty round
+    assert "channels=256" in plan(128, 4096, 22016)
+    assert "channels=128" in plan(512, 4096, 11008) and "channels=256" in plan(640, 4096, 11008)
+    assert "channels=256" in plan(8192, 4096, 22016)
+    # forcing a family / a split through the kernel id and grid_split_k
+    assert plan(512, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny")
+    assert "ksplit=4" in plan(64, 4096, 4096, kernel_id=kernels.KERNEL_TILED, grid_split_k=4)
+    with pytest.raises(ValueError, match="cta_N"):
+        plan(4, 4096, 4100)
+
+
 def test_quick_kernels_shim_exports_reference_symbol():
     import quick_kernels
     assert callable(quick_kernels.gemm_forward_cuda_quick)
