@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--sweep", default="1,8,64,512", help="comma-separated M values reported in 'sweep'")
     ap.add_argument("--sets", type=int, default=0, help="distinct weight sets cycled through (0 = enough for > 320 MiB)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 skinny, 2 tiled")
+    ap.add_argument("--split-k", type=int, default=0, help="K slices across workgroups (0 = the planner's choice; tuning only)")
     ap.add_argument("--layers", default="1x4096x12288,1x4096x22016,1x11008x4096",
                     help="MxKxN shapes (Llama-2-7B fused qkv, gate_up, down at bs=1) timed kernel-only into 'decode_layers'; '' = none")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -115,13 +116,13 @@ def main():
     def measure(M, steps, warmup):
         x = x_full[:M].contiguous()
         y = torch.empty((M, N), dtype=torch.float16, device=dev)
-        ws_bytes = lib.quick_w4a16_workspace_bytes_ex(M, K, N, G, args.kernel, 0)
+        ws_bytes = lib.quick_w4a16_workspace_bytes_ex(M, K, N, G, args.kernel, args.split_k)
         ws = torch.zeros(max(ws_bytes, 1), dtype=torch.uint8, device=dev)   # zero-filled once; the library keeps it so
 
         def launch(i):
             qw, sc, qz = sets[i % n_sets]
             rc = lib.quick_w4a16_gemm_f16_ex(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, y.data_ptr(),
-                                             ws.data_ptr(), ws_bytes, M, K, N, G, args.kernel, 0,
+                                             ws.data_ptr(), ws_bytes, M, K, N, G, args.kernel, args.split_k,
                                              torch.cuda.current_stream().cuda_stream)
             if rc != 0:
                 raise RuntimeError(_lib.last_error())
@@ -160,13 +161,13 @@ def main():
         # the kernel's own duration: event pair bound to each dispatch, cycling the same weight sets
         kus = (ctypes.c_float * steps)()
         rc = lib.quick_w4a16_gemm_profile(x.data_ptr(), qw_arr, sc_arr, qz_arr, n_sets, y.data_ptr(), ws.data_ptr(), ws_bytes,
-                                          M, K, N, G, args.kernel, 0, steps, kus, stream.cuda_stream)
+                                          M, K, N, G, args.kernel, args.split_k, steps, kus, stream.cuda_stream)
         if rc != 0:
             raise RuntimeError(_lib.last_error())
         k_us = float(np.mean(np.asarray(kus[:])[min(5, steps - 1):]))
         # same, cache-resident (one weight set): what a launch sees when the layer was just touched
         rc = lib.quick_w4a16_gemm_profile(x.data_ptr(), qw_arr, sc_arr, qz_arr, 1, y.data_ptr(), ws.data_ptr(), ws_bytes,
-                                          M, K, N, G, args.kernel, 0, steps, kus, stream.cuda_stream)
+                                          M, K, N, G, args.kernel, args.split_k, steps, kus, stream.cuda_stream)
         k_us_hot = float(np.mean(np.asarray(kus[:])[min(5, steps - 1):])) if rc == 0 else None
 
         flops, nbytes = oracle.algorithmic_flops(M, K, N), oracle.algorithmic_bytes(M, K, N, G)

@@ -154,6 +154,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     p = plan(128, 4096, 4096)
     assert "tokens=32 channels=128" in p and "ksplit=2" in p
     assert p.endswith(f"workspace={_lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, 0, 0)}")
+    assert "grid=80x3 ksplit=3" in plan(64, 8192, 10240)     # not only powers of two: 240 of 256 CUs
     # 256-channel tiles by how the tiles quantise onto 256 CUs
     assert "channels=128" in plan(512, 4096, 4096)           # 128 wide tiles would need a K split
     assert "channels=256" in plan(576, 4096, 4096)           # 144 wide tiles in one round beat 288 narrow ones
