@@ -29,11 +29,12 @@ for i, n in enumerate(names):
 for wk in (0, 1):
     v = d[:, 4 * wk:4 * wk + 4, :5].mean(axis=(0, 1)) / nst
     print(f"  waves wk={wk}: " + "  ".join(f"{x:.0f}" for x in v))
+# words 5-7 of a wave's record: stage count | start (100 MHz ticks) << 8;  prologue cycles;  cycles << 24 | 100 MHz ticks
+# from kernel entry to the end of the K loop (the ratio is the shader clock the kernel actually ran at)
 pro = d[:, :, 6].mean()
-cyc = (d[:, :, 7].astype(np.int64) >> 24).astype(np.float64).mean() if False else np.mean([int(v) >> 24 for v in ws.cpu().numpy().reshape(-1, 8)[: 256 * 8, 7]])
-rt = np.mean([int(v) & 0xffffff for v in ws.cpu().numpy().reshape(-1, 8)[: 256 * 8, 7]])
+cyc = np.mean([int(v) >> 24 for v in raw[:, 7]])
+rt = np.mean([int(v) & 0xffffff for v in raw[:, 7]])
 print(f"prologue {pro:.0f} cycles; entry -> end of K loop {cyc:.0f} shader cycles = {rt:.1f} ticks of 100 MHz -> {cyc / (rt * 10):.2f} GHz")
-raw = ws.cpu().numpy().reshape(-1, 8)[: 256 * 8]
 st = np.array([int(v) >> 8 for v in raw[:, 5]], dtype=np.float64)
 en = st + np.array([int(v) & 0xffffff for v in raw[:, 7]], dtype=np.float64)
 print(f"wave start spread {(st.max() - st.min()) / 100:.2f} us; first start -> last K-loop end {(en.max() - st.min()) / 100:.2f} us; "
