@@ -573,3 +573,31 @@ def test_llama70b_shapes_against_dense_dequant(qa, device, K, N, M):
     y = layer(x)
     assert tuple(y.shape) == (M, N)
     assert float((y.float() - want).abs().max() / want.abs().max()) <= TOL
+
+
+def test_random_shapes_against_dequantised_matmul(qa, device):
+    """60 seeded random (M, K, N, G) draws through whatever the planner picks (skinny/tiled, 128/256-channel tiles, K
+    splits that are not powers of two, ragged M, odd stage counts), twice each with the same workspace, against
+    fp32 matmul over the weights dequantised on the GPU (quick_dequantize_mi355x_f16 is bit-exact against the oracle,
+    see above).  Not a replacement for the oracle sweeps: a net for planner branches no fixed list thought of."""
+    from quick_amd import kernels as K_, packing
+    rng = np.random.default_rng(20260928)
+    gen = torch.Generator(device=device)
+    for case in range(int(os.environ.get("QUICK_AMD_RANDOM_CASES", "60"))):   # (a longer soak: set the variable)
+        G = int(rng.choice([32, 64, 128, 128, 128, 256]))
+        unit = max(G, 128)                                   # K is a multiple of 128 and of the group size
+        K = int(rng.integers(1, 8192 // unit + 1)) * unit
+        N = int(rng.integers(1, 97)) * 128
+        M = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 32, 40, 63, 64, 65, 100, 128, 200, 257, 384, 520, 700]))
+        if M * N * K > 2.5e10:
+            M = max(1, int(2.5e10 // (N * K)))
+        gen.manual_seed(case)
+        qw, sc, qz = packing.random_mi355x(K, N, G, device, generator=gen)
+        x = (torch.randn(M, K, device=device, generator=gen) * 0.5).half()
+        ref = x.float() @ K_.dequantize_mi355x(qw, sc, qz).float()
+        y1 = qa.gemm_forward(x, qw, sc, qz)
+        y2 = qa.gemm_forward(x, qw, sc, qz)
+        assert torch.equal(y1, y2), (case, M, K, N, G, K_.plan_describe(M, K, N, G))
+        err = (y1.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+        assert err <= TOL, (case, M, K, N, G, err, K_.plan_describe(M, K, N, G))
+    print(f"{case + 1} random shapes checked")
