@@ -1304,7 +1304,7 @@ static size_t skinny_lds_bytes(int M, int G, int ntw, int waves, int kt_per_spli
 //   12 skinny: no LDS copy of x            13 tiled: 32x32x16 MFMA flavour      14 tiled: plain (not XCD-aware) tile order
 //   15 tiled: 2 x 4 wave grid              16-20 tiled: ablation / phase stamps 21 skinny: flip the persistence default
 //   22-24 skinny: persistent slots per CU  25 skinny: exact dequantisation      26 skinny: force the table deferred-zero path
-//   28 skinny: no fragment deferred-zero   29 / 30 tiled: force / forbid 256-channel tiles
+//   27 tiled: force 128 x 256 four-wave tiles 28 skinny: no fragment deferred-zero   29 / 30 tiled: force / forbid 256-channel tiles
 static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) {
   Plan p{};
   const int KT = K / 128;
@@ -1349,7 +1349,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   } else {
     p.mt = mt_req ? (mt_req == 2 ? 2 : (mt_req == 8 ? 8 : 4)) : (M <= 32 ? 2 : 4);
     p.waves = waves_req == 16 ? 16 : 8;
-    const int wk = p.wn2 ? 4 : p.waves / 4;
+    int wk = p.wn2 ? 4 : p.waves / 4;
     // 32-token tiles once 64-token tiles would need a 4-way K split to cover the CUs (twice the tiles, half the slices
     // to reduce): M = 65..128 at N = 4096, 15.5 us instead of 16.5 us at M = 128 [r01]
     if (!mt_req && p.mt == 4 && (N / 128) * ((M + 63) / 64) * 4 <= 256 && (KT + wk - 1) / wk >= 8) p.mt = 2;
@@ -1369,6 +1369,21 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     const double wide_cost = 1.5 * ((wtiles + 255) / 256);
     const bool wide = ((kernel >> 29) & 1) || (!((kernel >> 30) & 1) && wtiles > 128 && wide_cost < narrow_cost);
     p.tch = wide_ok && wide ? 256 : 128;
+    // 128 x 256 tiles run by FOUR waves of 128 tokens x 64 channels each (128 accumulators per lane: at 256 threads hipcc
+    // hands out AGPRs, 396 registers, one workgroup per CU): 1.6 VALU and 0.25 LDS fragment reads per MFMA, half the
+    // L2 -> CU bytes per MAC of the 64 x 128 tile.  A round of them costs ~1.87 rounds of 64 x 256 tiles for twice the
+    // work [r01: M = 2048 at N = 4096 91.6 -> 85.6 us, 8192 x 4096 x 22016 1758 -> 1580 us, 4096 x 8192 x 8192 587 -> 534 us
+    // = 1.03 PFLOP/s], so they win where their rounds quantise no worse.  Kernel bit 27 forces them, bit 30 forbids them.
+    const long btiles = (long)(N / 256) * ((M + 127) / 128);
+    const double big_cost = 1.5 * 1.87 * ((btiles + 255) / 256);
+    const bool big = ((kernel >> 27) & 1) || (!((kernel >> 30) & 1) && !((kernel >> 29) & 1) && btiles > 128 &&
+                                              big_cost < std::min(narrow_cost, wide_cost));
+    if (wide_ok && big) {
+      p.tch = 256;
+      p.mt = 8;
+      p.waves = 4;
+      wk = 1;  // 4 waves along N, stages of 128 k
+    }
     p.ntiles = (N / p.tch) * ((M + p.mt * 16 - 1) / (p.mt * 16));
     p.slab_floats = (size_t)(p.tch / 16) * p.mt * 256;
     // one workgroup per CU: split K until the 256 CUs are covered, keeping >= 2 stages per slice
@@ -1614,7 +1629,8 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
       default: launch_skinny<4>(p, a, L); break;
     }
   } else {
-    if (p.tch == 256) launch_tiled<4, 2, 4, 256>(p, a, L);    // 64 tokens x 256 channels, 4 channel tiles per wave
+    if (p.tch == 256 && p.mt == 8) launch_tiled<8, 1, 4, 256>(p, a, L);  // 128 x 256, four waves of 128 tokens x 64 channels
+    else if (p.tch == 256) launch_tiled<4, 2, 4, 256>(p, a, L);    // 64 tokens x 256 channels, 4 channel tiles per wave
     else if (p.mt == 4 && p.wn2) launch_tiled<4, 4, 2>(p, a, L);  // 2 waves along N x 4 along K, 64 channels per wave
     else if (p.mt == 2) launch_tiled<2, 2>(p, a, L);
     else if (p.mt == 8) launch_tiled<8, 2>(p, a, L);

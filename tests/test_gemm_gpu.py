@@ -106,9 +106,10 @@ SHAPES = [  # (M, K, N, G)
 TILED_MFMA32 = TILED | (1 << 13)      # experimental 32x32x16 flavour of the tiled kernel
 TILED_16WAVES = TILED | (4 << 8)      # 4 x 4 waves per workgroup
 TILED_WIDE = TILED | (1 << 29)        # 64 x 256 workgroup tiles (the planner's choice once they cover the 256 CUs: large M)
+TILED_BIG = TILED | (1 << 27)         # 128 x 256 tiles run by four waves with 128 accumulators each (large M)
 
 
-@pytest.mark.parametrize("kernel_id", [0, SKINNY_DZ, SKINNY_EXACT, TILED, TILED_MFMA32, TILED_16WAVES, TILED_WIDE])
+@pytest.mark.parametrize("kernel_id", [0, SKINNY_DZ, SKINNY_EXACT, TILED, TILED_MFMA32, TILED_16WAVES, TILED_WIDE, TILED_BIG])
 @pytest.mark.parametrize("M,K,N,G", SHAPES)
 def test_synthetic_sweep(qa, device, M, K, N, G, kernel_id):
     x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M * 7 + K + N + G)
@@ -601,3 +602,25 @@ def test_random_shapes_against_dequantised_matmul(qa, device):
         err = (y1.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
         assert err <= TOL, (case, M, K, N, G, err, K_.plan_describe(M, K, N, G))
     print(f"{case + 1} random shapes checked")
+
+
+@pytest.mark.parametrize("kernel_id", [TILED_WIDE, TILED_BIG], ids=["64x256", "128x256"])
+@pytest.mark.parametrize("M,K,N,G", [(300, 512, 512, 128), (129, 1152, 768, 64), (640, 256, 1024, 32), (1100, 384, 512, 128)])
+def test_wide_tiles_epilogues_and_k_split(qa, device, M, K, N, G, kernel_id):
+    """The 256-channel tile variants with every epilogue (bias, residual, SiLU*mul) and with a forced K split, ragged M."""
+    from quick_amd import kernels as K_
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + K + N + G + 5)
+    want = oracle.w4a16_forward(x, iw, s, z, G).astype(np.float32)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device)
+    bias = torch.linspace(-1, 1, N, device=device).half()
+    res = torch.randn(M, N, device=device).half()
+    assert f"channels=256" in K_.plan_describe(M, K, N, G, kernel_id)
+    y = qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=kernel_id)
+    ref = want + bias.float().cpu().numpy() + res.float().cpu().numpy()
+    assert rel_err(y.cpu().numpy(), ref) <= TOL
+    for ks in (2, 3):
+        y2 = qa.gemm_forward(xd, *packed, kernel_id=kernel_id, grid_split_k=ks)
+        assert rel_err(y2.cpu().numpy(), want) <= TOL
+    y_act = qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kernel_id)
+    torch.testing.assert_close(y_act, K_.silu_mul(qa.gemm_forward(xd, *packed, kernel_id=kernel_id)), rtol=2e-3, atol=2e-3)

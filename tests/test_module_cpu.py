@@ -158,7 +158,9 @@ def test_plan_describe_pins_the_shape_heuristics():
     # 256-channel tiles by how the tiles quantise onto 256 CUs
     assert "channels=128" in plan(512, 4096, 4096)           # 128 wide tiles would need a K split
     assert "channels=256" in plan(576, 4096, 4096)           # 144 wide tiles in one round beat 288 narrow ones
-    assert "channels=256" in plan(1024, 4096, 4096)
+    assert "tokens=64 channels=256" in plan(1024, 4096, 4096)
+    assert "tokens=128 channels=256 waves=4" in plan(2048, 4096, 4096)   # 256 four-wave tiles: one round
+    assert "tokens=64" in plan(2560, 4096, 4096)                         # 320 of them would be two rounds
     assert "channels=128" in plan(192, 4096, 22016)          # 258 wide tiles = a second, nearly empty round
     assert "channels=256" in plan(128, 4096, 22016)
     assert "channels=128" in plan(512, 4096, 11008) and "channels=256" in plan(640, 4096, 11008)
