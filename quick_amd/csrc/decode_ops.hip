@@ -203,112 +203,12 @@ __device__ __forceinline__ void rope8(const half8_t x, const half_t* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void decode_rope_attention_kernel(
-    const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t, const half_t* __restrict__ sin_t,
-    const long* __restrict__ pos, half_t* __restrict__ k_cache, half_t* __restrict__ v_cache, half_t* __restrict__ out,
-    int nh, int nkv, int L, float scale) {
-  constexpr int D = 128;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sc = (float*)smem_raw;      // [len] scores / probabilities
-  float* red = sc + ((L + 3) & ~3);  // [4] per-wave partials, then [4][D] output partials
-  const int b = blockIdx.y, h = blockIdx.x, group = nh / nkv, kvh = h / group;
-  const int p = (int)pos[0], len = p + 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane & 15, rsel = lane >> 4;
-  const half_t* row = qkv + (size_t)b * (nh + 2 * nkv) * D;
-  const half_t* kp = k_cache + ((size_t)b * nkv + kvh) * L * D;
-  const half_t* vp = v_cache + ((size_t)b * nkv + kvh) * L * D;
-
-  float qr[8], kr[8];
-  rope8(*(const half8_t*)(row + (size_t)h * D + sub * 8), cos_t + (size_t)p * D, sin_t + (size_t)p * D, sub, qr);
-  rope8(*(const half8_t*)(row + (size_t)(nh + kvh) * D + sub * 8), cos_t + (size_t)p * D, sin_t + (size_t)p * D, sub, kr);
-  const half8_t vn = *(const half8_t*)(row + (size_t)(nh + nkv + kvh) * D + sub * 8);
-  if (threadIdx.x < 16) {
-    if (h % group == 0) {  // append to the caches (position p is not read by anyone in this launch)
-      half8_t kh;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) kh[j] = (half_t)kr[j];
-      *(half8_t*)(k_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = kh;
-      *(half8_t*)(v_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = vn;
-    }
-  }
-
-  constexpr int UNR = 8;
-  float mx = -INFINITY;
-  for (int t0 = wave * 4; t0 < len; t0 += 16 * UNR) {
-    half8_t kv[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int t = min(t0 + 16 * u + rsel, max(p - 1, 0));  // cache rows 0..p-1; row p comes from registers
-      kv[u] = *(const half8_t*)(kp + (size_t)t * D + sub * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int t = t0 + 16 * u + rsel;
-      float d = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) d += qr[j] * (t == p ? kr[j] : (float)kv[u][j]);
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
-      d *= scale;
-      if (t < len && sub == 0) sc[t] = d;
-      if (t < len) mx = fmaxf(mx, d);
-    }
-  }
-  mx = wave_max(mx);
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float sum = 0.f;
-  for (int t = threadIdx.x; t < len; t += 256) {
-    const float e = __expf(sc[t] - mx);
-    sc[t] = e;
-    sum += e;
-  }
-  sum = wave_sum(sum);
-  __syncthreads();
-  if (lane == 0) red[wave] = sum;
-  __syncthreads();
-  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
-  __syncthreads();
-
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int t0 = wave * 4; t0 < len; t0 += 16 * UNR) {
-    half8_t vv[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int t = min(t0 + 16 * u + rsel, max(p - 1, 0));
-      vv[u] = *(const half8_t*)(vp + (size_t)t * D + sub * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int t = t0 + 16 * u + rsel;
-      const float pt = t < len ? sc[t] : 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += pt * (t == p ? (float)vn[j] : (float)vv[u][j]);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    acc[j] += __shfl_xor(acc[j], 16);
-    acc[j] += __shfl_xor(acc[j], 32);
-  }
-  if (rsel == 0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[wave * D + sub * 8 + j] = acc[j];
-  }
-  __syncthreads();
-  if (threadIdx.x < D) {
-    const float v = (red[threadIdx.x] + red[D + threadIdx.x] + red[2 * D + threadIdx.x] + red[3 * D + threadIdx.x]) * inv;
-    out[((size_t)b * nh + h) * D + threadIdx.x] = (half_t)v;
-  }
-}
-
-// Single-pass form of the kernel above (online softmax): K and V rows of a batch are requested together and consumed in
+// Online softmax: K and V rows of a batch are requested together and consumed in
 // one sweep, every (wave, 16-lane row slot) keeps its own running (max, sum, 8 output dims per lane) and the 16 slots of
-// the workgroup are merged once at the end -- one barrier in the whole kernel instead of five, and no separate "all K,
-// then all V" phases (which, with every workgroup of a large batch starting at once, left HBM idle about half the
-// time: 3.9 TB/s at bs=64 [r01]).
+// the workgroup are merged once at the end -- one barrier in the whole kernel.  (The first version of this kernel made two
+// passes -- all scores into LDS, softmax, then all V -- with five barriers; with every workgroup of a large batch starting at
+// once its "all K, then all V" phases left HBM idle about half the time, 3.9 TB/s at bs=64, and the single pass is ahead at
+// every batch size: +8 % decode tok/s at bs=1, +1 % at bs=32, +0.5 % at bs=64..128 [r01].)
 __global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
     const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t, const half_t* __restrict__ sin_t,
     const long* __restrict__ pos, half_t* __restrict__ k_cache, half_t* __restrict__ v_cache, half_t* __restrict__ out,
@@ -649,8 +549,6 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
                                     void* k_cache, void* v_cache, void* out, int batch, int n_heads, int n_kv_heads,
                                     int head_dim, int cache_len, float scale, void* hip_stream) {
   if (batch <= 0 || head_dim != 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_UNSUPPORTED;
-  const size_t lds = (((size_t)cache_len + 3) & ~(size_t)3) * 4 + 4 * 128 * 4 + 128 * 4;
-  if (lds > 64 * 1024) return QUICK_ERR_UNSUPPORTED;
 #define QA_GQA(GROUP, UNR, GSPLIT)                                                                                 \
   hipLaunchKernelGGL((decode_rope_attention_gqa_kernel<GROUP, UNR>), dim3(n_kv_heads * (GSPLIT), batch), dim3(256), 0, \
                      (hipStream_t)hip_stream, (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, \
@@ -671,15 +569,7 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
     if (done) return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
   }
 #undef QA_GQA
-  // single-pass kernel while the launch is latency-bound (+8 % decode tok/s at bs=1, +5 % at bs=8 [r01]); from ~1000
-  // workgroups on the two-pass kernel is 0.5-1 % ahead
-  if (batch * n_heads < 1024) {
-    hipLaunchKernelGGL(decode_rope_attention_flash_kernel, dim3(n_heads, batch), dim3(256), 0, (hipStream_t)hip_stream,
-                       (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, (const long*)pos,
-                       (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads, cache_len, scale);
-    return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL(decode_rope_attention_kernel, dim3(n_heads, batch), dim3(256), (unsigned)lds, (hipStream_t)hip_stream,
+  hipLaunchKernelGGL(decode_rope_attention_flash_kernel, dim3(n_heads, batch), dim3(256), 0, (hipStream_t)hip_stream,
                      (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, (const long*)pos,
                      (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads, cache_len, scale);
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
