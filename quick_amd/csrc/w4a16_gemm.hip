@@ -80,6 +80,10 @@ __device__ __forceinline__ bool splitk_arrive(unsigned* counter, int nslices, un
   return *lds_word != 0u;
 }
 
+}  // namespace quick_amd
+#include "w4a16_wide.hpp"
+namespace quick_amd {
+
 // ------------------------------------------------------------------------------------------------
 // skinny kernel: one workgroup owns 16 tokens x (NTW*16) channels for the whole K; its waves split K (and
 // blockIdx.z splits it further when the grid would not fill the chip).
@@ -1254,7 +1258,8 @@ static int fail(int code, const char* fmt, ...) {
 }
 
 struct Plan {
-  int kernel;  // QUICK_KERNEL_SKINNY / QUICK_KERNEL_TILED
+  int kernel;  // QUICK_KERNEL_SKINNY / QUICK_KERNEL_TILED / QUICK_KERNEL_WIDE
+  int wide_mb, wide_pairs;  // wide: token tiles of 32 per workgroup, 32-channel pairs per wave
   int mt;      // skinny: channel tiles (of 16) per workgroup, NTW; tiled: token tiles per workgroup, BMT
   int waves;   // skinny: waves per workgroup
   bool xlds;   // skinny: x through an LDS copy
@@ -1320,7 +1325,34 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   const bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= 64);
   p.kernel = family == QUICK_KERNEL_AUTO ? (want_tiled ? QUICK_KERNEL_TILED : QUICK_KERNEL_SKINNY) : family;
   int ks = 1;
-  if (p.kernel == QUICK_KERNEL_SKINNY) {
+  if (p.kernel == QUICK_KERNEL_WIDE && (G % 128 != 0 && G != 64 && G != 32)) p.kernel = QUICK_KERNEL_TILED;  // odd group sizes
+  if (p.kernel == QUICK_KERNEL_WIDE) {
+    // bits 4-7: MB (token tiles of 32 per workgroup: 2, 4, 8), bits 8-11: PAIRS (32-channel pairs per wave: 1, 2); 0 = choose
+    int mb = mt_req, pairs = (kernel >> 8) & 15;
+    if (mb != 2 && mb != 4 && mb != 8) mb = M > 128 ? 8 : (M > 64 ? 4 : 2);
+    if (pairs != 1 && pairs != 2) pairs = 2;
+    if (N % (pairs * 128) != 0) pairs = 1;
+    p.wide_mb = mb;
+    p.wide_pairs = pairs;
+    p.waves = 4;
+    p.tch = pairs * 128;
+    const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / p.tch;
+    p.ntiles = MBk * NBk;
+    p.slab_floats = (size_t)mb * 32 * p.tch;
+    while (p.ntiles * ks * 2 <= 256 && KT / (ks * 2) >= 4) ks *= 2;
+    p.ksplit = std::max(1, std::min(grid_split_k > 0 ? grid_split_k : ks, KT));
+    p.kt_per_split = (KT + p.ksplit - 1) / p.ksplit;
+    long best = -1;
+    if (!((kernel >> 14) & 1) && (MBk * NBk) % 8 == 0)
+      for (int gm = 1; gm <= 8; gm *= 2) {
+        if (MBk % gm != 0 || NBk % (8 / gm) != 0) continue;
+        const long cost = (long)(MBk / gm) * 8 * mb + (long)(NBk * gm / 8) * (p.tch / 2);  // x rows + weight columns per XCD
+        if (best < 0 || cost < best) {
+          best = cost;
+          p.xcd_gm = gm;
+        }
+      }
+  } else if (p.kernel == QUICK_KERNEL_SKINNY) {
     const int mblocks = (M + 15) / 16;
     // channel tiles per workgroup ~ token blocks (weights are re-read per token block, x per channel block)
     int mt_auto = mblocks <= 1 ? 1 : (mblocks <= 2 ? 2 : 4);
@@ -1592,6 +1624,29 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
 #undef QA_TILED_K
 }
 
+template <int MB, int PAIRS>
+static void launch_wide(const Plan& p, const GemmArgs& a, const Launch& L) {
+  dim3 grid(p.ntiles, p.ksplit), block(256);
+  const unsigned lds = 2 * MB * 32 * 256;
+#define QA_WIDE_K(GMV)                                                                                             \
+  do {                                                                                                             \
+    auto kfn = w4a16_wide_kernel<MB, PAIRS, GMV>;                                                                  \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
+  } while (0)
+  switch (group_mode(a.G)) {
+    case 0: QA_WIDE_K(0); break;
+    case 1: QA_WIDE_K(1); break;
+    case 2: QA_WIDE_K(2); break;
+    default: QA_WIDE_K(3); break;
+  }
+#undef QA_WIDE_K
+}
+
 struct Fusion {
   const void* bias = nullptr;
   const void* residual = nullptr;
@@ -1605,7 +1660,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
                     const Launch& L) {
   if (int rc = check_shapes(M, K, N, G)) return rc;
   if (!x || !qweight || !scales || !qzeros || !y) return fail(QUICK_ERR_INVALID_ARGUMENT, "null tensor pointer");
-  if ((kernel & 15) > QUICK_KERNEL_TILED || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+  if ((kernel & 15) > QUICK_KERNEL_WIDE || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
   const Plan p = make_plan(M, K, N, G, kernel, grid_split_k);
   if (f.silu_mul && (f.bias || f.residual)) return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual");
   if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
@@ -1622,7 +1677,18 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     a.counters = (unsigned*)workspace;  // zero on entry (caller's contract), zero again when the launch completes
     a.slabs = (float*)((char*)workspace + counters_bytes(p));
   }
-  if (p.kernel == QUICK_KERNEL_SKINNY) {
+  if (p.kernel == QUICK_KERNEL_WIDE) {
+    if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
+    const int sel = p.wide_mb * 10 + p.wide_pairs;
+    switch (sel) {
+      case 21: launch_wide<2, 1>(p, a, L); break;
+      case 22: launch_wide<2, 2>(p, a, L); break;
+      case 41: launch_wide<4, 1>(p, a, L); break;
+      case 42: launch_wide<4, 2>(p, a, L); break;
+      case 81: launch_wide<8, 1>(p, a, L); break;
+      default: launch_wide<8, 2>(p, a, L); break;
+    }
+  } else if (p.kernel == QUICK_KERNEL_SKINNY) {
     switch (p.mt) {
       case 1: launch_skinny<1>(p, a, L); break;
       case 2: launch_skinny<2>(p, a, L); break;
@@ -1703,6 +1769,9 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
     snprintf(text, text_bytes, "skinny ntw=%d waves=%d x=%s dequant=%s grid=%dx%dx%d ksplit=%d workspace=%zu", p.mt, p.waves,
              p.xlds ? "lds" : "l2", p.dz ? (p.xlds ? "deferred-zero-table" : "deferred-zero-fragment") : "exact", p.grid_x,
              (M + 15) / 16, p.ksplit, p.ksplit, workspace_need(p));
+  else if (p.kernel == QUICK_KERNEL_WIDE)
+    snprintf(text, text_bytes, "wide tokens=%d channels=%d waves=4 grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
+             p.tch, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
   else
     snprintf(text, text_bytes, "tiled tokens=%d channels=%d waves=%d grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.mt * 16,
              p.tch, p.wn2 ? 8 : p.waves, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));

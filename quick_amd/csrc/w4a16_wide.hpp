@@ -1,0 +1,304 @@
+// "Wide" W4A16 kernel for large M on MI355X (gfx950): v_mfma_f32_32x32x16_f16, ONE wave per SIMD with the whole
+// 512-entry register file (accumulators in AGPRs), activations by LDS-DMA, weights HBM -> VGPR -> matrix core.
+//
+// Why a second large-M kernel (r01's w4a16_tiled_kernel stays for small token counts): the cost of this GEMM on the
+// matrix core's side is fixed, the cost on the VALU side -- 13 packed-f16 ops per packed dword -- is paid once per
+// (weight, wave), so VALU ops per MFMA fall with the number of TOKENS a wave owns.  A 16-cycle 16x16x32 MFMA hides no
+// VALU work of its own wave (tools/mfma_valu_overlap.hip); a 32-cycle 32x32x16 hides ~5 issue slots
+// (MI355X_MICROARCH.md, "one wave per SIMD").  So: 4 waves per workgroup, all along N, each wave owning ALL the
+// workgroup's MB*32 tokens x PAIRS*32 channels; 13 / MB VALU ops per MFMA (1.6 at MB = 8), no weight dequantised twice
+// in a workgroup, MB*PAIRS*16 accumulator registers (256 at MB = 8, PAIRS = 2).
+//
+// Operands of v_mfma_f32_32x32x16_f16 (A = 32 channels x 16 k, B = 16 k x 32 tokens, lane l = (rho = l % 32, h = l / 32)):
+//   A: lane holds channel rho, k = 8 h .. 8 h + 7 of the k16 step.  The HBM weight layout is unchanged ("mi355x order":
+//      a 16-channel x 128-k tile is 1 KiB, byte 16 * (c + 16 q) holds the dwords t = 0..3 of channel c, k = 32 t + 8 q + j):
+//      lane (rho, h) loads 16 bytes at [tile rho / 16][c = rho % 16, q = h] ("lo") and at q = 2 + h ("hi", +512 B); dword t of
+//      lo / hi is the A operand of k16 step 2 t / 2 t + 1.  No lane shuffles; every 16-lane group reads 256 contiguous bytes.
+//   B: lane holds token rho, k = 8 h .. + 7.  A stage (128 k) of the token tile lives in LDS ROW-MAJOR, 256 B per token,
+//      16-byte chunk c of row r stored at chunk c ^ (r % 16): ds_read_b128 of a fragment is conflict-free, and the image is
+//      filled by buffer_load_dwordx4 ... lds (LDS-DMA: no staging registers, no ds_write) in full 256-byte row segments,
+//      the swizzle applied to the per-lane SOURCE address (the LDS side of an LDS-DMA is lane-linear).
+//   C/D: lane holds token rho and channels (r % 4) + 8 (r / 4) + 4 h, r = 0..15, of the 32-channel pair.
+//
+// Pipeline: two LDS stage buffers and two weight register sets.  Iteration s issues the LDS-DMA of stage s + 1 and the
+// weight loads of stage s + 1, computes stage s (8 k16 steps), then waits vmcnt(0) -- for loads issued a whole stage
+// earlier -- and crosses ONE barrier.  The LDS-DMA is inline asm on purpose: hipcc makes every ds_read wait for every
+// LDS-DMA it knows about; the compiler-visible s_waitcnt builtin before the barrier also tells its waitcnt pass that the
+// weight prefetch has landed, so it adds no counted wait of its own (which the LDS-DMAs in flight would turn into a drain).
+#pragma once
+
+namespace quick_amd {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// 64 lanes x 16 bytes: global (descriptor base + voff + soff) -> LDS (lds_addr + 16 * lane).  M0 carries the LDS
+// address and is written in the statement that uses it (hipcc reserves M0 and does not preserve it across asm).
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc),
+               "s"(soff)
+               : "memory");
+}
+
+template <int PAIRS, int GM>
+struct WideW {  // one 128-k tile of this wave's weights: per 32-channel pair the lo / hi dwordx4 and the raw (scale, zero) words
+  u32x4 lo[PAIRS], hi[PAIRS];
+  uint32_t sz[PAIRS][groups_per_tile<GM>()];
+};
+
+struct WideBufs {
+  __amdgpu_buffer_rsrc_t x, w, s;
+  unsigned x_voff, w_voff, s_voff;
+  unsigned x_istride;   // bytes between the rows of consecutive LDS-DMA instructions of a wave: 16 rows
+  unsigned w_pstride;   // bytes between consecutive 32-channel pairs of the weights
+  unsigned s_pstride;   // ... of the (scale, zero point) words
+};
+
+template <int PAIRS, int GM>
+__device__ __forceinline__ void wide_load_w(WideW<PAIRS, GM>& w, const WideBufs& b, int kt, const GemmArgs& a) {
+  constexpr int NG = groups_per_tile<GM>();
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    const unsigned so = (unsigned)p * b.w_pstride + (unsigned)kt * 1024u;
+    w.lo[p] = __builtin_amdgcn_raw_buffer_load_b128(b.w, b.w_voff, so, 0);
+    w.hi[p] = __builtin_amdgcn_raw_buffer_load_b128(b.w, b.w_voff + 512u, so, 0);
+  }
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const unsigned g = (unsigned)group_index<GM>(kt, i * (4 / NG), a.tpg, a.G);
+      w.sz[p][i] = __builtin_amdgcn_raw_buffer_load_b32(b.s, b.s_voff, (unsigned)p * b.s_pstride + g * 64u, 0);
+    }
+}
+
+// stage (128 k) kt of the token tile -> LDS buffer at lds_addr: MB * 2 instructions per wave, 4 rows x 256 B each
+template <int MB>
+__device__ __forceinline__ void wide_issue_x(const WideBufs& b, int kt, unsigned lds_addr) {
+#pragma unroll
+  for (int i = 0; i < MB * 2; ++i) lds_dma16(b.x, b.x_voff, (unsigned)i * b.x_istride + (unsigned)kt * 256u, lds_addr + i * 4096);
+}
+
+// dequant8 (w4a16_common.hpp) without inline asm: the masks live in SGPRs and the magic number in a VGPR the compiler
+// cannot see through, so (q & mask) | magic selects v_and_or_b32 on its own -- no asm statement boundaries, hence none of
+// the s_nop hipcc pads them with (56 per 128 MFMAs in the first build of this kernel) and free scheduling.
+struct DqConsts {
+  uint32_t mlo, mhi, magic;
+};
+__device__ __forceinline__ DqConsts make_dq_consts() {
+  DqConsts d{0x000f000fu, 0x00f000f0u, 0x64006400u};
+  asm volatile("" : "+s"(d.mlo), "+s"(d.mhi));
+  asm volatile("" : "+v"(d.magic));
+  return d;
+}
+__device__ __forceinline__ half8_t dequant8(uint32_t q, const GroupQ& g, const DqConsts& d) {
+  const half2_t sixteenth = {(half_t)0.0625f, (half_t)0.0625f};
+  const uint32_t q8 = q >> 8;
+  const half2_t h0 = (as_h2((q & d.mlo) | d.magic) + g.nzlo) * g.s2;               // k0, k1
+  const half2_t h1 = (as_h2((q & d.mhi) | d.magic) * sixteenth + g.nzhi) * g.s2;   // k2, k3
+  const half2_t h2 = (as_h2((q8 & d.mlo) | d.magic) + g.nzlo) * g.s2;              // k4, k5
+  const half2_t h3 = (as_h2((q8 & d.mhi) | d.magic) * sixteenth + g.nzhi) * g.s2;  // k6, k7
+  half8_t r;
+  r[0] = h0[0]; r[1] = h0[1]; r[2] = h1[0]; r[3] = h1[1];
+  r[4] = h2[0]; r[5] = h2[1]; r[6] = h3[0]; r[7] = h3[1];
+  return r;
+}
+
+// One stage = 8 k16 steps x PAIRS "units"; unit u = (k16 step kk, pair p) is MB MFMAs sharing one dequantised A fragment.
+// Software pipeline inside the stage: while the MFMAs of unit u run, the VALU dequantises the fragment of unit u + 1 and
+// (p == 0) the LDS returns the B fragments of step kk + 1.  sched_group_barrier spells the interleave out -- one MFMA,
+// then its share of the VALU ops and one ds_read -- because hipcc otherwise emits "13 VALU, then MB MFMAs back to back":
+// an in-order wave issues the VALU block only after the last MFMA of the unit has issued, i.e. mostly in the open.
+template <int MB, int PAIRS, int GM>
+__device__ __forceinline__ void wide_compute(const WideW<PAIRS, GM>& w, unsigned xb, const DqConsts& dq, floatx16 (&acc)[PAIRS][MB]) {
+  typedef const __attribute__((address_space(3))) char* lds_ptr;
+  constexpr int NG = groups_per_tile<GM>();
+  constexpr int NU = 8 * PAIRS;
+  constexpr int VPM = (14 + MB - 1) / MB;  // VALU ops placed behind each MFMA (13 per fragment + the address xor)
+  GroupQ grp[PAIRS][NG];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+    for (int i = 0; i < NG; ++i) grp[p][i] = make_group(GroupRaw{w.sz[p][i]}, LaneSel{});
+  half8_t bf[2][MB], af[2];
+  auto read_frags = [&](int kk, half8_t (&f)[MB]) {
+    const lds_ptr xk = (lds_ptr)(uintptr_t)(xb ^ (unsigned)(kk << 5));  // chunk (2 kk + h) ^ (rho % 16) of this lane's row
+#pragma unroll
+    for (int mt = 0; mt < MB; ++mt) f[mt] = *(const __attribute__((address_space(3))) half8_t*)(xk + mt * 8192);
+  };
+  auto frag = [&](int u) {
+    const int kk = u / PAIRS, p = u % PAIRS;
+    const uint32_t q = (kk & 1) ? w.hi[p][kk >> 1] : w.lo[p][kk >> 1];
+    return dequant8(q, grp[p][group_slot<GM>(kk >> 1)], dq);
+  };
+  read_frags(0, bf[0]);
+  af[0] = frag(0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int kk = u / PAIRS, p = u % PAIRS;
+    const bool reads = p == 0 && kk < 7;
+    if (u + 1 < NU) af[(u + 1) & 1] = frag(u + 1);
+    if (reads) read_frags(kk + 1, bf[(kk + 1) & 1]);
+#pragma unroll
+    for (int mt = 0; mt < MB; ++mt) acc[p][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u & 1], bf[kk & 1][mt], acc[p][mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MB; ++mt) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // MFMA
+      if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);  // VALU
+      if (reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Workgroup tile (MB*32 tokens) x (PAIRS*128 channels), 4 waves along N.  Grid: x = tiles (XCD-aware order), y = K slices.
+template <int MB, int PAIRS, int GM>
+__global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
+  constexpr int STAGE_BYTES = MB * 32 * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE_BYTES
+
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int rho = lane & 31, h = lane >> 5;
+  const int NB = a.N / (PAIRS * 128);
+  int nb = blockIdx.x % NB, mb = blockIdx.x / NB;
+  if (a.xcd_gm > 0) {  // see w4a16_tiled_kernel: every XCD gets a compact rectangle of tiles
+    const int MBk = gridDim.x / NB, gn = 8 / a.xcd_gm;
+    const int mcnt = MBk / a.xcd_gm, ncnt = NB / gn;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    mb = (xcd / gn) * mcnt + idx / ncnt;
+    nb = (xcd % gn) * ncnt + idx % ncnt;
+  }
+  const int ks = blockIdx.y;
+  const int KT = a.K >> 7, NGRP = a.K / a.G;
+  const int kt_lo = ks * a.kt_per_split, kt_hi = min(KT, kt_lo + a.kt_per_split);
+  const int nstage = kt_hi - kt_lo;
+  const int m0 = mb * MB * 32;
+  const int ct0 = (nb * 4 + wave) * PAIRS * 2;  // first 16-channel tile of this wave
+
+  WideBufs b;
+  {
+    const unsigned rows = (unsigned)min(a.M - m0, MB * 32);  // rows past M read as zeros (buffer bounds) and are never stored
+    const unsigned xrow = 4u * (unsigned)wave + ((unsigned)lane >> 4);
+    b.x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (size_t)m0 * a.K), 0, rows * (unsigned)a.K * 2u, 0x00020000);
+    b.x_voff = xrow * (unsigned)a.K * 2u + 16u * (((unsigned)lane & 15u) ^ xrow);
+    b.x_istride = 16u * (unsigned)a.K * 2u;
+    b.w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.QW + (size_t)ct0 * KT * 64), 0, (unsigned)(2 * PAIRS) * (unsigned)KT * 1024u, 0x00020000);
+    b.w_voff = ((unsigned)rho >> 4) * (unsigned)KT * 1024u + 16u * (((unsigned)rho & 15u) + 16u * (unsigned)h);
+    b.w_pstride = 2u * (unsigned)KT * 1024u;
+    b.s = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint32_t*)a.S + (size_t)ct0 * NGRP * 16), 0, (unsigned)(2 * PAIRS) * (unsigned)NGRP * 64u, 0x00020000);
+    b.s_voff = ((unsigned)rho >> 4) * (unsigned)NGRP * 64u + 4u * ((unsigned)rho & 15u);
+    b.s_pstride = 2u * (unsigned)NGRP * 64u;
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lds0 = lds_base + (unsigned)wave * 1024u;  // LDS-DMA destination of this wave's first instruction: rows 4 w .. 4 w + 3
+  // B-fragment read address of this lane in stage buffer 0, token tile 0, k16 step 0: row rho, chunk h ^ (rho % 16)
+  const unsigned xrd = lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4);
+
+  floatx16 acc[PAIRS][MB];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+    for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][mt][r] = 0.f;
+
+  // Straight-line loop body on purpose: with control flow around the MFMAs hipcc carries the accumulators through the
+  // loop in VGPRs and copies them to AGPRs and back every iteration (and then spills).  So the weight "double buffer" is a
+  // register copy at the end of the stage (18 moves per 128-k stage), and the last iteration issues its prefetch anyway --
+  // a replay of the last stage into the other LDS buffer, which nobody reads.
+  const DqConsts dq = make_dq_consts();
+  WideW<PAIRS, GM> wc, wn;
+  if (nstage > 0) {
+    wide_issue_x<MB>(b, kt_lo, lds0);
+    wide_load_w<PAIRS, GM>(wc, b, kt_lo, a);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __builtin_amdgcn_s_barrier();
+
+  for (int s = 0; s < nstage; ++s) {
+    const int ktn = min(kt_lo + s + 1, kt_hi - 1);
+    const unsigned par = (unsigned)(s & 1);
+    wide_issue_x<MB>(b, ktn, lds0 + (par ^ 1u) * STAGE_BYTES);
+    wide_load_w<PAIRS, GM>(wn, b, ktn, a);
+    __builtin_amdgcn_sched_barrier(0);
+    wide_compute<MB, PAIRS, GM>(wc, xrd + par * STAGE_BYTES, dq, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // stage s + 1 has landed (LDS-DMA and weights) ...
+    __builtin_amdgcn_s_barrier();        // ... in every wave, and everybody is done reading stage s
+    wc = wn;
+  }
+
+  // ---- K split across workgroups: slab = [(p, mt, c)][wave][lane] floatx4
+  if (a.ksplit > 1) {
+    constexpr unsigned SLAB_BYTES = PAIRS * MB * 16384;
+    const __amdgpu_buffer_rsrc_t rs = slab_rsrc(a.slabs + (size_t)blockIdx.x * a.ksplit * (SLAB_BYTES / 4), a.ksplit * SLAB_BYTES);
+    const unsigned my = ((unsigned)wave * 64u + (unsigned)lane) * 16u;
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+      for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          slab_store(rs, ks * SLAB_BYTES + ((p * MB + mt) * 4 + c) * 4096 + my,
+                     floatx4{acc[p][mt][4 * c], acc[p][mt][4 * c + 1], acc[p][mt][4 * c + 2], acc[p][mt][4 * c + 3]});
+    if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
+    // every slice is read back from its slab (the own one too) and added in index order: the sum does not depend on
+    // who arrived last, and no second copy of the accumulators is needed
+    for (int o = 0; o < a.ksplit; ++o) {
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+        for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const floatx4 part = slab_load(rs, o * SLAB_BYTES + ((p * MB + mt) * 4 + c) * 4096 + my);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[p][mt][4 * c + r] = o == 0 ? part[r] : acc[p][mt][4 * c + r] + part[r];
+          }
+    }
+  }
+
+  // ---- epilogue: lane = token m0 + 32 mt + rho, channels ch0 + 32 p + 8 c + 4 h .. + 3 (c = r / 4)
+  const int ch0 = ct0 * 16;
+  if (a.silu_mul) {  // gate / up interleaved by 8: c = 0, 2 gate of the two 16-channel tiles, c = 1, 3 their up
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+      for (int mt = 0; mt < MB; ++mt) {
+        const int m = m0 + mt * 32 + rho;
+        if (m < a.M) {
+#pragma unroll
+          for (int c = 0; c < 4; c += 2) {
+            half4_t o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = silu_mul_f16((half_t)acc[p][mt][4 * c + r], (half_t)acc[p][mt][4 * c + 4 + r]);
+            *(half4_t*)(a.Y + (size_t)m * (a.N >> 1) + ((ch0 + 32 * p) >> 1) + 4 * c + 4 * h) = o;
+          }
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int nc = ch0 + 32 * p + 8 * c + 4 * h;
+      half4_t bv = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+      if (a.bias) bv = *(const half4_t*)(a.bias + nc);
+#pragma unroll
+      for (int mt = 0; mt < MB; ++mt) {
+        const int m = m0 + mt * 32 + rho;
+        if (m < a.M) {
+          half4_t res = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+          if (a.residual) res = *(const half4_t*)(a.residual + (size_t)m * a.N + nc);
+          half4_t o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[p][mt][4 * c + r] + (float)bv[r] + (float)res[r]);
+          *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
+        }
+      }
+    }
+}
+
+}  // namespace quick_amd

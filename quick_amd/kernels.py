@@ -3,6 +3,7 @@
 torch; the arithmetic is entirely in the HIP library -- there is no CPU / eager fallback.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -81,8 +82,23 @@ def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=
     if kernel.shape[0] * 4 != K:
         raise ValueError(f"kernel has {kernel.shape[0] * 4} input channels, in_feats has {K}")
     G = K // scaling_factors.shape[0]                 # gemm_cuda_quick.cu:1477
+    # the library takes raw pointers: everything it will dereference is checked here (dtype, device, contiguity, shape)
+    if tuple(scaling_factors.shape) != (K // G, 2 * N) or tuple(zeros.shape) != (K // G, N // 4):
+        raise ValueError(f"scaling_factors / zeros must be [{K // G}, {2 * N}] / [{K // G}, {N // 4}] for K={K} N={N} G={G}, "
+                         f"got {tuple(scaling_factors.shape)} / {tuple(zeros.shape)}")
+    n_out = N // 2 if silu_mul else N
+    for t, shape, name in ((out, (M, n_out), "out"), (bias, (N,), "bias"), (residual, (M, N), "residual"),
+                           (rmsnorm_weight, (K,), "rmsnorm_weight")):
+        if t is None:
+            continue
+        _expect(t, torch.float16, name)
+        if tuple(t.shape) != shape or t.device != in_feats.device:
+            raise ValueError(f"{name} must be a {list(shape)} fp16 tensor on {in_feats.device}, got {list(t.shape)} on {t.device}")
+    for t, name in ((kernel, "kernel"), (scaling_factors, "scaling_factors"), (zeros, "zeros")):
+        if t.device != in_feats.device:
+            raise RuntimeError(f"{name} is on {t.device}, in_feats on {in_feats.device}")
     if out is None:
-        out = torch.empty((M, N // 2 if silu_mul else N), dtype=torch.float16, device=in_feats.device)
+        out = torch.empty((M, n_out), dtype=torch.float16, device=in_feats.device)
     if M == 0:
         return out
     with torch.cuda.device(in_feats.device):          # OptionalCUDAGuard, gemm_cuda_quick.cu:1465
@@ -101,18 +117,66 @@ def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=
     return out
 
 
-def gemm_forward_cuda_quick(in_feats, kernel, scaling_factors, zeros, split_k_iters):
-    """Drop-in for ``quick_kernels.gemm_forward_cuda_quick`` (csrc/gemm_cuda_quick.h:3-8).
+def _tensor_version(t):
+    return 0 if t.is_inference() else t._version     # inference tensors have no version counter (and cannot be rewritten in place outside inference mode)
 
-    Same arguments, dtypes and error behaviour; ``kernel`` / ``scaling_factors`` / ``zeros`` are the
-    module buffers in MI355X order (what ``WQLinear_QUICK`` holds after ``prepare()``).  Return shape
-    follows the reference: ``[M, N]`` when ``split_k_iters > 1`` (its ``.sum(0)``), ``[1, M, N]`` otherwise
-    (gemm_cuda_quick.cu:1515-1516).  ``split_k_iters`` is a tuning hint for NVIDIA parts; this library
-    chooses its own K partitioning and always returns the fully reduced result.
+
+class _Repacked:
+    __slots__ = ("refs", "versions", "packed")
+
+
+_REPACK_CACHE = {}     # (data_ptr of qweight, scales, qzeros) -> _Repacked; entries die with the tensors they mirror
+
+
+def reference_to_mi355x_cached(kernel, scaling_factors, zeros):
+    """MI355X-order copies of reference-order packed tensors, made once per tensor triple by the HIP repack kernel.
+
+    This is what lets the reference's own ``WQLinear_QUICK.forward`` (quick/awq/modules/linear/quick.py:158-166), whose
+    buffers hold the checkpoint order of ``from_linear`` (quick.py:88-150), call this library unchanged.  The entry is
+    keyed on the identity (weak references) and version counters of the three tensors: an in-place rewrite
+    (``load_state_dict``, ``copy_``) or a new tensor object invalidates it, and it is dropped when a tensor dies.  Cost: a
+    second copy of the layer's packed weights in HBM -- ``quick_amd.WQLinear_QUICK`` avoids it by permuting its own
+    buffers in place and calling :func:`gemm_forward` directly.
+    """
+    tensors = (kernel, scaling_factors, zeros)
+    key = tuple(t.data_ptr() for t in tensors)
+    versions = tuple(_tensor_version(t) for t in tensors)
+    ent = _REPACK_CACHE.get(key)
+    if ent is not None and ent.versions == versions and all(r() is t for r, t in zip(ent.refs, tensors)):
+        return ent.packed
+    ent = _Repacked()
+    ent.packed = repack_cuda_to_mi355x(kernel, scaling_factors, zeros)
+    ent.versions = versions
+    drop = lambda _ref, key=key: _REPACK_CACHE.pop(key, None)
+    ent.refs = tuple(weakref.ref(t, drop) for t in tensors)
+    _REPACK_CACHE[key] = ent
+    return ent.packed
+
+
+def gemm_forward_cuda_quick(in_feats, kernel, scaling_factors, zeros, split_k_iters):
+    """Drop-in for ``quick_kernels.gemm_forward_cuda_quick`` (csrc/gemm_cuda_quick.h:3-8, csrc/pybind.cpp:5-8).
+
+    Same arguments, dtypes, error behaviour and -- like the reference -- the REFERENCE's packed order: ``kernel`` /
+    ``scaling_factors`` / ``zeros`` are what ``WQLinear_QUICK.from_linear`` of the reference writes and what its
+    checkpoints hold (quick.py:88-150), so the reference's unchanged module can call it.  The MI355X-order copy the HIP
+    kernels consume is made on first use and cached (:func:`reference_to_mi355x_cached`).  Return shape follows the
+    reference: ``[M, N]`` when ``split_k_iters > 1`` (its ``.sum(0)``), ``[1, M, N]`` otherwise
+    (gemm_cuda_quick.cu:1515-1516).  ``split_k_iters`` is a tuning hint for NVIDIA parts; this library chooses its own K
+    partitioning and always returns the fully reduced result.
     """
     if split_k_iters < 1:
         raise ValueError("split_k_iters must be >= 1")
-    out = gemm_forward(in_feats, kernel, scaling_factors, zeros)
+    _expect(in_feats, torch.float16, "in_feats")
+    _expect(kernel, torch.int32, "kernel")
+    _expect(scaling_factors, torch.float16, "scaling_factors")
+    _expect(zeros, torch.int32, "zeros")
+    if in_feats.dim() != 2:
+        raise RuntimeError("in_feats must be 2-D [M, K]")
+    K, N = kernel.shape[0] * 4, kernel.shape[1] // 4 * 8       # gemm_cuda_quick.cu:1468
+    if in_feats.shape[1] != K:
+        raise ValueError(f"kernel has {K} input channels, in_feats has {in_feats.shape[1]}")
+    plan_describe(max(int(in_feats.shape[0]), 1), K, N, K // scaling_factors.shape[0])   # the reference's shape errors, before any repack
+    out = gemm_forward(in_feats, *reference_to_mi355x_cached(kernel, scaling_factors, zeros))
     return out if split_k_iters > 1 else out.unsqueeze(0)
 
 

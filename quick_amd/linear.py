@@ -20,6 +20,25 @@ import torch.nn as nn
 from . import kernels, packing
 
 
+class _Layout:
+    """Which order the packed buffers of a ``WQLinear_QUICK`` hold.  ``prepared`` is the fact; ``key`` (identity and
+    version of the three storages) is how a rewrite from outside is noticed.  Copies and pickles of a module carry the
+    fact and re-key themselves on first use -- their buffers are new storages holding the same bits."""
+    __slots__ = ("prepared", "key")
+
+    def __init__(self, prepared=False, key=None):
+        self.prepared, self.key = prepared, key
+
+    def __deepcopy__(self, memo):
+        return _Layout(self.prepared, None)
+
+    def __getstate__(self):
+        return {"prepared": self.prepared}
+
+    def __setstate__(self, state):
+        self.prepared, self.key = state["prepared"], None
+
+
 class WQLinear_QUICK(nn.Module):
     def __init__(self, w_bit, group_size, in_features, out_features, bias, dev, k_split_1=2, k_split_2=8):
         super().__init__()
@@ -41,20 +60,29 @@ class WQLinear_QUICK(nn.Module):
             self.register_buffer("bias", torch.zeros((out_features), dtype=torch.float16, device=dev))
         else:
             self.bias = None
-        self._mi355x_key = None
+        self._layout = _Layout()
 
     # ---------------------------------------------------------------- layout tracking
     def _key(self):
-        return tuple((t.data_ptr(), t._version, t.device) for t in (self.qweight, self.scales, self.qzeros))
+        # (inference tensors -- anything made under torch.inference_mode(), which is how the reference runs every forward,
+        # quick/awq/modules/fused/model.py:76, examples/benchmark.py:45 -- have no version counter)
+        return tuple((t.data_ptr(), 0 if t.is_inference() else t._version, t.device) for t in (self.qweight, self.scales, self.qzeros))
 
     @property
     def is_prepared(self):
         """True when the buffers currently hold MI355X order."""
-        return self._mi355x_key is not None and self._mi355x_key == self._key()
+        lay = self._layout
+        if not lay.prepared:
+            return False
+        if lay.key is None:                 # a copy / unpickled module: same bits in new storages
+            lay.key = self._key()
+        elif lay.key != self._key():        # rewritten from outside: reference order again
+            lay.prepared, lay.key = False, None
+        return lay.prepared
 
     def _set_packed(self, qweight, scales, qzeros, prepared):
         self.qweight, self.scales, self.qzeros = qweight, scales, qzeros
-        self._mi355x_key = self._key() if prepared else None
+        self._layout = _Layout(prepared, self._key() if prepared else None)
 
     def prepare(self):
         """Permute reference-order buffers into MI355X order (HIP repack kernels on the GPU)."""
@@ -78,7 +106,7 @@ class WQLinear_QUICK(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         was = self.is_prepared
         super()._apply(fn, *args, **kwargs)
-        self._mi355x_key = self._key() if was else None   # .to()/.cuda() move bits, they do not reorder them
+        self._layout = _Layout(was, self._key() if was else None)   # .to()/.cuda() move bits, they do not reorder them
         return self
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):

@@ -45,7 +45,8 @@ GOLD = [p for p in golden_files("exact_") if "k64" not in p] + golden_files("qua
 
 
 @pytest.mark.parametrize("kernel_id,ksplit", [(0, 0), (SKINNY_DZ, 1), (SKINNY_DZ, 2), (SKINNY_EXACT, 1), (SKINNY_EXACT, 2),
-                                              (TILED, 1), (TILED, 2)])
+                                              (TILED, 1), (TILED, 2), (3, 1), (3, 2), (3 | (8 << 4) | (2 << 8), 1),
+                                              (3 | (4 << 4) | (1 << 8), 2)])
 @pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[:-4])
 def test_golden_fixture_forward(qa, device, path, kernel_id, ksplit):
     g = load_golden(path)
@@ -107,9 +108,17 @@ TILED_MFMA32 = TILED | (1 << 13)      # experimental 32x32x16 flavour of the til
 TILED_16WAVES = TILED | (4 << 8)      # 4 x 4 waves per workgroup
 TILED_WIDE = TILED | (1 << 29)        # 64 x 256 workgroup tiles (the planner's choice once they cover the 256 CUs: large M)
 TILED_BIG = TILED | (1 << 27)         # 128 x 256 tiles run by four waves with 128 accumulators each (large M)
+WIDE = 3                              # 32x32x16 MFMA kernel, one wave per SIMD, activations by LDS-DMA (large M)
 
 
-@pytest.mark.parametrize("kernel_id", [0, SKINNY_DZ, SKINNY_EXACT, TILED, TILED_MFMA32, TILED_16WAVES, TILED_WIDE, TILED_BIG])
+def wide(mb, pairs):                  # explicit workgroup tile: mb * 32 tokens x pairs * 128 channels
+    return WIDE | (mb << 4) | (pairs << 8)
+
+
+WIDE_IDS = [WIDE] + [wide(mb, pairs) for mb in (2, 4, 8) for pairs in (1, 2)]
+
+
+@pytest.mark.parametrize("kernel_id", [0, SKINNY_DZ, SKINNY_EXACT, TILED, TILED_MFMA32, TILED_16WAVES, TILED_WIDE, TILED_BIG] + WIDE_IDS)
 @pytest.mark.parametrize("M,K,N,G", SHAPES)
 def test_synthetic_sweep(qa, device, M, K, N, G, kernel_id):
     x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M * 7 + K + N + G)

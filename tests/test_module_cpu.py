@@ -217,3 +217,71 @@ def test_quantize_module_linears_replaces_and_skips():
     assert isinstance(m["lm_head"], torch.nn.Linear)
     with pytest.raises(ValueError):
         quantize_module_linears(torch.nn.ModuleDict({"x": torch.nn.Linear(192, 128)}), 4, 128)
+
+
+# ------------------------------------------------------------------------------------------------
+# layout tracking: inference mode, copies, pickles
+# ------------------------------------------------------------------------------------------------
+def _reference_checkpoint_module():
+    g = load_golden(golden_files("exact_k128n256")[0])
+    m = WQLinear_QUICK(4, int(g["G"]), int(g["K"]), int(g["N"]), False, "cpu")
+    m.load_state_dict({"qweight": _t(g["ref_qweight"]), "scales": _t(g["ref_qscales"]), "qzeros": _t(g["ref_qzeros"])})
+    return g, m
+
+
+def test_prepare_inside_inference_mode():
+    """The reference runs every forward under torch.inference_mode() (quick/awq/modules/fused/model.py:76,
+    examples/benchmark.py:45): the lazy prepare() of the first forward then creates inference tensors, which have no
+    version counter."""
+    g, m = _reference_checkpoint_module()
+    assert not m.is_prepared
+    with torch.inference_mode():
+        m.prepare()
+        assert m.is_prepared
+        assert m.qweight.is_inference()
+    assert m.is_prepared                                                # ... and still outside
+    sd = m.state_dict()
+    assert np.array_equal(sd["qweight"].numpy(), g["ref_qweight"])
+    # a module CREATED under inference mode, loaded there too
+    with torch.inference_mode():
+        m2 = WQLinear_QUICK(4, int(g["G"]), int(g["K"]), int(g["N"]), False, "cpu")
+        m2.load_state_dict({k: v.clone() for k, v in sd.items()})
+        assert not m2.is_prepared
+        m2.prepare()
+        assert m2.is_prepared and torch.equal(m2.qweight, m.qweight)
+
+
+def test_deepcopy_and_pickle_keep_the_layout():
+    import copy
+    import io
+    g, m = _reference_checkpoint_module()
+    m.prepare()
+    for clone in (copy.deepcopy(m), torch.load(io.BytesIO(_save_bytes(m)), weights_only=False)):
+        assert clone.qweight.data_ptr() != m.qweight.data_ptr()
+        assert clone.is_prepared                                        # same MI355X-order bits in new storages
+        assert torch.equal(clone.qweight, m.qweight)
+        sd = clone.state_dict()                                         # ... so the checkpoint is still the reference's
+        assert np.array_equal(sd["qweight"].numpy(), g["ref_qweight"])
+        assert np.array_equal(sd["qzeros"].numpy(), g["ref_qzeros"])
+        assert np.array_equal(sd["scales"].numpy().view(np.uint16), g["ref_qscales"].view(np.uint16))
+        clone.load_state_dict(sd)                                       # an in-place rewrite is still noticed
+        assert not clone.is_prepared
+    unprepared = copy.deepcopy(_reference_checkpoint_module()[1])
+    assert not unprepared.is_prepared
+
+
+def _save_bytes(module):
+    import io
+    buf = io.BytesIO()
+    torch.save(module, buf)
+    return buf.getvalue()
+
+
+def test_gemm_forward_validates_optional_tensors():
+    """Everything handed to the library as a raw pointer is checked on the Python side first (no GPU needed: the checks
+    come before the device check of the tensors they concern only where the message says so)."""
+    from quick_amd import kernels
+    x = torch.zeros(2, 128, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        kernels.gemm_forward(x, torch.zeros(32, 64, dtype=torch.int32), torch.zeros(1, 256, dtype=torch.float16),
+                             torch.zeros(1, 32, dtype=torch.int32))
