@@ -13,6 +13,7 @@ Cache, so small-M numbers are HBM numbers, not cache numbers.  Rank 0 prints ONE
                        rocprofv3 --kernel-trace reports) against the HBM or MFMA peak
   sweep                the same two measurements for every M of the BASELINE sweep (1, 8, 64, 512)
   decode_layers        kernel duration and HBM fraction of the Llama-2-7B layer shapes at M=1 (N=1 only)
+  decode               decode tok/s of a synthetic Llama-2-7B stack at bs = 1, 64 (128/128, hipGraph step; N=1 only)
   cpu_baseline         the reference's CPU path (dequantize_gemm + torch.matmul, restated in oracle/cpu_path.py)
                        timed on the host cores on a bounded sample, N=1 only
 
@@ -38,27 +39,67 @@ def log(*a):
 
 
 
-def pmc_traffic(M, K, N, G, kernel):
+def pmc_traffic(M, K, N, G, kernel, plan):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 counter pass for this shape
-    (profiles/rNN_pmc_m<M>_*.txt, written by tools/prof_passes.sh on K=N=4096, g=128, planner's kernel): counters
-    need their own rocprofv3 run, so this is read back rather than collected inside the timed run.  Bytes =
-    2 * FETCH_SIZE KiB (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE KiB."""
+    (profiles/rNN_pmc_m<M>_*.txt, written by tools/prof_passes.sh on K=N=4096, g=128): counters need their own rocprofv3
+    run (gpurun refuses --pmc next to anything but --kernel-trace), so this is read back rather than collected inside the
+    timed run.  Bytes = 2 * FETCH_SIZE KiB (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md 'HBM') +
+    WRITE_SIZE KiB.  The file must be ABOUT the kernel the planner picks today: its '== <kernel>' header is matched against
+    the plan's family word, and its SHA-256 goes into the JSON; a stale or foreign file yields traffic = null, not a number."""
     import glob
-    import os
+    import hashlib
     if (K, N, G, kernel) != (4096, 4096, 128, 0):
         return None, None
     here = os.path.dirname(os.path.abspath(__file__))
     files = sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_m{M}_*.txt")))
     if not files:
         return None, None
+    text = open(files[-1]).read()
+    family = plan.split()[0]                                   # "skinny" | "tiled" | "wide"
+    heads = [l for l in text.splitlines() if l.startswith("== ")]
+    if not heads or not any(f"w4a16_{family}" in h or (family == "wide" and "w4a16_ring" in h) for h in heads):
+        return None, {"file": "profiles/" + os.path.basename(files[-1]), "rejected": f"profiled kernel is not the planner's ({family})"}
     vals = {}
-    for line in open(files[-1]):
+    for line in text.splitlines():
         f = line.split()
         if len(f) >= 2 and f[0] in ("FETCH_SIZE", "WRITE_SIZE") and f[0] not in vals:
             vals[f[0]] = float(f[1])
     if "FETCH_SIZE" not in vals:
         return None, None
-    return (2.0 * vals["FETCH_SIZE"] + vals.get("WRITE_SIZE", 0.0)) * 1024.0, "profiles/" + os.path.basename(files[-1])
+    src = {"file": "profiles/" + os.path.basename(files[-1]), "sha256": hashlib.sha256(text.encode()).hexdigest()[:16],
+           "kernel": heads[0][3:].split(":")[0]}
+    return (2.0 * vals["FETCH_SIZE"] + vals.get("WRITE_SIZE", 0.0)) * 1024.0, src
+
+
+def decode_leg(dev, seconds, log):
+    """Second half of the BASELINE metric: decode tok/s of a synthetic Llama-2-7B AWQ-QUICK stack at bs = 1 and 64,
+    prefill/decode = 128/128, the reference's methodology (examples/benchmark.py:38-67,127-129: tok/s = bs / median step),
+    one decode step captured in a hipGraph.  Runs after the timed GEMM steps; `seconds` bounds it (fewer decode steps)."""
+    import time
+
+    import numpy as np
+    import torch
+    from quick_amd.decoder import CONFIGS, SyntheticDecoder, run_generation
+    out = []
+    cfg = CONFIGS["llama2-7b"]
+    t0 = time.perf_counter()
+    for bs in (1, 64):
+        if time.perf_counter() - t0 > seconds:
+            break
+        model = SyntheticDecoder(cfg, bs, 256, dev)
+        torch.cuda.synchronize()
+        run_generation(model, 128, 8, use_graph=False, fused=True)                  # warm-up (allocator, lazy init)
+        gen = 128 if time.perf_counter() - t0 < 0.5 * seconds else 32
+        prefill, steps = run_generation(model, 128, gen, use_graph=True, fused=True)
+        med = float(np.median(steps))
+        out.append({"model": cfg.name, "batch": bs, "prefill_len": 128, "decode_len": gen, "tok_s": bs / med, "ms_per_step": med * 1e3,
+                    "prefill_tok_s": 128 * bs / prefill, "weight_stream_GBs": model.weight_bytes() / med / 1e9,
+                    "launch": "hipgraph", "data": "synthetic random weights"})
+        log(f"decode {cfg.name} bs={bs}: {bs / med:9.1f} tok/s  {med * 1e3:.3f} ms/step  weights at {model.weight_bytes() / med / 1e9:.0f} GB/s")
+        del model
+        torch.cuda.empty_cache()
+    return out
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -76,6 +117,7 @@ def main():
     ap.add_argument("--layers", default="1x4096x12288,1x4096x22016,1x11008x4096",
                     help="MxKxN shapes (Llama-2-7B fused qkv, gate_up, down at bs=1) timed kernel-only into 'decode_layers'; '' = none")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--decode-seconds", type=float, default=40.0, help="budget of the decode tok/s leg (Llama-2-7B bs=1,64; 0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,7 +129,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the W4A16 GEMM has no CPU implementation")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = replicas.init("nccl", dev)        # replicas only: RCCL is used for the barrier and the max over ranks, nothing else
+    dist = replicas.init("gloo")             # replicas only, no RCCL anywhere: the barrier and the max over ranks run on CPU tensors
 
     from quick_amd import _lib, packing
     from quick_amd.build import build
@@ -156,7 +198,7 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        ms_step = replicas.max_over_ranks(dist, e0.elapsed_time(e1) / steps, dev)
+        ms_step = replicas.max_over_ranks(dist, e0.elapsed_time(e1) / steps)
 
         # the kernel's own duration: event pair bound to each dispatch, cycling the same weight sets
         psteps = min(steps, 300)   # per-dispatch event pairs: a few hundred launches are plenty for the kernel's own duration
@@ -178,7 +220,10 @@ def main():
         else:
             roof = {"bound": "mfma", "achieved": flops / (k_us * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"], roof["traffic_source"] = pmc_traffic(M, K, N, G, args.kernel)
+        pbuf = ctypes.create_string_buffer(256)
+        lib.quick_w4a16_plan_describe(M, K, N, G, args.kernel, args.split_k, pbuf, 256)
+        roof["plan"] = pbuf.value.decode()
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(M, K, N, G, args.kernel, roof["plan"])
         roof.update({"kernel_us": k_us, "kernel_us_cache_resident": k_us_hot, "algorithmic_bytes": nbytes, "flops": flops,
                      })
         return {"M": M, "ms_per_step": ms_step, "tops": flops / (ms_step * 1e-3) / 1e12, "tops_kernel_only": flops / (k_us * 1e-6) / 1e12,
@@ -275,19 +320,19 @@ def main():
         n_cpu, spent = 128, 0.0
         y_cpu, dt1 = cpu_call(n_cpu)
         spent += dt1
-        while n_cpu < N and dt1 * 2.5 < (args.cpu_seconds - spent):
+        while n_cpu < N and dt1 * 2.5 * 3 < (args.cpu_seconds - spent):     # leave room for >= 3 timed calls at the final width
             n_cpu = min(N, n_cpu * 2)
             y_cpu, dt1 = cpu_call(n_cpu)
             spent += dt1
-        reps, total = 1, dt1
-        while total + dt1 < (args.cpu_seconds - spent) and reps < 50:
+        times = [dt1]
+        while (len(times) < 3 or sum(times) + dt1 < (args.cpu_seconds - spent)) and len(times) < 50:
             y_cpu, dt1 = cpu_call(n_cpu)
-            total += dt1
-            reps += 1
-        dt = total / reps
+            times.append(dt1)
+        reps, total = len(times), sum(times)
+        dt = float(np.median(times))
         out["cpu_baseline"] = {
             "value": oracle.algorithmic_flops(args.M, K, n_cpu) / dt / 1e12, "unit": "TFLOP/s", "cores": cores,
-            "kind": "port", "ms_per_call": dt * 1e3,
+            "kind": "port", "ms_per_call": dt * 1e3, "calls": reps, "ms_per_call_min_max": [min(times) * 1e3, max(times) * 1e3],
             "sample": f"{reps} call(s) of the reference CPU path (dequantize_gemm + torch.matmul, dequant redone per call, "
                       f"oracle/cpu_path.py) on output channels 0..{n_cpu - 1} of the M={args.M} K={K} N={N} g={G} layer, "
                       f"{total:.1f} s on {cores} torch threads",
@@ -297,6 +342,13 @@ def main():
         from quick_amd import gemm_forward
         y_gpu = gemm_forward(x_full[:args.M].contiguous(), qw, sc, qz, kernel_id=args.kernel).float().cpu()
         out["parity_rel_err_vs_cpu_baseline"] = float((y_gpu[:, :n_cpu] - y_cpu.float()).abs().max() / y_cpu.float().abs().max())
+
+    # ---- decode tok/s (BASELINE metric, second half), after everything that is timed above
+    if rank == 0 and world == 1 and args.decode_seconds > 0:
+        try:
+            out["decode"] = decode_leg(dev, args.decode_seconds, log)
+        except Exception as e:                                   # pragma: no cover  (never lose the GEMM line to the extra leg)
+            out["decode"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -43,7 +43,7 @@ extern "C" {
 #define QUICK_KERNEL_AUTO 0
 #define QUICK_KERNEL_SKINNY 1 /* M-tiles straight from L2 to VGPRs, k split over the waves of a workgroup */
 #define QUICK_KERNEL_TILED 2  /* activations staged through LDS, MFMA-bound regime */
-#define QUICK_KERNEL_WIDE 3   /* large M: 32x32x16 MFMA, one wave per SIMD, activations by LDS-DMA (G % 128 == 0, G = 64, G = 32) */
+#define QUICK_KERNEL_WIDE 3   /* large M: 32x32x16 MFMA, one wave per SIMD, operands by LDS-DMA (G % 128 == 0; else TILED runs) */
 
 int quick_amd_abi_version(void);
 const char* quick_amd_last_error(void);

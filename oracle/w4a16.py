@@ -21,7 +21,7 @@ import numpy as np
 
 __all__ = [
     "quantize_intweight", "pack_cuda_order", "unpack_cuda_order", "pack_mi355x", "unpack_mi355x",
-    "dequantize", "gemm_fp32acc", "w4a16_forward", "gemm_splitk_fp16_partials", "quick_cat_cuda_order",
+    "unpack_mi355x_columns", "dequantize", "gemm_fp32acc", "w4a16_forward", "gemm_splitk_fp16_partials", "quick_cat_cuda_order",
     "algorithmic_bytes", "algorithmic_flops", "make_synthetic",
 ]
 
@@ -182,6 +182,25 @@ def unpack_mi355x(qweight: np.ndarray, qscales: np.ndarray, qzeros: np.ndarray):
     s = (words & 0xffff).astype(np.uint16).view(np.float16)
     z = ((words >> 16) & 15).astype(np.uint8)
     return iw, s, z
+
+
+def unpack_mi355x_columns(qweight: np.ndarray, qscales: np.ndarray, qzeros: np.ndarray, cols):
+    """(iw[K, len(cols)], s[K/G, len(cols)], z[K/G, len(cols)]) of the output channels `cols` only -- the same closed
+    form as unpack_mi355x, evaluated for a handful of columns, so that a test can check sampled channels of a layer that
+    is far too large to unpack (or to dequantise on the CPU) whole."""
+    K, N = qweight.shape[0] * 4, qweight.shape[1] * 2
+    cols = np.asarray(cols, dtype=np.int64)
+    k = np.arange(K, dtype=np.int64)[:, None]
+    n = cols[None, :]
+    idx = (((n // 16) * (K // 128) + k // 128) * 64 + (n % 16) + 16 * ((k % 32) // 8)) * 4 + (k % 128) // 32
+    j = k % 8
+    nib = (4 * (j % 2) + j // 2) + np.zeros_like(n)
+    flat = np.ascontiguousarray(qweight).view(np.uint32).ravel()
+    iw = ((flat[idx] >> (4 * nib).astype(np.uint32)) & 15).astype(np.uint8)
+    NG = qscales.shape[0]
+    g = np.arange(NG, dtype=np.int64)[:, None]
+    words = np.ascontiguousarray(qscales).view(np.uint32).ravel()[((n // 16) * NG + g) * 16 + (n % 16)]
+    return iw, (words & 0xffff).astype(np.uint16).view(np.float16), ((words >> 16) & 15).astype(np.uint8)
 
 
 # --------------------------------------------------------------------------------------------

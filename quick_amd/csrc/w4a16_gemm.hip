@@ -1257,9 +1257,17 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// ring slots that fit the 160 KiB of LDS for a (MB, PAIRS) tile at one (scale, zero) word per pair and stage (G % 128 == 0)
+constexpr int wide_ring_nbuf(int mb, int pairs) {
+  const int slot = mb * 8192 + pairs * 8192 + pairs * 1024;
+  const int n = (160 * 1024) / slot;
+  return n > 6 ? 6 : n;
+}
+
 struct Plan {
   int kernel;  // QUICK_KERNEL_SKINNY / QUICK_KERNEL_TILED / QUICK_KERNEL_WIDE
   int wide_mb, wide_pairs;  // wide: token tiles of 32 per workgroup, 32-channel pairs per wave
+  int wide_nbuf;            // wide: LDS ring slots (>= 3: w4a16_ring_kernel, everything by LDS-DMA; 0: w4a16_wide_kernel)
   int mt;      // skinny: channel tiles (of 16) per workgroup, NTW; tiled: token tiles per workgroup, BMT
   int waves;   // skinny: waves per workgroup
   bool xlds;   // skinny: x through an LDS copy
@@ -1325,7 +1333,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   const bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= 64);
   p.kernel = family == QUICK_KERNEL_AUTO ? (want_tiled ? QUICK_KERNEL_TILED : QUICK_KERNEL_SKINNY) : family;
   int ks = 1;
-  if (p.kernel == QUICK_KERNEL_WIDE && (G % 128 != 0 && G != 64 && G != 32)) p.kernel = QUICK_KERNEL_TILED;  // odd group sizes
+  if (p.kernel == QUICK_KERNEL_WIDE && G % 128 != 0) p.kernel = QUICK_KERNEL_TILED;  // small groups: r01's tiled kernel
   if (p.kernel == QUICK_KERNEL_WIDE) {
     // bits 4-7: MB (token tiles of 32 per workgroup: 2, 4, 8), bits 8-11: PAIRS (32-channel pairs per wave: 1, 2); 0 = choose
     int mb = mt_req, pairs = (kernel >> 8) & 15;
@@ -1334,6 +1342,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     if (N % (pairs * 128) != 0) pairs = 1;
     p.wide_mb = mb;
     p.wide_pairs = pairs;
+    // bit 12: no ring (the double-buffered kernel at every tile size); bits 22-24: ring slots (0 = as many as fit, up to 6)
+    const int nb_req = (kernel >> 22) & 7, nb_max = mb == 8 ? 0 : wide_ring_nbuf(mb, pairs);
+    p.wide_nbuf = (no_xlds || nb_max < 3) ? 0 : (nb_req >= 3 ? std::min(nb_req, nb_max) : nb_max);
     p.waves = 4;
     p.tch = pairs * 128;
     const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / p.tch;
@@ -1346,7 +1357,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     if (!((kernel >> 14) & 1) && (MBk * NBk) % 8 == 0)
       for (int gm = 1; gm <= 8; gm *= 2) {
         if (MBk % gm != 0 || NBk % (8 / gm) != 0) continue;
-        const long cost = (long)(MBk / gm) * 8 * mb + (long)(NBk * gm / 8) * (p.tch / 2);  // x rows + weight columns per XCD
+        const long cost = (long)(MBk / gm) * 64 * mb + (long)(NBk * gm / 8) * (p.tch / 2);  // bytes per k: x rows (2 B) + weight columns (1/2 B) per XCD
         if (best < 0 || cost < best) {
           best = cost;
           p.xcd_gm = gm;
@@ -1624,8 +1635,47 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
 #undef QA_TILED_K
 }
 
+template <int MB, int PAIRS, int NBUF>
+static void launch_ring(const Plan& p, const GemmArgs& a, const Launch& L) {
+  dim3 grid(p.ntiles, p.ksplit), block(256);
+  constexpr unsigned lds = NBUF * (MB * 8192 + PAIRS * 8192 + PAIRS * 1024);
+#define QA_RING_K(GMV)                                                                                             \
+  do {                                                                                                             \
+    auto kfn = w4a16_ring_kernel<MB, PAIRS, GMV, NBUF>;                                                            \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
+  } while (0)
+  if constexpr (MB == 2 && PAIRS == 1 && NBUF == 6)
+    if (p.ablate && a.G == 128) {  // timing experiments (results are wrong on purpose)
+      auto kfn1 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 1>;
+      auto kfn2 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 2>;
+      auto kfn5 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 5>;
+      auto kfn9 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 9>;
+      auto kfn = p.ablate == 1 ? kfn1 : (p.ablate == 5 ? kfn5 : (p.ablate == 9 ? kfn9 : kfn2));
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
+      return;
+    }
+  if (group_mode(a.G) == 0) QA_RING_K(0);
+  else QA_RING_K(1);
+#undef QA_RING_K
+}
+
 template <int MB, int PAIRS>
 static void launch_wide(const Plan& p, const GemmArgs& a, const Launch& L) {
+  if constexpr (MB <= 4) {
+    if (p.wide_nbuf >= 3) {
+      constexpr int NMAX = wide_ring_nbuf(MB, PAIRS);
+      if (p.wide_nbuf == 3) launch_ring<MB, PAIRS, 3>(p, a, L);
+      else if (NMAX >= 4 && p.wide_nbuf == 4) launch_ring<MB, PAIRS, (NMAX >= 4 ? 4 : 3)>(p, a, L);
+      else launch_ring<MB, PAIRS, NMAX>(p, a, L);
+      return;
+    }
+  }
   dim3 grid(p.ntiles, p.ksplit), block(256);
   const unsigned lds = 2 * MB * 32 * 256;
 #define QA_WIDE_K(GMV)                                                                                             \
@@ -1638,12 +1688,17 @@ static void launch_wide(const Plan& p, const GemmArgs& a, const Launch& L) {
     }                                                                                                              \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
-  switch (group_mode(a.G)) {
-    case 0: QA_WIDE_K(0); break;
-    case 1: QA_WIDE_K(1); break;
-    case 2: QA_WIDE_K(2); break;
-    default: QA_WIDE_K(3); break;
-  }
+  if constexpr ((MB == 2 && PAIRS == 1) || (MB == 8 && PAIRS == 2))
+    if (p.ablate && a.G == 128) {  // timing experiments (results are wrong on purpose)
+      auto kfn1 = w4a16_wide_kernel<MB, PAIRS, 0, 1>;
+      auto kfn2 = w4a16_wide_kernel<MB, PAIRS, 0, 2>;
+      auto kfn = p.ablate == 1 ? kfn1 : kfn2;
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
+      return;
+    }
+  if (group_mode(a.G) == 0) QA_WIDE_K(0);
+  else QA_WIDE_K(1);
 #undef QA_WIDE_K
 }
 
@@ -1770,8 +1825,8 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
              p.xlds ? "lds" : "l2", p.dz ? (p.xlds ? "deferred-zero-table" : "deferred-zero-fragment") : "exact", p.grid_x,
              (M + 15) / 16, p.ksplit, p.ksplit, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_WIDE)
-    snprintf(text, text_bytes, "wide tokens=%d channels=%d waves=4 grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
-             p.tch, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
+    snprintf(text, text_bytes, "wide tokens=%d channels=%d waves=4 ring=%d grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
+             p.tch, p.wide_nbuf, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
   else
     snprintf(text, text_bytes, "tiled tokens=%d channels=%d waves=%d grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.mt * 16,
              p.tch, p.wn2 ? 8 : p.waves, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));

@@ -1,18 +1,17 @@
-// "Wide" W4A16 kernel for large M on MI355X (gfx950): v_mfma_f32_32x32x16_f16, ONE wave per SIMD with the whole
-// 512-entry register file (accumulators in AGPRs), activations by LDS-DMA, weights HBM -> VGPR -> matrix core.
+// Large-M W4A16 kernels for MI355X (gfx950): v_mfma_f32_32x32x16_f16, ONE wave per SIMD (accumulators in AGPRs),
+// operands brought on chip by LDS-DMA.
 //
-// Why a second large-M kernel (r01's w4a16_tiled_kernel stays for small token counts): the cost of this GEMM on the
-// matrix core's side is fixed, the cost on the VALU side -- 13 packed-f16 ops per packed dword -- is paid once per
-// (weight, wave), so VALU ops per MFMA fall with the number of TOKENS a wave owns.  A 16-cycle 16x16x32 MFMA hides no
-// VALU work of its own wave (tools/mfma_valu_overlap.hip); a 32-cycle 32x32x16 hides ~5 issue slots
-// (MI355X_MICROARCH.md, "one wave per SIMD").  So: 4 waves per workgroup, all along N, each wave owning ALL the
-// workgroup's MB*32 tokens x PAIRS*32 channels; 13 / MB VALU ops per MFMA (1.6 at MB = 8), no weight dequantised twice
-// in a workgroup, MB*PAIRS*16 accumulator registers (256 at MB = 8, PAIRS = 2).
+// Why these kernels (r01's w4a16_tiled_kernel stays for small token counts): the cost of this GEMM on the matrix core's
+// side is fixed, the cost on the VALU side -- 13 packed-f16 ops per packed dword -- is paid once per (weight, wave), so
+// VALU ops per MFMA fall with the number of TOKENS a wave owns.  A 16-cycle 16x16x32 MFMA hides no VALU work of its own
+// wave (tools/mfma_valu_overlap.hip); a 32-cycle 32x32x16 hides ~5 issue slots (MI355X_MICROARCH.md, "one wave per
+// SIMD").  So: 4 waves per workgroup, all along N, each wave owning ALL the workgroup's MB*32 tokens x PAIRS*32 channels;
+// 13 / MB VALU ops per MFMA, no weight dequantised twice in a workgroup, MB*PAIRS*16 accumulator registers.
 //
 // Operands of v_mfma_f32_32x32x16_f16 (A = 32 channels x 16 k, B = 16 k x 32 tokens, lane l = (rho = l % 32, h = l / 32)):
 //   A: lane holds channel rho, k = 8 h .. 8 h + 7 of the k16 step.  The HBM weight layout is unchanged ("mi355x order":
 //      a 16-channel x 128-k tile is 1 KiB, byte 16 * (c + 16 q) holds the dwords t = 0..3 of channel c, k = 32 t + 8 q + j):
-//      lane (rho, h) loads 16 bytes at [tile rho / 16][c = rho % 16, q = h] ("lo") and at q = 2 + h ("hi", +512 B); dword t of
+//      lane (rho, h) takes 16 bytes at [tile rho / 16][c = rho % 16, q = h] ("lo") and at q = 2 + h ("hi", +512 B); dword t of
 //      lo / hi is the A operand of k16 step 2 t / 2 t + 1.  No lane shuffles; every 16-lane group reads 256 contiguous bytes.
 //   B: lane holds token rho, k = 8 h .. + 7.  A stage (128 k) of the token tile lives in LDS ROW-MAJOR, 256 B per token,
 //      16-byte chunk c of row r stored at chunk c ^ (r % 16): ds_read_b128 of a fragment is conflict-free, and the image is
@@ -20,21 +19,31 @@
 //      the swizzle applied to the per-lane SOURCE address (the LDS side of an LDS-DMA is lane-linear).
 //   C/D: lane holds token rho and channels (r % 4) + 8 (r / 4) + 4 h, r = 0..15, of the 32-channel pair.
 //
-// Pipeline: two LDS stage buffers and two weight register sets.  Iteration s issues the LDS-DMA of stage s + 1 and the
-// weight loads of stage s + 1, computes stage s (8 k16 steps), then waits vmcnt(0) -- for loads issued a whole stage
-// earlier -- and crosses ONE barrier.  The LDS-DMA is inline asm on purpose: hipcc makes every ds_read wait for every
-// LDS-DMA it knows about; the compiler-visible s_waitcnt builtin before the barrier also tells its waitcnt pass that the
-// weight prefetch has landed, so it adds no counted wait of its own (which the LDS-DMAs in flight would turn into a drain).
+// Two pipelines around the same compute core:
+//   w4a16_wide_kernel  (256-token tiles: a stage is 2-4 k cycles of MFMA, longer than any load): two LDS stage buffers for
+//       x, the weights HBM -> VGPR one stage ahead, vmcnt(0) + one barrier per stage.
+//   w4a16_ring_kernel  (64- and 128-token tiles: a stage is SHORTER than a trip to L2 / HBM): x, the packed weights and the
+//       (scale, zero) words all travel by LDS-DMA into a ring of NBUF stage slots, NBUF - 2 stages in flight behind a
+//       COUNTED vmcnt; a wave picks its own packed weights out of the slot again with ds_read_b128 one stage early.  The
+//       weights still go to the matrix core straight from registers after dequantisation -- what passes through LDS is the
+//       4-bit stream, as a prefetch queue that costs no registers.
+// All LDS-DMA is inline asm on purpose: hipcc makes every ds_read wait for every LDS-DMA it knows about, and beside them
+// it turns its counted waits for ordinary loads into drains (cdna_hip_programming.md, "Three .s-level traps").
 #pragma once
 
 namespace quick_amd {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-// 64 lanes x 16 bytes: global (descriptor base + voff + soff) -> LDS (lds_addr + 16 * lane).  M0 carries the LDS
+// 64 lanes x 16 (4) bytes: global (descriptor base + voff + soff) -> LDS (lds_addr + 16 (4) * lane).  M0 carries the LDS
 // address and is written in the statement that uses it (hipcc reserves M0 and does not preserve it across asm).
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc),
+               "s"(soff)
+               : "memory");
+}
+__device__ __forceinline__ void lds_dma4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc),
                "s"(soff)
                : "memory");
 }
@@ -45,37 +54,35 @@ struct WideW {  // one 128-k tile of this wave's weights: per 32-channel pair th
   uint32_t sz[PAIRS][groups_per_tile<GM>()];
 };
 
+template <int MB>
 struct WideBufs {
   __amdgpu_buffer_rsrc_t x, w, s;
-  unsigned x_voff, w_voff, s_voff;
-  unsigned x_istride;   // bytes between the rows of consecutive LDS-DMA instructions of a wave: 16 rows
-  unsigned w_pstride;   // bytes between consecutive 32-channel pairs of the weights
-  unsigned s_pstride;   // ... of the (scale, zero point) words
+  unsigned x_voff[MB * 2];  // per LDS-DMA instruction of a stage: clamped row * K * 2 + swizzled chunk * 16
+  unsigned w_voff, s_voff;
+  unsigned w_pstride;  // bytes between consecutive 32-channel pairs of the weights
+  unsigned s_pstride;  // ... of the (scale, zero point) words
 };
 
-template <int PAIRS, int GM>
-__device__ __forceinline__ void wide_load_w(WideW<PAIRS, GM>& w, const WideBufs& b, int kt, const GemmArgs& a) {
-  constexpr int NG = groups_per_tile<GM>();
+// Descriptors and per-lane offsets.  x: instruction i of a wave moves rows 16 i + 4 wave + lane / 16 of the token tile,
+// lane % 16 picks the 16-byte chunk (the row's chunk c lands at LDS chunk c ^ (row % 16), so the lane writing LDS chunk
+// lane % 16 fetches source chunk (lane % 16) ^ (row % 16)).  Rows past M replay row M - 1 (never stored).
+template <int MB, int PAIRS>
+__device__ __forceinline__ WideBufs<MB> wide_bufs(const GemmArgs& a, int m0, int ct0, int lane, int wave) {
+  WideBufs<MB> b;
+  const int KT = a.K >> 7, NGRP = a.K / a.G;
+  const unsigned rho = (unsigned)lane & 31u, h = (unsigned)lane >> 5;
+  const unsigned xrow = 4u * (unsigned)wave + ((unsigned)lane >> 4);
+  b.x = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (unsigned)a.M * (unsigned)a.K * 2u, 0x00020000);
 #pragma unroll
-  for (int p = 0; p < PAIRS; ++p) {
-    const unsigned so = (unsigned)p * b.w_pstride + (unsigned)kt * 1024u;
-    w.lo[p] = __builtin_amdgcn_raw_buffer_load_b128(b.w, b.w_voff, so, 0);
-    w.hi[p] = __builtin_amdgcn_raw_buffer_load_b128(b.w, b.w_voff + 512u, so, 0);
-  }
-#pragma unroll
-  for (int p = 0; p < PAIRS; ++p)
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      const unsigned g = (unsigned)group_index<GM>(kt, i * (4 / NG), a.tpg, a.G);
-      w.sz[p][i] = __builtin_amdgcn_raw_buffer_load_b32(b.s, b.s_voff, (unsigned)p * b.s_pstride + g * 64u, 0);
-    }
-}
-
-// stage (128 k) kt of the token tile -> LDS buffer at lds_addr: MB * 2 instructions per wave, 4 rows x 256 B each
-template <int MB>
-__device__ __forceinline__ void wide_issue_x(const WideBufs& b, int kt, unsigned lds_addr) {
-#pragma unroll
-  for (int i = 0; i < MB * 2; ++i) lds_dma16(b.x, b.x_voff, (unsigned)i * b.x_istride + (unsigned)kt * 256u, lds_addr + i * 4096);
+  for (int i = 0; i < MB * 2; ++i)
+    b.x_voff[i] = (unsigned)min(m0 + 16 * i + (int)xrow, a.M - 1) * (unsigned)a.K * 2u + 16u * (((unsigned)lane & 15u) ^ xrow);
+  b.w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.QW + (size_t)ct0 * KT * 64), 0, (unsigned)(2 * PAIRS) * (unsigned)KT * 1024u, 0x00020000);
+  b.w_voff = (rho >> 4) * (unsigned)KT * 1024u + 16u * ((rho & 15u) + 16u * h);
+  b.w_pstride = 2u * (unsigned)KT * 1024u;
+  b.s = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint32_t*)a.S + (size_t)ct0 * NGRP * 16), 0, (unsigned)(2 * PAIRS) * (unsigned)NGRP * 64u, 0x00020000);
+  b.s_voff = (rho >> 4) * (unsigned)NGRP * 64u + 4u * (rho & 15u);
+  b.s_pstride = 2u * (unsigned)NGRP * 64u;
+  return b;
 }
 
 // dequant8 (w4a16_common.hpp) without inline asm: the masks live in SGPRs and the magic number in a VGPR the compiler
@@ -108,11 +115,25 @@ __device__ __forceinline__ half8_t dequant8(uint32_t q, const GroupQ& g, const D
 // (p == 0) the LDS returns the B fragments of step kk + 1.  sched_group_barrier spells the interleave out -- one MFMA,
 // then its share of the VALU ops and one ds_read -- because hipcc otherwise emits "13 VALU, then MB MFMAs back to back":
 // an in-order wave issues the VALU block only after the last MFMA of the unit has issued, i.e. mostly in the open.
-template <int MB, int PAIRS, int GM>
-__device__ __forceinline__ void wide_compute(const WideW<PAIRS, GM>& w, unsigned xb, const DqConsts& dq, floatx16 (&acc)[PAIRS][MB]) {
+// `hook(u)` runs at the head of unit u: the callers spread their LDS-DMA issue (and the ring kernel its early weight
+// read) over the units with it -- a wave that issues a stage's 16 KiB of LDS-DMA in one go keeps the CU's 64 B/clk vector
+// memory path busy for ~1000 cycles during which no wave issues an MFMA.
+// ABL (timing experiments only, results are wrong): 1 = no compute (hooks only), 2 = the callers issue no loads in the K loop.
+template <int MB, int PAIRS, int GM, int ABL = 0, class Hook>
+__device__ __forceinline__ void wide_compute(const WideW<PAIRS, GM>& w, unsigned xb, const DqConsts& dq, floatx16 (&acc)[PAIRS][MB],
+                                             Hook&& hook) {
   typedef const __attribute__((address_space(3))) char* lds_ptr;
   constexpr int NG = groups_per_tile<GM>();
   constexpr int NU = 8 * PAIRS;
+  if constexpr (ABL & 1) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      hook(u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("" ::"v"(w.lo[0]), "v"(w.hi[0]), "v"(w.sz[0][0]));
+    return;
+  }
   constexpr int VPM = (14 + MB - 1) / MB;  // VALU ops placed behind each MFMA (13 per fragment + the address xor)
   GroupQ grp[PAIRS][NG];
 #pragma unroll
@@ -137,99 +158,53 @@ __device__ __forceinline__ void wide_compute(const WideW<PAIRS, GM>& w, unsigned
   for (int u = 0; u < NU; ++u) {
     const int kk = u / PAIRS, p = u % PAIRS;
     const bool reads = p == 0 && kk < 7;
+    hook(u);
+    __builtin_amdgcn_sched_barrier(0);
     if (u + 1 < NU) af[(u + 1) & 1] = frag(u + 1);
     if (reads) read_frags(kk + 1, bf[(kk + 1) & 1]);
 #pragma unroll
     for (int mt = 0; mt < MB; ++mt) acc[p][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u & 1], bf[kk & 1][mt], acc[p][mt], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < MB; ++mt) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // MFMA
       if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);  // VALU
-      if (reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+      if (reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // DS read
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// Workgroup tile (MB*32 tokens) x (PAIRS*128 channels), 4 waves along N.  Grid: x = tiles (XCD-aware order), y = K slices.
-template <int MB, int PAIRS, int GM>
-__global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
-  constexpr int STAGE_BYTES = MB * 32 * 256;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE_BYTES
-
-  const int lane = threadIdx.x & 63;
-  const int wave = uniform(threadIdx.x >> 6);
-  const int rho = lane & 31, h = lane >> 5;
+// tile / K-slice coordinates shared by the two kernels
+struct WideTile {
+  int mb, nb, ks, kt_lo, kt_hi, nstage, m0;
+};
+template <int MB, int PAIRS>
+__device__ __forceinline__ WideTile wide_tile(const GemmArgs& a) {
+  WideTile t;
   const int NB = a.N / (PAIRS * 128);
-  int nb = blockIdx.x % NB, mb = blockIdx.x / NB;
+  t.nb = blockIdx.x % NB;
+  t.mb = blockIdx.x / NB;
   if (a.xcd_gm > 0) {  // see w4a16_tiled_kernel: every XCD gets a compact rectangle of tiles
     const int MBk = gridDim.x / NB, gn = 8 / a.xcd_gm;
     const int mcnt = MBk / a.xcd_gm, ncnt = NB / gn;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    mb = (xcd / gn) * mcnt + idx / ncnt;
-    nb = (xcd % gn) * ncnt + idx % ncnt;
+    t.mb = (xcd / gn) * mcnt + idx / ncnt;
+    t.nb = (xcd % gn) * ncnt + idx % ncnt;
   }
-  const int ks = blockIdx.y;
-  const int KT = a.K >> 7, NGRP = a.K / a.G;
-  const int kt_lo = ks * a.kt_per_split, kt_hi = min(KT, kt_lo + a.kt_per_split);
-  const int nstage = kt_hi - kt_lo;
-  const int m0 = mb * MB * 32;
-  const int ct0 = (nb * 4 + wave) * PAIRS * 2;  // first 16-channel tile of this wave
+  t.ks = blockIdx.y;
+  const int KT = a.K >> 7;
+  t.kt_lo = t.ks * a.kt_per_split;
+  t.kt_hi = min(KT, t.kt_lo + a.kt_per_split);
+  t.nstage = t.kt_hi - t.kt_lo;
+  t.m0 = t.mb * MB * 32;
+  return t;
+}
 
-  WideBufs b;
-  {
-    const unsigned rows = (unsigned)min(a.M - m0, MB * 32);  // rows past M read as zeros (buffer bounds) and are never stored
-    const unsigned xrow = 4u * (unsigned)wave + ((unsigned)lane >> 4);
-    b.x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (size_t)m0 * a.K), 0, rows * (unsigned)a.K * 2u, 0x00020000);
-    b.x_voff = xrow * (unsigned)a.K * 2u + 16u * (((unsigned)lane & 15u) ^ xrow);
-    b.x_istride = 16u * (unsigned)a.K * 2u;
-    b.w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.QW + (size_t)ct0 * KT * 64), 0, (unsigned)(2 * PAIRS) * (unsigned)KT * 1024u, 0x00020000);
-    b.w_voff = ((unsigned)rho >> 4) * (unsigned)KT * 1024u + 16u * (((unsigned)rho & 15u) + 16u * (unsigned)h);
-    b.w_pstride = 2u * (unsigned)KT * 1024u;
-    b.s = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint32_t*)a.S + (size_t)ct0 * NGRP * 16), 0, (unsigned)(2 * PAIRS) * (unsigned)NGRP * 64u, 0x00020000);
-    b.s_voff = ((unsigned)rho >> 4) * (unsigned)NGRP * 64u + 4u * ((unsigned)rho & 15u);
-    b.s_pstride = 2u * (unsigned)NGRP * 64u;
-  }
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned lds0 = lds_base + (unsigned)wave * 1024u;  // LDS-DMA destination of this wave's first instruction: rows 4 w .. 4 w + 3
-  // B-fragment read address of this lane in stage buffer 0, token tile 0, k16 step 0: row rho, chunk h ^ (rho % 16)
-  const unsigned xrd = lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4);
-
-  floatx16 acc[PAIRS][MB];
-#pragma unroll
-  for (int p = 0; p < PAIRS; ++p)
-#pragma unroll
-    for (int mt = 0; mt < MB; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[p][mt][r] = 0.f;
-
-  // Straight-line loop body on purpose: with control flow around the MFMAs hipcc carries the accumulators through the
-  // loop in VGPRs and copies them to AGPRs and back every iteration (and then spills).  So the weight "double buffer" is a
-  // register copy at the end of the stage (18 moves per 128-k stage), and the last iteration issues its prefetch anyway --
-  // a replay of the last stage into the other LDS buffer, which nobody reads.
-  const DqConsts dq = make_dq_consts();
-  WideW<PAIRS, GM> wc, wn;
-  if (nstage > 0) {
-    wide_issue_x<MB>(b, kt_lo, lds0);
-    wide_load_w<PAIRS, GM>(wc, b, kt_lo, a);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  __builtin_amdgcn_s_barrier();
-
-  for (int s = 0; s < nstage; ++s) {
-    const int ktn = min(kt_lo + s + 1, kt_hi - 1);
-    const unsigned par = (unsigned)(s & 1);
-    wide_issue_x<MB>(b, ktn, lds0 + (par ^ 1u) * STAGE_BYTES);
-    wide_load_w<PAIRS, GM>(wn, b, ktn, a);
-    __builtin_amdgcn_sched_barrier(0);
-    wide_compute<MB, PAIRS, GM>(wc, xrd + par * STAGE_BYTES, dq, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // stage s + 1 has landed (LDS-DMA and weights) ...
-    __builtin_amdgcn_s_barrier();        // ... in every wave, and everybody is done reading stage s
-    wc = wn;
-  }
-
-  // ---- K split across workgroups: slab = [(p, mt, c)][wave][lane] floatx4
+// K split across workgroups (slab = [(p, mt, c)][wave][lane] floatx4) and the fused epilogue.
+template <int MB, int PAIRS>
+__device__ __forceinline__ void wide_finish(const GemmArgs& a, const WideTile& t, floatx16 (&acc)[PAIRS][MB], char* smem, int ct0,
+                                            int lane, int wave) {
+  const int rho = lane & 31, h = lane >> 5;
   if (a.ksplit > 1) {
     constexpr unsigned SLAB_BYTES = PAIRS * MB * 16384;
     const __amdgpu_buffer_rsrc_t rs = slab_rsrc(a.slabs + (size_t)blockIdx.x * a.ksplit * (SLAB_BYTES / 4), a.ksplit * SLAB_BYTES);
@@ -240,7 +215,7 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
       for (int mt = 0; mt < MB; ++mt)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          slab_store(rs, ks * SLAB_BYTES + ((p * MB + mt) * 4 + c) * 4096 + my,
+          slab_store(rs, t.ks * SLAB_BYTES + ((p * MB + mt) * 4 + c) * 4096 + my,
                      floatx4{acc[p][mt][4 * c], acc[p][mt][4 * c + 1], acc[p][mt][4 * c + 2], acc[p][mt][4 * c + 3]});
     if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
     // every slice is read back from its slab (the own one too) and added in index order: the sum does not depend on
@@ -259,14 +234,14 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
     }
   }
 
-  // ---- epilogue: lane = token m0 + 32 mt + rho, channels ch0 + 32 p + 8 c + 4 h .. + 3 (c = r / 4)
+  // lane = token m0 + 32 mt + rho, channels ch0 + 32 p + 8 c + 4 h .. + 3 (c = r / 4)
   const int ch0 = ct0 * 16;
   if (a.silu_mul) {  // gate / up interleaved by 8: c = 0, 2 gate of the two 16-channel tiles, c = 1, 3 their up
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p)
 #pragma unroll
       for (int mt = 0; mt < MB; ++mt) {
-        const int m = m0 + mt * 32 + rho;
+        const int m = t.m0 + mt * 32 + rho;
         if (m < a.M) {
 #pragma unroll
           for (int c = 0; c < 4; c += 2) {
@@ -288,7 +263,7 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
       if (a.bias) bv = *(const half4_t*)(a.bias + nc);
 #pragma unroll
       for (int mt = 0; mt < MB; ++mt) {
-        const int m = m0 + mt * 32 + rho;
+        const int m = t.m0 + mt * 32 + rho;
         if (m < a.M) {
           half4_t res = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
           if (a.residual) res = *(const half4_t*)(a.residual + (size_t)m * a.N + nc);
@@ -299,6 +274,193 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
         }
       }
     }
+}
+
+template <int MB, int PAIRS>
+__device__ __forceinline__ void wide_zero(floatx16 (&acc)[PAIRS][MB]) {
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+    for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][mt][r] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256-token tiles: x double-buffered in LDS, weights HBM -> VGPR one stage ahead
+// ------------------------------------------------------------------------------------------------
+template <int MB, int PAIRS, int GM>
+__device__ __forceinline__ void wide_load_w(WideW<PAIRS, GM>& w, const WideBufs<MB>& b, int kt, const GemmArgs& a) {
+  constexpr int NG = groups_per_tile<GM>();
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    const unsigned so = (unsigned)p * b.w_pstride + (unsigned)kt * 1024u;
+    w.lo[p] = __builtin_amdgcn_raw_buffer_load_b128(b.w, b.w_voff, so, 0);
+    w.hi[p] = __builtin_amdgcn_raw_buffer_load_b128(b.w, b.w_voff + 512u, so, 0);
+  }
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const unsigned g = (unsigned)group_index<GM>(kt, i * (4 / NG), a.tpg, a.G);
+      w.sz[p][i] = __builtin_amdgcn_raw_buffer_load_b32(b.s, b.s_voff, (unsigned)p * b.s_pstride + g * 64u, 0);
+    }
+}
+
+// Workgroup tile (MB*32 tokens) x (PAIRS*128 channels), 4 waves along N.  Grid: x = tiles (XCD-aware order), y = K slices.
+template <int MB, int PAIRS, int GM, int ABL = 0>
+__global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
+  constexpr int STAGE_BYTES = MB * 32 * 256;
+  constexpr int XI = MB * 2, NU = 8 * PAIRS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE_BYTES
+
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int rho = lane & 31, h = lane >> 5;
+  const WideTile t = wide_tile<MB, PAIRS>(a);
+  const int ct0 = (t.nb * 4 + wave) * PAIRS * 2;  // first 16-channel tile of this wave
+  const WideBufs<MB> b = wide_bufs<MB, PAIRS>(a, t.m0, ct0, lane, wave);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lds0 = lds_base + (unsigned)wave * 1024u;  // LDS-DMA destination of this wave's first instruction: rows 4 w .. 4 w + 3
+  // B-fragment read address of this lane in stage buffer 0, token tile 0, k16 step 0: row rho, chunk h ^ (rho % 16)
+  const unsigned xrd = lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4);
+
+  floatx16 acc[PAIRS][MB];
+  wide_zero<MB, PAIRS>(acc);
+
+  // Straight-line loop body on purpose: with control flow around the MFMAs hipcc carries the accumulators through the
+  // loop in VGPRs and copies them to AGPRs and back every iteration (and then spills).  So the weight "double buffer" is a
+  // register copy at the end of the stage (18 moves per 128-k stage), and the last iteration issues its prefetch anyway --
+  // a replay of the last stage into the other LDS buffer, which nobody reads.
+  const DqConsts dq = make_dq_consts();
+  WideW<PAIRS, GM> wc, wn;
+  if (t.nstage > 0) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) lds_dma16(b.x, b.x_voff[i], (unsigned)t.kt_lo * 256u, lds0 + i * 4096);
+    wide_load_w<MB, PAIRS, GM>(wc, b, t.kt_lo, a);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __builtin_amdgcn_s_barrier();
+
+  for (int s = 0; s < t.nstage; ++s) {
+    const int ktn = min(t.kt_lo + s + 1, t.kt_hi - 1);
+    const unsigned par = (unsigned)(s & 1);
+    const unsigned dst = lds0 + (par ^ 1u) * STAGE_BYTES;
+    if constexpr (!(ABL & 2)) wide_load_w<MB, PAIRS, GM>(wn, b, ktn, a);
+    else wn = wc;
+    __builtin_amdgcn_sched_barrier(0);
+    wide_compute<MB, PAIRS, GM, ABL>(wc, xrd + par * STAGE_BYTES, dq, acc, [&](int u) {
+      // this unit's share of the next stage's LDS-DMA (all of it issued two units before the stage ends)
+      constexpr int PER = (XI + NU - 3) / (NU - 2);
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int i = u * PER + j;
+        if constexpr (!(ABL & 2))
+          if (i < XI) lds_dma16(b.x, b.x_voff[i], (unsigned)ktn * 256u, dst + i * 4096);
+      }
+    });
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // stage s + 1 has landed (LDS-DMA and weights) ...
+    __builtin_amdgcn_s_barrier();        // ... in every wave, and everybody is done reading stage s
+    wc = wn;
+  }
+  wide_finish<MB, PAIRS>(a, t, acc, smem, ct0, lane, wave);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 64- / 128-token tiles: everything by LDS-DMA into a ring of NBUF stage slots, counted vmcnt
+// ------------------------------------------------------------------------------------------------
+// Slot = [x: MB * 8 KiB][packed weights: 4 waves x PAIRS x (lo, hi) KiB][(scale, zero) words: 4 waves x PAIRS x NG x 256 B].
+// At the top of iteration s the slots hold stages s .. s + NBUF - 2: s and s + 1 landed and visible to every wave (s + 1
+// because a wave reads its stage-(s + 1) weights out of the slot during stage s), the rest in flight; slot (s - 1) % NBUF
+// was released by the barrier that ended iteration s - 1 and receives stage s + NBUF - 1, issued over the units of stage s.
+// Every wave issues the same L = MB * 2 + PAIRS * 2 + PAIRS * NG LDS-DMA instructions per stage, so "stage s + 2 has
+// landed" is s_waitcnt vmcnt((NBUF - 3) * L) at the end of iteration s, followed by the one barrier of the stage.
+template <int MB, int PAIRS, int GM, int NBUF, int ABL = 0>
+__global__ __launch_bounds__(256) void w4a16_ring_kernel(const GemmArgs a) {
+  constexpr int NG = groups_per_tile<GM>();
+  constexpr int X_BYTES = MB * 8192, W_BYTES = PAIRS * 8192, S_BYTES = PAIRS * NG * 1024;
+  constexpr int SLOT = X_BYTES + W_BYTES + S_BYTES;
+  constexpr int XI = MB * 2, LW = PAIRS * 2, LS = PAIRS * NG, L = XI + LW + LS, NU = 8 * PAIRS;
+  constexpr int PENDING = (NBUF - 3) * ((ABL & 4) ? LW + LS : ((ABL & 8) ? XI : L));
+  static_assert(NBUF >= 3 && NBUF * SLOT <= 160 * 1024 && PENDING <= 63, "ring does not fit LDS / the vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF * SLOT
+
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int rho = lane & 31, h = lane >> 5;
+  const WideTile t = wide_tile<MB, PAIRS>(a);
+  const int ct0 = (t.nb * 4 + wave) * PAIRS * 2;
+  const WideBufs<MB> b = wide_bufs<MB, PAIRS>(a, t.m0, ct0, lane, wave);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned xdst = lds_base + (unsigned)wave * 1024u;                           // + slot + i * 4096
+  const unsigned wdst = lds_base + X_BYTES + (unsigned)wave * (PAIRS * 2048);        // + slot + (2 p + hi) * 1024
+  const unsigned sdst = lds_base + X_BYTES + W_BYTES + (unsigned)wave * (LS * 256);  // + slot + (p * NG + i) * 256
+  const unsigned xrd = lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4);
+  const unsigned w_voff_hi = b.w_voff + 512u;
+
+  // item j of stage kt -> slot at byte offset `slot`: the x rows first, then the packed weights, then the group words
+  auto issue = [&](int j, int kt, unsigned slot) {
+    if constexpr (ABL & 4) { if (j < XI) return; }   // (timing experiments: no x / no weight traffic)
+    if constexpr (ABL & 8) { if (j >= XI) return; }
+    if (j < XI) {
+      lds_dma16(b.x, b.x_voff[j], (unsigned)kt * 256u, xdst + slot + j * 4096);
+    } else if (j < XI + LW) {
+      const int p = (j - XI) >> 1, hi = (j - XI) & 1;
+      lds_dma16(b.w, hi ? w_voff_hi : b.w_voff, (unsigned)p * b.w_pstride + (unsigned)kt * 1024u, wdst + slot + (j - XI) * 1024);
+    } else {
+      const int p = (j - XI - LW) / NG, i = (j - XI - LW) % NG;
+      const unsigned g = (unsigned)group_index<GM>(kt, i * (4 / NG), a.tpg, a.G);
+      lds_dma4(b.s, b.s_voff, (unsigned)p * b.s_pstride + g * 64u, sdst + slot + (j - XI - LW) * 256);
+    }
+  };
+  typedef const __attribute__((address_space(3))) char* lds_ptr;
+  auto read_w = [&](WideW<PAIRS, GM>& w, unsigned slot) {  // this lane's own 16 + 16 bytes per pair, and its group words
+    const lds_ptr wp = (lds_ptr)(uintptr_t)(wdst + slot + (unsigned)lane * 16u);
+    const lds_ptr sp = (lds_ptr)(uintptr_t)(sdst + slot + (unsigned)lane * 4u);
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      w.lo[p] = *(const __attribute__((address_space(3))) u32x4*)(wp + (2 * p) * 1024);
+      w.hi[p] = *(const __attribute__((address_space(3))) u32x4*)(wp + (2 * p + 1) * 1024);
+#pragma unroll
+      for (int i = 0; i < NG; ++i) w.sz[p][i] = *(const __attribute__((address_space(3))) uint32_t*)(sp + (p * NG + i) * 256);
+    }
+  };
+
+  floatx16 acc[PAIRS][MB];
+  wide_zero<MB, PAIRS>(acc);
+  const DqConsts dq = make_dq_consts();
+  WideW<PAIRS, GM> wc, wn;
+
+  // prologue: stages 0 .. NBUF - 2 into slots 0 .. NBUF - 2 (past the end of the K range: replays of the last stage)
+#pragma unroll
+  for (int q = 0; q < NBUF - 1; ++q) {
+    const int kt = min(t.kt_lo + q, t.kt_hi - 1);
+#pragma unroll
+    for (int j = 0; j < L; ++j) issue(j, kt, (unsigned)q * SLOT);
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory");  // stages 0 and 1 have landed
+  __builtin_amdgcn_s_barrier();
+  read_w(wc, 0u);
+
+  unsigned cur = 0u, nxt = (unsigned)SLOT, fill = (unsigned)(NBUF - 1) * SLOT;  // slot offsets of stage s, s + 1, s + NBUF - 1
+  for (int s = 0; s < t.nstage; ++s) {
+    const int ktf = min(t.kt_lo + s + NBUF - 1, t.kt_hi - 1);
+    wide_compute<MB, PAIRS, GM, ABL>(wc, xrd + cur, dq, acc, [&](int u) {
+      constexpr int PER = (L + NU - 2) / (NU - 1);  // everything issued one unit before the stage ends
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+        if constexpr (!(ABL & 2))
+          if (u * PER + j < L) issue(u * PER + j, ktf, fill);
+      if (u == NU / 2) read_w(wn, nxt);  // next stage's packed weights: LDS -> registers, half a stage early
+    });
+    if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory");  // stage s + 2 has landed ...
+    __builtin_amdgcn_s_barrier();                                    // ... in every wave; everybody is done with stage s
+    wc = wn;
+    fill = cur;
+    cur = nxt;
+    nxt = nxt + SLOT >= (unsigned)(NBUF * SLOT) ? 0u : nxt + SLOT;
+  }
+  wide_finish<MB, PAIRS>(a, t, acc, smem, ct0, lane, wave);
 }
 
 }  // namespace quick_amd

@@ -12,13 +12,13 @@ def world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend, device=None):
-    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them)."""
+def init(backend="gloo"):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them).  gloo on
+    CPU tensors: the path has no exchange step, so no RCCL communicator is ever created (north star: "no RCCL")."""
     import torch.distributed as dist
     if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
         return None
-    kw = {"device_id": device} if (device is not None and backend == "nccl") else {}
-    dist.init_process_group(backend, **kw)
+    dist.init_process_group(backend)
     return dist
 
 

@@ -37,3 +37,16 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def exact_layer(K, N, G, seed):
+    """The seeded layer of tests/golden/gen_golden.py::_exact_layer (weights that quantise exactly), regenerated: logical
+    (iw[K, N] uint8, s[K/G, N] fp16, z[K/G, N] uint8).  torch's CPU generator is deterministic for a given build, and the GPU
+    box runs the same image, so the fixture only has to hold the seed."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    iw = torch.randint(0, 16, (N, K), generator=g)
+    z = torch.randint(0, 16, (N, K // G), generator=g)
+    s = (torch.rand(N, K // G, generator=g) * 0.02 + 0.005).half()
+    return (np.ascontiguousarray(iw.numpy().T).astype(np.uint8), np.ascontiguousarray(s.numpy().T),
+            np.ascontiguousarray(z.numpy().T).astype(np.uint8))

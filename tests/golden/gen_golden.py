@@ -16,7 +16,9 @@ What is pinned:
   gemm     WQLinear_GEMM.forward without awq_ext = dequantize_gemm + torch.matmul (gemm.py:173-181);
   cat      QUICK_cat (quick/awq/utils/fused_utils.py:119-159);
   quant    AwqQuantizer.pseudo_quantize_tensor (quick/awq/quantize/quantizer.py:46-72) feeding
-           from_linear, for the non-exact rounding case.
+           from_linear, for the non-exact rounding case;
+  pin      the BASELINE size K = N = 4096, g = 128: seed + SHA-256 of the reference packer's three buffers + sampled
+           dequantised weights and sampled outputs of the reference CPU path (`python gen_golden.py pin` makes only this).
 """
 import importlib.util
 import os
@@ -87,10 +89,42 @@ def _exact_layer(K, N, G, seed):
     return w, s, z.half(), iw
 
 
+def make_pin(QUICK, GEMM, dequantize_gemm):
+    # BASELINE size (K = N = 4096, g = 128): too big to store, so the fixture holds the seed the layer is regenerated from,
+    # the SHA-256 of the three buffers the REFERENCE packer made of it, sampled dequantised weights and sampled outputs of
+    # the REFERENCE CPU path ("for 4096^2 only seeds + SHA-256 of packed buffers + sampled outputs")
+    import hashlib
+    K, N, G, M, seed = 4096, 4096, 128, 16, 900
+    w, s, z, iw = _exact_layer(K, N, G, seed=seed)
+    lin = _linear(w)
+    ql = QUICK.from_linear(lin, 4, G, False, s.clone(), z.clone())
+    gl = GEMM.from_linear(lin, 4, G, False, s.t().contiguous(), z.t().contiguous())
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(seed + 1)).half()
+    with torch.no_grad():
+        y = gl(x)
+        wdeq = dequantize_gemm(gl.qweight, gl.qzeros, gl.scales, 4, G)
+    rng = np.random.default_rng(seed + 2)
+    ys_m, ys_n = rng.integers(0, M, 2048), rng.integers(0, N, 2048)
+    ws_k, ws_n = rng.integers(0, K, 4096), rng.integers(0, N, 4096)
+    sha = lambda t: hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
+    np.savez_compressed(
+        os.path.join(OUT, "pin_k4096n4096g128.npz"), K=K, N=N, G=G, M=M, seed=seed, x=x.numpy(),
+        sha_qweight=sha(ql.qweight), sha_qscales=sha(ql.scales), sha_qzeros=sha(ql.qzeros),
+        y_rows=ys_m, y_cols=ys_n, y_ref=y.numpy()[ys_m, ys_n],
+        w_k=ws_k, w_n=ws_n, w_ref=wdeq.numpy()[ws_k, ws_n],
+        col_abs_sum=y.float().abs().sum(0).numpy(),      # one number per output channel: catches a wrong column anywhere
+    )
+    print("wrote 4096^2 pin:", sha(ql.qweight)[:16], sha(ql.scales)[:16], sha(ql.qzeros)[:16])
+
+
+
 def main():
     torch.manual_seed(0)
     QUICK, GEMM, dequantize_gemm, QUICK_cat, pseudo_quantize_tensor = _load_reference()
 
+    if len(sys.argv) > 1 and sys.argv[1] == "pin":     # only the BASELINE-size pin (the other fixtures are untouched)
+        make_pin(QUICK, GEMM, dequantize_gemm)
+        return
     cases = [("k64n128g64", 64, 128, 64, 3), ("k128n128g128", 128, 128, 128, 5), ("k128n256g32", 128, 256, 32, 7),
              ("k256n512g64", 256, 512, 64, 16), ("k384n256g128", 384, 256, 128, 33), ("k512n768g128", 512, 768, 128, 1)]
     for i, (name, K, N, G, M) in enumerate(cases):
@@ -153,6 +187,7 @@ def main():
         ref_wdeq=wdeq.numpy(), ref_y=y.numpy(),
     )
     print("wrote quant case")
+    make_pin(QUICK, GEMM, dequantize_gemm)
 
 
 if __name__ == "__main__":

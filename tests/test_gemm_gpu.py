@@ -115,7 +115,9 @@ def wide(mb, pairs):                  # explicit workgroup tile: mb * 32 tokens 
     return WIDE | (mb << 4) | (pairs << 8)
 
 
-WIDE_IDS = [WIDE] + [wide(mb, pairs) for mb in (2, 4, 8) for pairs in (1, 2)]
+WIDE_NORING = 1 << 12                 # 64- / 128-token tiles on the double-buffered kernel instead of the LDS-DMA ring
+WIDE_IDS = ([WIDE] + [wide(mb, pairs) for mb in (2, 4, 8) for pairs in (1, 2)] + [wide(mb, pairs) | WIDE_NORING for mb in (2, 4) for pairs in (1, 2)]
+            + [wide(2, 1) | (3 << 22), wide(2, 1) | (4 << 22), wide(2, 2) | (3 << 22)])     # shorter rings
 
 
 @pytest.mark.parametrize("kernel_id", [0, SKINNY_DZ, SKINNY_EXACT, TILED, TILED_MFMA32, TILED_16WAVES, TILED_WIDE, TILED_BIG] + WIDE_IDS)
@@ -281,6 +283,82 @@ def test_model_shapes(qa, device, K, N, M):
     assert rel_err(y.cpu().numpy(), want) <= TOL
 
 
+def _random_layer_and_sampled_oracle(qa, device, M, K, N, G, seed, ncols=256):
+    """A layer of random bits made on the GPU (MI355X order; the numpy packer would take minutes at these sizes), x, and
+    the ORACLE's result on `ncols` sampled output channels: the sampled channels are unpacked from the packed tensors with
+    the oracle's closed form (oracle.unpack_mi355x_columns) and pushed through oracle.w4a16_forward on the CPU."""
+    from quick_amd import packing
+    g = torch.Generator(device=device).manual_seed(seed)
+    qw, sc, qz = packing.random_mi355x(K, N, G, device, g)
+    x = (torch.randn(M, K, device=device, generator=g) * 0.5).half()
+    rng = np.random.default_rng(seed)
+    cols = np.unique(np.concatenate([rng.integers(0, N, ncols), [0, 15, 16, 127, 128, N - 129, N - 128, N - 1]]))
+    iw, s, z = oracle.unpack_mi355x_columns(qw.cpu().numpy(), sc.cpu().numpy(), qz.cpu().numpy(), cols)
+    want = oracle.w4a16_forward(x.cpu().numpy(), iw, s, z, G).astype(np.float32)
+    return (qw, sc, qz), x, cols, want
+
+
+# every GEMM shape of the three e2e configs (SURVEY.md appendix B; fused qkv and fused gate_up widths included) at the decode
+# batch sizes of BASELINE.json (1, 16, 64) -- Mistral-7B bs=64: (4096, 6144), (4096, 28672), (14336, 4096), (4096, 4096)
+E2E_SHAPES = [(4096, 4096), (4096, 12288), (4096, 22016), (11008, 4096),                       # Llama-2-7B
+              (4096, 6144), (4096, 14336), (4096, 28672), (14336, 4096),                        # Mistral-7B
+              (8192, 8192), (8192, 10240), (8192, 28672), (8192, 57344), (28672, 8192)]        # Llama-2-70B
+
+
+@pytest.mark.parametrize("K,N", E2E_SHAPES)
+@pytest.mark.parametrize("M", [1, 16, 64])
+def test_e2e_layer_shapes_sampled_channels_against_oracle(qa, device, K, N, M):
+    packed, x, cols, want = _random_layer_and_sampled_oracle(qa, device, M, K, N, 128, seed=K + N + M)
+    y = qa.gemm_forward(x, *packed)
+    assert tuple(y.shape) == (M, N)
+    got = y[:, torch.from_numpy(cols).to(device)].float().cpu().numpy()
+    assert float(np.abs(got - want).max()) <= TOL * float(np.abs(want).max())
+
+
+@pytest.mark.parametrize("kernel_id", [0, TILED, WIDE, wide(4, 2), wide(8, 2)], ids=["auto", "tiled", "wide", "wide128x256", "wide256x256"])
+@pytest.mark.parametrize("M,K,N", [(128, 4096, 12288), (2048, 4096, 12288), (8192, 4096, 6144), (2048, 8192, 10240), (1024, 11008, 4096)])
+def test_prefill_shapes_sampled_channels_against_oracle(qa, device, M, K, N, kernel_id):
+    """Prefill token counts (bs x 128) on real layer shapes, every large-M kernel family."""
+    packed, x, cols, want = _random_layer_and_sampled_oracle(qa, device, M, K, N, 128, seed=M + K + N, ncols=64)
+    y = qa.gemm_forward(x, *packed, kernel_id=kernel_id)
+    got = y[:, torch.from_numpy(cols).to(device)].float().cpu().numpy()
+    assert float(np.abs(got - want).max()) <= TOL * float(np.abs(want).max())
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE size pinned by the reference itself: tests/golden/pin_k4096n4096g128.npz (seed + hashes + sampled outputs)
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def pin(device):
+    from conftest import exact_layer
+    g = load_golden(golden_files("pin_")[0])
+    iw, s, z = exact_layer(int(g["K"]), int(g["N"]), int(g["G"]), int(g["seed"]))
+    return g, iw, s, z
+
+
+@pytest.mark.parametrize("kernel_id", [0, SKINNY_EXACT, SKINNY_DZ, TILED, WIDE], ids=["auto", "skinny-exact", "skinny-dz", "tiled", "wide"])
+def test_baseline_size_reference_pin(qa, device, pin, kernel_id):
+    """K = N = 4096, g = 128: the HIP result against sampled outputs of the REFERENCE's CPU path on the same layer."""
+    g, iw, s, z = pin
+    y = qa.gemm_forward(_dev(g["x"], device), *_pack_dev(iw, s, z, device), kernel_id=kernel_id).cpu().numpy().astype(np.float32)
+    ref = g["y_ref"].astype(np.float32)
+    assert float(np.abs(y[g["y_rows"], g["y_cols"]] - ref).max()) <= TOL * float(np.abs(ref).max())
+    assert float(np.abs(np.abs(y).sum(0) - g["col_abs_sum"]).max()) <= TOL * float(g["col_abs_sum"].max())
+
+
+@pytest.mark.parametrize("M", [64, 512])
+def test_baseline_size_reference_pin_at_bench_token_counts(qa, device, pin, M):
+    """The bench's token counts on the pinned layer: rows are the fixture's 16 rows repeated, so every row has a
+    reference-made value (rows of a GEMM are independent; test_baseline_rows_are_independent_of_batch)."""
+    g, iw, s, z = pin
+    x = np.tile(g["x"], (M // g["x"].shape[0], 1))
+    y = qa.gemm_forward(_dev(x, device), *_pack_dev(iw, s, z, device)).cpu().numpy().astype(np.float32)
+    ref = g["y_ref"].astype(np.float32)
+    for rep in (0, M // 16 - 1):
+        assert float(np.abs(y[g["y_rows"] + 16 * rep, g["y_cols"]] - ref).max()) <= TOL * float(np.abs(ref).max())
+    assert float(np.abs(np.abs(y).sum(0) - g["col_abs_sum"] * (M // 16)).max()) <= TOL * float(g["col_abs_sum"].max()) * (M // 16)
+
+
 # ------------------------------------------------------------------------------------------------
 # operator interface and error behaviour (csrc/gemm_cuda_quick.cu:1456-1517)
 # ------------------------------------------------------------------------------------------------
@@ -308,7 +386,7 @@ def test_reference_operator_signature_and_errors(qa, device):
     import quick_kernels
     M, K, N, G = 5, 256, 128, 128
     x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=3)
-    packed = _pack_dev(iw, s, z, device)
+    packed = [_dev(a, device) for a in oracle.pack_cuda_order(iw, s, z)]       # the REFERENCE's order, as its module holds it
     xd = _dev(x, device)
     want = oracle.w4a16_forward(x, iw, s, z, G)
     y8 = quick_kernels.gemm_forward_cuda_quick(xd, *packed, 8)
@@ -326,7 +404,89 @@ def test_reference_operator_signature_and_errors(qa, device):
     bad_g = [packed[0], torch.zeros(K // 16, 2 * N, dtype=torch.float16, device=device), torch.zeros(K // 16, N // 4, dtype=torch.int32, device=device)]
     with pytest.raises(ValueError, match="multiple of 32"):                    # line 1483
         quick_kernels.gemm_forward_cuda_quick(xd, *bad_g, 8)
-    assert tuple(qa.gemm_forward(xd[:0], *packed).shape) == (0, N)            # empty batch
+    mi = _pack_dev(iw, s, z, device)
+    assert tuple(qa.gemm_forward(xd[:0], *mi).shape) == (0, N)                # empty batch
+    with pytest.raises(ValueError, match="out must be"):                      # raw pointers are shape-checked on the way in
+        qa.gemm_forward(xd, *mi, out=torch.empty(M, N + 128, dtype=torch.float16, device=device))
+    with pytest.raises(RuntimeError, match="float16"):
+        qa.gemm_forward(xd, *mi, bias=torch.zeros(N, device=device))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[:-4])
+def test_function_level_drop_in_takes_reference_order_tensors(qa, device, path):
+    """What the reference's unchanged WQLinear_QUICK.forward does (quick/awq/modules/linear/quick.py:158-166): hand its own
+    buffers -- checkpoint order, quick.py:88-150 -- to quick_kernels.gemm_forward_cuda_quick.  The fixtures' ref_q* tensors
+    ARE those buffers (made by the reference packer), ref_y the reference CPU path's output for them."""
+    import quick_kernels
+    from quick_amd import kernels as K_
+    g = load_golden(path)
+    ref = [_dev(g[k], device) for k in ("ref_qweight", "ref_qscales", "ref_qzeros")]
+    x = _dev(g["x"], device)
+    y = quick_kernels.gemm_forward_cuda_quick(x, *ref, 8)
+    assert tuple(y.shape) == g["ref_y"].shape and rel_err(y.cpu().numpy(), g["ref_y"]) <= TOL
+    y1 = quick_kernels.gemm_forward_cuda_quick(x, *ref, 1)                    # split_k == 1: [1, M, N]
+    assert tuple(y1.shape) == (1,) + g["ref_y"].shape and torch.equal(y1[0], y)
+    n_cached = len(K_._REPACK_CACHE)
+    assert torch.equal(quick_kernels.gemm_forward_cuda_quick(x, *ref, 8), y) and len(K_._REPACK_CACHE) == n_cached   # cache hit
+    # an in-place rewrite of the buffers (load_state_dict / copy_) must invalidate the cached MI355X-order copy
+    other = oracle.make_synthetic(1, int(g["K"]), int(g["N"]), int(g["G"]), seed=77)[1:]
+    for t, a in zip(ref, oracle.pack_cuda_order(*other)):
+        t.copy_(_dev(a, device))
+    y2 = quick_kernels.gemm_forward_cuda_quick(x, *ref, 8)
+    assert rel_err(y2.cpu().numpy(), oracle.w4a16_forward(g["x"], *other, int(g["G"]))) <= TOL
+    # ... and the entry dies with the tensors
+    key = tuple(t.data_ptr() for t in ref)
+    assert key in K_._REPACK_CACHE
+    del ref, t
+    import gc
+    gc.collect()
+    assert key not in K_._REPACK_CACHE
+
+
+def test_function_level_drop_in_at_baseline_size(qa, device, pin):
+    import quick_kernels
+    g, iw, s, z = pin
+    ref = [_dev(a, device) for a in oracle.pack_cuda_order(iw, s, z)]
+    y = quick_kernels.gemm_forward_cuda_quick(_dev(g["x"], device), *ref, 8).cpu().numpy().astype(np.float32)
+    r = g["y_ref"].astype(np.float32)
+    assert float(np.abs(y[g["y_rows"], g["y_cols"]] - r).max()) <= TOL * float(np.abs(r).max())
+
+
+def test_fused_qkv_with_unequal_widths_runs_through_the_gemm(qa, device):
+    """GQA: q 4096 / k 1024 / v 1024 (the reference's fuse_qkv_quick raises here, quick/awq/utils/fused_utils.py:138-142):
+    three reference-format layers -> fuse_qkv_quick -> forward == the oracle on the concatenated layer."""
+    K, G = 4096, 128
+    mods, logical = [], []
+    for i, N in enumerate((4096, 1024, 1024)):
+        x, iw, s, z = oracle.make_synthetic(3, K, N, G, seed=500 + i)
+        m = qa.WQLinear_QUICK(4, G, K, N, False, "cpu")
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in zip(("qweight", "scales", "qzeros"), oracle.pack_cuda_order(iw, s, z))})
+        mods.append(m.to(device))
+        logical.append((iw, s, z))
+    mods[1].prepare()                                    # a mix of prepared and reference-order inputs
+    fused = qa.fuse_qkv_quick(None, *mods)
+    assert fused.out_features == 6144
+    x = oracle.make_synthetic(64, K, 128, G, seed=9)[0]
+    y = fused(_dev(x, device))
+    want = oracle.w4a16_forward(x, *[np.concatenate([l[i] for l in logical], axis=1) for i in range(3)], G)
+    assert fused.is_prepared and rel_err(y.cpu().numpy(), want) <= TOL
+    for m, l, lo in zip(mods, logical, (0, 4096, 5120)):          # and each part equals its own layer (other K split: not bitwise)
+        assert rel_err(m(_dev(x, device)).cpu().numpy(), y[:, lo:lo + l[0].shape[1]].cpu().numpy()) <= 1e-3
+
+
+def test_first_forward_under_inference_mode(qa, device):
+    """The reference runs every forward under torch.inference_mode() (quick/awq/modules/fused/model.py:76): the lazy
+    prepare() of the first forward creates inference tensors."""
+    g = load_golden(GOLD[0])
+    m = qa.WQLinear_QUICK(4, int(g["G"]), int(g["K"]), int(g["N"]), False, "cpu")
+    m.load_state_dict({"qweight": torch.from_numpy(g["ref_qweight"]), "scales": torch.from_numpy(g["ref_qscales"]),
+                       "qzeros": torch.from_numpy(g["ref_qzeros"])})
+    m = m.to(device)
+    with torch.inference_mode():
+        y = m(_dev(g["x"], device))
+        y_again = m(_dev(g["x"], device))
+    assert m.is_prepared and torch.equal(y, y_again) and rel_err(y.cpu().numpy(), g["ref_y"]) <= TOL
+    assert np.array_equal(m.state_dict()["qweight"].cpu().numpy(), g["ref_qweight"])
 
 
 def test_quantize_linear_end_to_end(qa, device):
@@ -583,6 +743,12 @@ def test_llama70b_shapes_against_dense_dequant(qa, device, K, N, M):
     y = layer(x)
     assert tuple(y.shape) == (M, N)
     assert float((y.float() - want).abs().max() / want.abs().max()) <= TOL
+    # second net, independent of the GPU's own dequantisation: 256 sampled channels through the CPU oracle
+    cols = np.unique(np.random.default_rng(K + N + M).integers(0, N, 256))
+    iw, s, z = oracle.unpack_mi355x_columns(layer.qweight.cpu().numpy(), layer.scales.cpu().numpy(), layer.qzeros.cpu().numpy(), cols)
+    ref = oracle.w4a16_forward(x.cpu().numpy(), iw, s, z, 128).astype(np.float32)
+    got = y[:, torch.from_numpy(cols).to(device)].float().cpu().numpy()
+    assert float(np.abs(got - ref).max()) <= TOL * float(np.abs(ref).max())
 
 
 def test_random_shapes_against_dequantised_matmul(qa, device):

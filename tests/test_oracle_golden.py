@@ -117,3 +117,31 @@ def test_cpu_reference_path_restatement(path):
     assert np.array_equal(w.numpy().view(np.uint16), g["ref_wdeq"].view(np.uint16))
     y = cpu_path.forward(torch.from_numpy(g["x"]), torch.from_numpy(qw), torch.from_numpy(qz), torch.from_numpy(s), G)
     assert rel_err(y.numpy(), g["ref_y"]) <= 2e-3      # same ops; host BLAS blocking may reorder the sums
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE size: K = N = 4096, g = 128 (fixture = seed + SHA-256 of the reference packer's output + sampled values)
+# ------------------------------------------------------------------------------------------------
+def test_baseline_size_pin_packer_dequant_and_forward():
+    import hashlib
+    from conftest import exact_layer
+    g = load_golden(golden_files("pin_")[0])
+    K, N, G = int(g["K"]), int(g["N"]), int(g["G"])
+    iw, s, z = exact_layer(K, N, G, int(g["seed"]))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    qw, qs, qz = oracle.pack_cuda_order(iw, s, z)                   # the oracle's packer == the reference packer, 4096^2
+    assert (sha(qw), sha(qs), sha(qz)) == (str(g["sha_qweight"]), str(g["sha_qscales"]), str(g["sha_qzeros"]))
+    iw2, s2, z2 = oracle.unpack_cuda_order(qw, qs, qz)
+    assert np.array_equal(iw2, iw) and np.array_equal(z2, z)
+    wdeq = oracle.dequantize(iw, s, z, G)                           # sampled weights: bit exact against dequantize_gemm
+    assert np.array_equal(wdeq[g["w_k"], g["w_n"]].view(np.uint16), g["w_ref"].view(np.uint16))
+    y = oracle.w4a16_forward(g["x"], iw, s, z, G)                   # sampled outputs of the reference CPU path
+    scale = float(np.abs(g["y_ref"].astype(np.float32)).max())
+    assert float(np.abs(y[g["y_rows"], g["y_cols"]].astype(np.float32) - g["y_ref"].astype(np.float32)).max()) <= 2e-3 * scale
+    cs = np.abs(y.astype(np.float32)).sum(0)
+    assert float(np.abs(cs - g["col_abs_sum"]).max()) <= 2e-3 * float(g["col_abs_sum"].max())
+    # the MI355X-order packer and its column sampler are inverses of each other at this size too
+    cols = np.array([0, 1, 15, 16, 17, 127, 128, 2049, 4095])
+    iwc, sc, zc = oracle.unpack_mi355x_columns(*oracle.pack_mi355x(iw, s, z), cols)
+    assert np.array_equal(iwc, iw[:, cols]) and np.array_equal(zc, z[:, cols])
+    assert np.array_equal(sc.view(np.uint16), s[:, cols].view(np.uint16))

@@ -26,9 +26,18 @@ def wide(mb, pairs):
     return WIDE | (mb << 4) | (pairs << 8)
 
 
+NORING = 1 << 12
+
+
+def ring(n):
+    return n << 22
+
+
 DEFAULT_VARIANTS = {
-    "auto": (0, 0), "tiled": (2, 0), "tiled_big": (2 | (1 << 27), 0), "tiled_wide": (2 | (1 << 29), 0),
-    "w2x1": (wide(2, 1), 0), "w2x2": (wide(2, 2), 0), "w4x1": (wide(4, 1), 0), "w4x2": (wide(4, 2), 0),
+    "auto": (0, 0), "tiled": (2, 0), "tiled_big": (2 | (1 << 27), 0),
+    "w2x1": (wide(2, 1), 0), "w2x1n4": (wide(2, 1) | ring(4), 0), "w2x1n3": (wide(2, 1) | ring(3), 0), "w2x1nr": (wide(2, 1) | NORING, 0),
+    "w2x2": (wide(2, 2), 0), "w2x2nr": (wide(2, 2) | NORING, 0),
+    "w4x1": (wide(4, 1), 0), "w4x1nr": (wide(4, 1) | NORING, 0), "w4x2": (wide(4, 2), 0), "w4x2nr": (wide(4, 2) | NORING, 0),
     "w8x1": (wide(8, 1), 0), "w8x2": (wide(8, 2), 0),
 }
 
@@ -40,6 +49,7 @@ def main():
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--G", type=int, default=128)
     ap.add_argument("--out", default="")
+    ap.add_argument("--xfill", default="randn", help="randn | zeros | ones: what the activations hold (DVFS experiments)")
     args = ap.parse_args()
     variants = dict(DEFAULT_VARIANTS)
     if args.variants:
@@ -62,6 +72,10 @@ def main():
         arr = lambda i: (ctypes.c_void_p * ns)(*[st[i].data_ptr() for st in sets])
         qa_, sa_, za_ = arr(0), arr(1), arr(2)
         x = (torch.randn((M, K), device=dev, generator=gen) * 0.5).half()
+        if args.xfill == "zeros":
+            x.zero_()
+        elif args.xfill == "ones":
+            x.fill_(1.0)
         y = torch.empty((M, N), dtype=torch.float16, device=dev)
         ref = gemm_forward(x, *sets[0]).float()
         scale = float(ref.abs().max())
