@@ -1257,9 +1257,10 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-// ring slots that fit the 160 KiB of LDS for a (MB, PAIRS) tile at one (scale, zero) word per pair and stage (G % 128 == 0)
-constexpr int wide_ring_nbuf(int mb, int pairs) {
-  const int slot = mb * 8192 + pairs * 8192 + pairs * 1024;
+// ring slots that fit the 160 KiB of LDS for a (MB, PAIRS) tile at one (scale, zero) word per pair and stage (G % 128 == 0);
+// wk = waves along K (1: four waves, 2: eight)
+constexpr int wide_ring_nbuf(int mb, int pairs, int wk = 1) {
+  const int slot = mb * 8192 + pairs * 8192 + wk * pairs * 1024;
   const int n = (160 * 1024) / slot;
   return n > 6 ? 6 : n;
 }
@@ -1342,10 +1343,12 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     if (N % (pairs * 128) != 0) pairs = 1;
     p.wide_mb = mb;
     p.wide_pairs = pairs;
-    // bit 12: no ring (the double-buffered kernel at every tile size); bits 22-24: ring slots (0 = as many as fit, up to 6)
-    const int nb_req = (kernel >> 22) & 7, nb_max = mb == 8 ? 0 : wide_ring_nbuf(mb, pairs);
+    // bit 12: no ring (the double-buffered kernel at every tile size); bits 22-24: ring slots (0 = as many as fit, up to 6);
+    // bit 15: eight waves per workgroup (two per SIMD, k16 steps split by parity) -- ring kernel, tiles up to 128 x 128 / 64 x 256
+    const bool eight = ((kernel >> 15) & 1) && mb * pairs <= 4 && !no_xlds;
+    const int nb_req = (kernel >> 22) & 7, nb_max = mb == 8 ? 0 : wide_ring_nbuf(mb, pairs, eight ? 2 : 1);
     p.wide_nbuf = (no_xlds || nb_max < 3) ? 0 : (nb_req >= 3 ? std::min(nb_req, nb_max) : nb_max);
-    p.waves = 4;
+    p.waves = (eight && p.wide_nbuf >= 3) ? 8 : 4;
     p.tch = pairs * 128;
     const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / p.tch;
     p.ntiles = MBk * NBk;
@@ -1635,13 +1638,13 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
 #undef QA_TILED_K
 }
 
-template <int MB, int PAIRS, int NBUF>
+template <int MB, int PAIRS, int NBUF, int WK = 1>
 static void launch_ring(const Plan& p, const GemmArgs& a, const Launch& L) {
-  dim3 grid(p.ntiles, p.ksplit), block(256);
-  constexpr unsigned lds = NBUF * (MB * 8192 + PAIRS * 8192 + PAIRS * 1024);
+  dim3 grid(p.ntiles, p.ksplit), block(256 * WK);
+  constexpr unsigned lds = NBUF * (MB * 8192 + PAIRS * 8192 + WK * PAIRS * 1024);
 #define QA_RING_K(GMV)                                                                                             \
   do {                                                                                                             \
-    auto kfn = w4a16_ring_kernel<MB, PAIRS, GMV, NBUF>;                                                            \
+    auto kfn = w4a16_ring_kernel<MB, PAIRS, GMV, NBUF, 0, WK>;                                                     \
     static bool attr_set = false;                                                                                  \
     if (!attr_set) {                                                                                               \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
@@ -1649,13 +1652,23 @@ static void launch_ring(const Plan& p, const GemmArgs& a, const Launch& L) {
     }                                                                                                              \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
-  if constexpr (MB == 2 && PAIRS == 1 && NBUF == 6)
+  if constexpr (MB == 2 && PAIRS == 1 && NBUF == 6 && WK == 1)
     if (p.ablate && a.G == 128) {  // timing experiments (results are wrong on purpose)
       auto kfn1 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 1>;
       auto kfn2 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 2>;
       auto kfn5 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 5>;
       auto kfn9 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 9>;
-      auto kfn = p.ablate == 1 ? kfn1 : (p.ablate == 5 ? kfn5 : (p.ablate == 9 ? kfn9 : kfn2));
+      auto kfn18 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 18>;
+      auto kfn = p.ablate == 1 ? kfn1 : (p.ablate == 5 ? kfn5 : (p.ablate == 9 ? kfn9 : (p.ablate == 18 ? kfn18 : kfn2)));
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
+      return;
+    }
+  if constexpr (MB == 2 && PAIRS == 1 && WK == 2)
+    if (p.ablate && a.G == 128) {
+      auto kfn1 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 1, WK>;
+      auto kfn2 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 2, WK>;
+      auto kfn = p.ablate == 1 ? kfn1 : kfn2;
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
       return;
@@ -1667,6 +1680,15 @@ static void launch_ring(const Plan& p, const GemmArgs& a, const Launch& L) {
 
 template <int MB, int PAIRS>
 static void launch_wide(const Plan& p, const GemmArgs& a, const Launch& L) {
+  if constexpr (MB <= 4 && MB * PAIRS <= 4) {
+    if (p.wide_nbuf >= 3 && p.waves == 8) {  // eight waves (two per SIMD), the k16 steps split by parity
+      constexpr int NMAX8 = wide_ring_nbuf(MB, PAIRS, 2);
+      if (p.wide_nbuf == 3) launch_ring<MB, PAIRS, 3, 2>(p, a, L);
+      else if (NMAX8 >= 4 && p.wide_nbuf == 4) launch_ring<MB, PAIRS, (NMAX8 >= 4 ? 4 : 3), 2>(p, a, L);
+      else launch_ring<MB, PAIRS, NMAX8, 2>(p, a, L);
+      return;
+    }
+  }
   if constexpr (MB <= 4) {
     if (p.wide_nbuf >= 3) {
       constexpr int NMAX = wide_ring_nbuf(MB, PAIRS);
@@ -1825,8 +1847,8 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
              p.xlds ? "lds" : "l2", p.dz ? (p.xlds ? "deferred-zero-table" : "deferred-zero-fragment") : "exact", p.grid_x,
              (M + 15) / 16, p.ksplit, p.ksplit, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_WIDE)
-    snprintf(text, text_bytes, "wide tokens=%d channels=%d waves=4 ring=%d grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
-             p.tch, p.wide_nbuf, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
+    snprintf(text, text_bytes, "wide tokens=%d channels=%d waves=%d ring=%d grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
+             p.tch, p.waves, p.wide_nbuf, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
   else
     snprintf(text, text_bytes, "tiled tokens=%d channels=%d waves=%d grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.mt * 16,
              p.tch, p.wn2 ? 8 : p.waves, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));

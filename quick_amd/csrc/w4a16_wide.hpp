@@ -54,30 +54,33 @@ struct WideW {  // one 128-k tile of this wave's weights: per 32-channel pair th
   uint32_t sz[PAIRS][groups_per_tile<GM>()];
 };
 
-template <int MB>
+template <int NX>
 struct WideBufs {
   __amdgpu_buffer_rsrc_t x, w, s;
-  unsigned x_voff[MB * 2];  // per LDS-DMA instruction of a stage: clamped row * K * 2 + swizzled chunk * 16
+  unsigned x_voff[NX];  // per LDS-DMA instruction of a stage: clamped row * K * 2 + swizzled chunk * 16
   unsigned w_voff, s_voff;
   unsigned w_pstride;  // bytes between consecutive 32-channel pairs of the weights
   unsigned s_pstride;  // ... of the (scale, zero point) words
 };
 
-// Descriptors and per-lane offsets.  x: instruction i of a wave moves rows 16 i + 4 wave + lane / 16 of the token tile,
-// lane % 16 picks the 16-byte chunk (the row's chunk c lands at LDS chunk c ^ (row % 16), so the lane writing LDS chunk
-// lane % 16 fetches source chunk (lane % 16) ^ (row % 16)).  Rows past M replay row M - 1 (never stored).
-template <int MB, int PAIRS>
-__device__ __forceinline__ WideBufs<MB> wide_bufs(const GemmArgs& a, int m0, int ct0, int lane, int wave) {
-  WideBufs<MB> b;
+// Descriptors and per-lane offsets.  x: with NW = 4 WK waves, instruction i of a wave moves rows 4 NW i + 4 wave + lane / 16
+// of the token tile, lane % 16 picks the 16-byte chunk (the row's chunk c lands at LDS chunk c ^ (row % 16), so the lane
+// writing LDS chunk lane % 16 fetches source chunk (lane % 16) ^ (row % 16)).  Rows past M replay row M - 1 (never stored).
+// WK = 2 (eight waves, the two halves of a workgroup split the k16 steps of every stage by parity): wave (wn, wk) takes only
+// the "lo" (wk = 0) or "hi" (wk = 1) 16 bytes of its weights -- w_voff points at its half.
+template <int MB, int PAIRS, int WK = 1>
+__device__ __forceinline__ WideBufs<MB * 2 / WK> wide_bufs(const GemmArgs& a, int m0, int ct0, int lane, int wave) {
+  constexpr int NW = 4 * WK, NX = MB * 2 / WK;
+  WideBufs<NX> b;
   const int KT = a.K >> 7, NGRP = a.K / a.G;
   const unsigned rho = (unsigned)lane & 31u, h = (unsigned)lane >> 5;
   const unsigned xrow = 4u * (unsigned)wave + ((unsigned)lane >> 4);
   b.x = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (unsigned)a.M * (unsigned)a.K * 2u, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < MB * 2; ++i)
-    b.x_voff[i] = (unsigned)min(m0 + 16 * i + (int)xrow, a.M - 1) * (unsigned)a.K * 2u + 16u * (((unsigned)lane & 15u) ^ xrow);
+  for (int i = 0; i < NX; ++i)
+    b.x_voff[i] = (unsigned)min(m0 + 4 * NW * i + (int)xrow, a.M - 1) * (unsigned)a.K * 2u + 16u * (((unsigned)lane & 15u) ^ (xrow & 15u));
   b.w = __builtin_amdgcn_make_buffer_rsrc((void*)(a.QW + (size_t)ct0 * KT * 64), 0, (unsigned)(2 * PAIRS) * (unsigned)KT * 1024u, 0x00020000);
-  b.w_voff = (rho >> 4) * (unsigned)KT * 1024u + 16u * ((rho & 15u) + 16u * h);
+  b.w_voff = (rho >> 4) * (unsigned)KT * 1024u + 16u * ((rho & 15u) + 16u * h) + (WK == 2 ? ((unsigned)wave >> 2) * 512u : 0u);
   b.w_pstride = 2u * (unsigned)KT * 1024u;
   b.s = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint32_t*)a.S + (size_t)ct0 * NGRP * 16), 0, (unsigned)(2 * PAIRS) * (unsigned)NGRP * 64u, 0x00020000);
   b.s_voff = (rho >> 4) * (unsigned)NGRP * 64u + 4u * (rho & 15u);
@@ -111,27 +114,80 @@ __device__ __forceinline__ half8_t dequant8(uint32_t q, const GroupQ& g, const D
 }
 
 // One stage = 8 k16 steps x PAIRS "units"; unit u = (k16 step kk, pair p) is MB MFMAs sharing one dequantised A fragment.
-// Software pipeline inside the stage: while the MFMAs of unit u run, the VALU dequantises the fragment of unit u + 1 and
-// (p == 0) the LDS returns the B fragments of step kk + 1.  sched_group_barrier spells the interleave out -- one MFMA,
-// then its share of the VALU ops and one ds_read -- because hipcc otherwise emits "13 VALU, then MB MFMAs back to back":
-// an in-order wave issues the VALU block only after the last MFMA of the unit has issued, i.e. mostly in the open.
+// Software pipeline: while the MFMAs of unit u run, the VALU dequantises the fragment of unit u + 1 and (p == 0) the LDS
+// returns the B fragments of step kk + 1.  The pipeline runs ACROSS the stage boundary: the last unit of a stage prepares
+// the first unit of the next one -- group constants and A fragment from the next stage's weights (already in registers),
+// and, where the caller guarantees that the next stage's tokens have landed (PRE_B: the ring kernel), its B fragments --
+// into `carry`, so that the first MFMA of a stage issues right behind the barrier.  sched_group_barrier spells the
+// interleave out -- one MFMA, then its share of the VALU ops and one ds_read -- because hipcc otherwise emits "13 VALU,
+// then MB MFMAs back to back": an in-order wave issues the VALU block only after the last MFMA has issued, i.e. in the open.
 // `hook(u)` runs at the head of unit u: the callers spread their LDS-DMA issue (and the ring kernel its early weight
-// read) over the units with it -- a wave that issues a stage's 16 KiB of LDS-DMA in one go keeps the CU's 64 B/clk vector
-// memory path busy for ~1000 cycles during which no wave issues an MFMA.
+// read) over the units with it -- a wave that issues a stage's 16 KiB of LDS-DMA in one go keeps the CU's vector memory
+// path busy for ~1000 cycles during which no wave issues an MFMA.
 // ABL (timing experiments only, results are wrong): 1 = no compute (hooks only), 2 = the callers issue no loads in the K loop.
-template <int MB, int PAIRS, int GM, int ABL = 0, class Hook>
-__device__ __forceinline__ void wide_compute(const WideW<PAIRS, GM>& w, unsigned xb, const DqConsts& dq, floatx16 (&acc)[PAIRS][MB],
-                                             Hook&& hook) {
+// B fragments are requested DEPTH k16 steps ahead of their MFMAs: a step is MB * PAIRS MFMAs = 32 * MB * PAIRS cycles, an
+// LDS round trip under load 130-200, so short steps need a longer lead (first build: lead 1 everywhere -- at MB = 2 every
+// MFMA waited ~100 cycles for a fragment requested eight instructions earlier).
+template <int MB, int PAIRS>
+constexpr int wide_bdepth() { return MB * PAIRS >= 8 ? 1 : (MB * PAIRS >= 4 ? 2 : 3); }
+
+template <int MB, int PAIRS, int GM>
+struct WideCarry {
+  half8_t af;
+  half8_t bf[wide_bdepth<MB, PAIRS>()][MB];
+  GroupQ grp[PAIRS][groups_per_tile<GM>()];
+};
+
+// fragments of this wave's step i (WK = 2: the wave owns k16 steps 2 i + wk, and xb already carries the ^ (wk << 5))
+template <int MB, int WK = 1, int ABL = 0>
+__device__ __forceinline__ void wide_read_frags(unsigned xb, int i, half8_t (&f)[MB]) {
   typedef const __attribute__((address_space(3))) char* lds_ptr;
+  if constexpr (ABL & 16) {  // timing experiment: no LDS reads, the fragments are whatever the registers hold
+#pragma unroll
+    for (int mt = 0; mt < MB; ++mt) asm volatile("" : "=v"(f[mt]));
+    return;
+  }
+  const lds_ptr xk = (lds_ptr)(uintptr_t)(xb ^ (unsigned)(i << (WK == 2 ? 6 : 5)));  // chunk (2 kk + h) ^ (rho % 16) of this lane's row
+#pragma unroll
+  for (int mt = 0; mt < MB; ++mt) f[mt] = *(const __attribute__((address_space(3))) half8_t*)(xk + mt * 8192);
+}
+template <int PAIRS, int GM, int WK = 1>
+__device__ __forceinline__ half8_t wide_frag(const WideW<PAIRS, GM>& w, const GroupQ (&grp)[PAIRS][groups_per_tile<GM>()], int u,
+                                             const DqConsts& dq) {
+  const int i = u / PAIRS, p = u % PAIRS;
+  const int t = WK == 2 ? i : (i >> 1);  // the k32 step, i.e. the dword of the lane's 16 bytes
+  const uint32_t q = WK == 2 ? w.lo[p][t] : ((i & 1) ? w.hi[p][t] : w.lo[p][t]);
+  return dequant8(q, grp[p][group_slot<GM>(t)], dq);
+}
+// what the first unit of a stage needs, from that stage's weights (and, PRE_B, its landed tokens at LDS address xb)
+template <int MB, int PAIRS, int GM, bool PRE_B, int WK = 1>
+__device__ __forceinline__ void wide_prepare(WideCarry<MB, PAIRS, GM>& c, const WideW<PAIRS, GM>& w, unsigned xb, const DqConsts& dq) {
   constexpr int NG = groups_per_tile<GM>();
-  constexpr int NU = 8 * PAIRS;
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+    for (int i = 0; i < NG; ++i) c.grp[p][i] = make_group(GroupRaw{w.sz[p][i]}, LaneSel{});
+  c.af = wide_frag<PAIRS, GM, WK>(w, c.grp, 0, dq);
+  if constexpr (PRE_B) {
+#pragma unroll
+    for (int d = 0; d < wide_bdepth<MB, PAIRS>(); ++d) wide_read_frags<MB, WK>(xb, d, c.bf[d]);
+  }
+}
+
+template <int MB, int PAIRS, int GM, int ABL = 0, bool PRE_B = false, int WK = 1, class Hook>
+__device__ __forceinline__ void wide_compute(const WideW<PAIRS, GM>& w, const WideW<PAIRS, GM>& wnext, unsigned xb, unsigned xb_next,
+                                             const DqConsts& dq, floatx16 (&acc)[PAIRS][MB], WideCarry<MB, PAIRS, GM>& carry,
+                                             Hook&& hook) {
+  constexpr int NG = groups_per_tile<GM>();
+  constexpr int NSTEP = 8 / WK;  // k16 steps of the stage this wave computes
+  constexpr int NU = NSTEP * PAIRS;
   if constexpr (ABL & 1) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       hook(u);
       __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("" ::"v"(w.lo[0]), "v"(w.hi[0]), "v"(w.sz[0][0]));
+    asm volatile("" ::"v"(w.lo[0]), "v"(w.hi[0]), "v"(w.sz[0][0]), "v"(wnext.lo[0]));
     return;
   }
   constexpr int VPM = (14 + MB - 1) / MB;  // VALU ops placed behind each MFMA (13 per fragment + the address xor)
@@ -139,36 +195,50 @@ __device__ __forceinline__ void wide_compute(const WideW<PAIRS, GM>& w, unsigned
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p)
 #pragma unroll
-    for (int i = 0; i < NG; ++i) grp[p][i] = make_group(GroupRaw{w.sz[p][i]}, LaneSel{});
-  half8_t bf[2][MB], af[2];
-  auto read_frags = [&](int kk, half8_t (&f)[MB]) {
-    const lds_ptr xk = (lds_ptr)(uintptr_t)(xb ^ (unsigned)(kk << 5));  // chunk (2 kk + h) ^ (rho % 16) of this lane's row
+    for (int i = 0; i < NG; ++i) grp[p][i] = carry.grp[p][i];
+  constexpr int DEPTH = wide_bdepth<MB, PAIRS>(), NBF = DEPTH + 1;
+  static_assert(DEPTH < NSTEP, "fragment lead longer than the stage");
+  half8_t bf[NBF][MB], af[2];
+  af[0] = carry.af;
+  if constexpr (PRE_B) {
 #pragma unroll
-    for (int mt = 0; mt < MB; ++mt) f[mt] = *(const __attribute__((address_space(3))) half8_t*)(xk + mt * 8192);
-  };
-  auto frag = [&](int u) {
-    const int kk = u / PAIRS, p = u % PAIRS;
-    const uint32_t q = (kk & 1) ? w.hi[p][kk >> 1] : w.lo[p][kk >> 1];
-    return dequant8(q, grp[p][group_slot<GM>(kk >> 1)], dq);
-  };
-  read_frags(0, bf[0]);
-  af[0] = frag(0);
-  __builtin_amdgcn_sched_barrier(0);
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int mt = 0; mt < MB; ++mt) bf[d][mt] = carry.bf[d][mt];
+  } else {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) wide_read_frags<MB, WK, ABL>(xb, d, bf[d]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int kk = u / PAIRS, p = u % PAIRS;
-    const bool reads = p == 0 && kk < 7;
+    const bool last = u + 1 == NU;
+    const int ahead = kk + DEPTH;  // the step whose fragments this unit requests (p == 0 units only)
+    const bool reads = p == 0 && (ahead < NSTEP || PRE_B);
     hook(u);
     __builtin_amdgcn_sched_barrier(0);
-    if (u + 1 < NU) af[(u + 1) & 1] = frag(u + 1);
-    if (reads) read_frags(kk + 1, bf[(kk + 1) & 1]);
+    if (reads) {
+      if (ahead < NSTEP) wide_read_frags<MB, WK, ABL>(xb, ahead, bf[ahead % NBF]);
+      else wide_read_frags<MB, WK, ABL>(xb_next, ahead - NSTEP, carry.bf[ahead - NSTEP]);  // the next stage's first steps (PRE_B: landed)
+    }
+    if (!last) {
+      af[(u + 1) & 1] = wide_frag<PAIRS, GM, WK>(w, grp, u + 1, dq);
+    } else {  // the next stage's group constants and first A fragment
 #pragma unroll
-    for (int mt = 0; mt < MB; ++mt) acc[p][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u & 1], bf[kk & 1][mt], acc[p][mt], 0, 0, 0);
+      for (int pp = 0; pp < PAIRS; ++pp)
+#pragma unroll
+        for (int i = 0; i < NG; ++i) carry.grp[pp][i] = make_group(GroupRaw{wnext.sz[pp][i]}, LaneSel{});
+      carry.af = wide_frag<PAIRS, GM, WK>(wnext, carry.grp, 0, dq);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MB; ++mt) acc[p][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u & 1], bf[kk % NBF][mt], acc[p][mt], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < MB; ++mt) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // MFMA
-      if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);  // VALU
-      if (reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // DS read
+      if (reads && !(ABL & 16)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+      if (last) __builtin_amdgcn_sched_group_barrier(0x002, VPM + (4 * PAIRS * NG + MB - 1) / MB, 0);  // VALU (+ the group constants)
+      else __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -201,23 +271,28 @@ __device__ __forceinline__ WideTile wide_tile(const GemmArgs& a) {
 }
 
 // K split across workgroups (slab = [(p, mt, c)][wave][lane] floatx4) and the fused epilogue.
+// `wave` = the wave's index along N (0..3); waves with active == false (the second K half of an eight-wave workgroup, whose
+// partial was already added in) only take part in the workgroup barriers.
 template <int MB, int PAIRS>
 __device__ __forceinline__ void wide_finish(const GemmArgs& a, const WideTile& t, floatx16 (&acc)[PAIRS][MB], char* smem, int ct0,
-                                            int lane, int wave) {
+                                            int lane, int wave, bool active = true) {
   const int rho = lane & 31, h = lane >> 5;
   if (a.ksplit > 1) {
     constexpr unsigned SLAB_BYTES = PAIRS * MB * 16384;
     const __amdgpu_buffer_rsrc_t rs = slab_rsrc(a.slabs + (size_t)blockIdx.x * a.ksplit * (SLAB_BYTES / 4), a.ksplit * SLAB_BYTES);
     const unsigned my = ((unsigned)wave * 64u + (unsigned)lane) * 16u;
+    if (active) {
 #pragma unroll
-    for (int p = 0; p < PAIRS; ++p)
+      for (int p = 0; p < PAIRS; ++p)
 #pragma unroll
-      for (int mt = 0; mt < MB; ++mt)
+        for (int mt = 0; mt < MB; ++mt)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          slab_store(rs, t.ks * SLAB_BYTES + ((p * MB + mt) * 4 + c) * 4096 + my,
-                     floatx4{acc[p][mt][4 * c], acc[p][mt][4 * c + 1], acc[p][mt][4 * c + 2], acc[p][mt][4 * c + 3]});
+          for (int c = 0; c < 4; ++c)
+            slab_store(rs, t.ks * SLAB_BYTES + ((p * MB + mt) * 4 + c) * 4096 + my,
+                       floatx4{acc[p][mt][4 * c], acc[p][mt][4 * c + 1], acc[p][mt][4 * c + 2], acc[p][mt][4 * c + 3]});
+    }
     if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
+    if (!active) return;
     // every slice is read back from its slab (the own one too) and added in index order: the sum does not depend on
     // who arrived last, and no second copy of the accumulators is needed
     for (int o = 0; o < a.ksplit; ++o) {
@@ -234,6 +309,7 @@ __device__ __forceinline__ void wide_finish(const GemmArgs& a, const WideTile& t
     }
   }
 
+  if (!active) return;
   // lane = token m0 + 32 mt + rho, channels ch0 + 32 p + 8 c + 4 h .. + 3 (c = r / 4)
   const int ch0 = ct0 * 16;
   if (a.silu_mul) {  // gate / up interleaved by 8: c = 0, 2 gate of the two 16-channel tiles, c = 1, 3 their up
@@ -290,7 +366,7 @@ __device__ __forceinline__ void wide_zero(floatx16 (&acc)[PAIRS][MB]) {
 // 256-token tiles: x double-buffered in LDS, weights HBM -> VGPR one stage ahead
 // ------------------------------------------------------------------------------------------------
 template <int MB, int PAIRS, int GM>
-__device__ __forceinline__ void wide_load_w(WideW<PAIRS, GM>& w, const WideBufs<MB>& b, int kt, const GemmArgs& a) {
+__device__ __forceinline__ void wide_load_w(WideW<PAIRS, GM>& w, const WideBufs<MB * 2>& b, int kt, const GemmArgs& a) {
   constexpr int NG = groups_per_tile<GM>();
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p) {
@@ -319,7 +395,7 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
   const int rho = lane & 31, h = lane >> 5;
   const WideTile t = wide_tile<MB, PAIRS>(a);
   const int ct0 = (t.nb * 4 + wave) * PAIRS * 2;  // first 16-channel tile of this wave
-  const WideBufs<MB> b = wide_bufs<MB, PAIRS>(a, t.m0, ct0, lane, wave);
+  const WideBufs<MB * 2> b = wide_bufs<MB, PAIRS>(a, t.m0, ct0, lane, wave);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned lds0 = lds_base + (unsigned)wave * 1024u;  // LDS-DMA destination of this wave's first instruction: rows 4 w .. 4 w + 3
   // B-fragment read address of this lane in stage buffer 0, token tile 0, k16 step 0: row rho, chunk h ^ (rho % 16)
@@ -341,6 +417,8 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __builtin_amdgcn_s_barrier();
+  WideCarry<MB, PAIRS, GM> carry;
+  wide_prepare<MB, PAIRS, GM, false>(carry, wc, 0u, dq);
 
   for (int s = 0; s < t.nstage; ++s) {
     const int ktn = min(t.kt_lo + s + 1, t.kt_hi - 1);
@@ -349,7 +427,7 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
     if constexpr (!(ABL & 2)) wide_load_w<MB, PAIRS, GM>(wn, b, ktn, a);
     else wn = wc;
     __builtin_amdgcn_sched_barrier(0);
-    wide_compute<MB, PAIRS, GM, ABL>(wc, xrd + par * STAGE_BYTES, dq, acc, [&](int u) {
+    wide_compute<MB, PAIRS, GM, ABL, false>(wc, wn, xrd + par * STAGE_BYTES, 0u, dq, acc, carry, [&](int u) {
       // this unit's share of the next stage's LDS-DMA (all of it issued two units before the stage ends)
       constexpr int PER = (XI + NU - 3) / (NU - 2);
 #pragma unroll
@@ -369,33 +447,43 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
 // ------------------------------------------------------------------------------------------------
 // 64- / 128-token tiles: everything by LDS-DMA into a ring of NBUF stage slots, counted vmcnt
 // ------------------------------------------------------------------------------------------------
-// Slot = [x: MB * 8 KiB][packed weights: 4 waves x PAIRS x (lo, hi) KiB][(scale, zero) words: 4 waves x PAIRS x NG x 256 B].
+// Slot = [x: MB * 8 KiB][packed weights: PAIRS * 8 KiB, 1 KiB pieces per wave][(scale, zero) words: NW waves x PAIRS x NG x 256 B].
 // At the top of iteration s the slots hold stages s .. s + NBUF - 2: s and s + 1 landed and visible to every wave (s + 1
-// because a wave reads its stage-(s + 1) weights out of the slot during stage s), the rest in flight; slot (s - 1) % NBUF
-// was released by the barrier that ended iteration s - 1 and receives stage s + NBUF - 1, issued over the units of stage s.
-// Every wave issues the same L = MB * 2 + PAIRS * 2 + PAIRS * NG LDS-DMA instructions per stage, so "stage s + 2 has
+// because a wave reads its stage-(s + 1) weights and first token fragments out of the slot during stage s), the rest in
+// flight; slot (s - 1) % NBUF was released by the barrier that ended iteration s - 1 and receives stage s + NBUF - 1,
+// issued over the units of stage s.  Every wave issues the same L LDS-DMA instructions per stage, so "stage s + 2 has
 // landed" is s_waitcnt vmcnt((NBUF - 3) * L) at the end of iteration s, followed by the one barrier of the stage.
-template <int MB, int PAIRS, int GM, int NBUF, int ABL = 0>
-__global__ __launch_bounds__(256) void w4a16_ring_kernel(const GemmArgs a) {
+//
+// WK = 2: EIGHT waves, two per SIMD -- wave (wn, wk) owns the channels of wave wn and the k16 steps of parity wk of every
+// stage (for wk = 0 these are the "lo" dwords of its weights, for wk = 1 the "hi" ones: no weight is fetched or dequantised
+// twice).  One wave alone on a SIMD issues ~1 instruction per 6 cycles on this instruction mix (dependent packed-f16 chains,
+// waits): at 64 tokens per tile that, not the matrix pipe, bounds the stage.  Two waves interleave.  The two K halves are
+// added through LDS after the loop.
+template <int MB, int PAIRS, int GM, int NBUF, int ABL = 0, int WK = 1>
+__global__ __launch_bounds__(256 * WK) void w4a16_ring_kernel(const GemmArgs a) {
   constexpr int NG = groups_per_tile<GM>();
-  constexpr int X_BYTES = MB * 8192, W_BYTES = PAIRS * 8192, S_BYTES = PAIRS * NG * 1024;
+  constexpr int NW = 4 * WK;
+  constexpr int X_BYTES = MB * 8192, W_BYTES = PAIRS * 8192, S_BYTES = NW * PAIRS * NG * 256;
   constexpr int SLOT = X_BYTES + W_BYTES + S_BYTES;
-  constexpr int XI = MB * 2, LW = PAIRS * 2, LS = PAIRS * NG, L = XI + LW + LS, NU = 8 * PAIRS;
+  constexpr int XI = MB * 2 / WK, LW = PAIRS * 2 / WK, LS = PAIRS * NG, L = XI + LW + LS, NU = 8 / WK * PAIRS;
   constexpr int PENDING = (NBUF - 3) * ((ABL & 4) ? LW + LS : ((ABL & 8) ? XI : L));
   static_assert(NBUF >= 3 && NBUF * SLOT <= 160 * 1024 && PENDING <= 63, "ring does not fit LDS / the vmcnt field");
+  static_assert(WK == 1 || (WK - 1) * 4 * PAIRS * MB * 4096 <= NBUF * SLOT, "K-half exchange must fit in the ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF * SLOT
 
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
+  const int wn = wave & 3, wk = wave >> 2;
   const int rho = lane & 31, h = lane >> 5;
   const WideTile t = wide_tile<MB, PAIRS>(a);
-  const int ct0 = (t.nb * 4 + wave) * PAIRS * 2;
-  const WideBufs<MB> b = wide_bufs<MB, PAIRS>(a, t.m0, ct0, lane, wave);
+  const int ct0 = (t.nb * 4 + wn) * PAIRS * 2;
+  const WideBufs<XI> b = wide_bufs<MB, PAIRS, WK>(a, t.m0, ct0, lane, wave);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned xdst = lds_base + (unsigned)wave * 1024u;                           // + slot + i * 4096
-  const unsigned wdst = lds_base + X_BYTES + (unsigned)wave * (PAIRS * 2048);        // + slot + (2 p + hi) * 1024
+  const unsigned xdst = lds_base + (unsigned)wave * 1024u;                           // + slot + i * NW KiB
+  const unsigned wdst = lds_base + X_BYTES + (unsigned)wave * (LW * 1024);           // + slot + piece * 1024
   const unsigned sdst = lds_base + X_BYTES + W_BYTES + (unsigned)wave * (LS * 256);  // + slot + (p * NG + i) * 256
-  const unsigned xrd = lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4);
+  // B-fragment read address of this lane: row rho, chunk (k16 step wk) * 2 + h, swizzled by rho % 16
+  const unsigned xrd = (lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4)) ^ (WK == 2 ? (unsigned)wk << 5 : 0u);
   const unsigned w_voff_hi = b.w_voff + 512u;
 
   // item j of stage kt -> slot at byte offset `slot`: the x rows first, then the packed weights, then the group words
@@ -403,10 +491,11 @@ __global__ __launch_bounds__(256) void w4a16_ring_kernel(const GemmArgs a) {
     if constexpr (ABL & 4) { if (j < XI) return; }   // (timing experiments: no x / no weight traffic)
     if constexpr (ABL & 8) { if (j >= XI) return; }
     if (j < XI) {
-      lds_dma16(b.x, b.x_voff[j], (unsigned)kt * 256u, xdst + slot + j * 4096);
+      lds_dma16(b.x, b.x_voff[j], (unsigned)kt * 256u, xdst + slot + j * (NW * 1024));
     } else if (j < XI + LW) {
-      const int p = (j - XI) >> 1, hi = (j - XI) & 1;
-      lds_dma16(b.w, hi ? w_voff_hi : b.w_voff, (unsigned)p * b.w_pstride + (unsigned)kt * 1024u, wdst + slot + (j - XI) * 1024);
+      const int piece = j - XI;  // WK = 1: (pair, lo / hi); WK = 2: pair (this wave's half only)
+      const int p = WK == 2 ? piece : (piece >> 1), hi = WK == 2 ? 0 : (piece & 1);
+      lds_dma16(b.w, hi ? w_voff_hi : b.w_voff, (unsigned)p * b.w_pstride + (unsigned)kt * 1024u, wdst + slot + piece * 1024);
     } else {
       const int p = (j - XI - LW) / NG, i = (j - XI - LW) % NG;
       const unsigned g = (unsigned)group_index<GM>(kt, i * (4 / NG), a.tpg, a.G);
@@ -414,13 +503,18 @@ __global__ __launch_bounds__(256) void w4a16_ring_kernel(const GemmArgs a) {
     }
   };
   typedef const __attribute__((address_space(3))) char* lds_ptr;
-  auto read_w = [&](WideW<PAIRS, GM>& w, unsigned slot) {  // this lane's own 16 + 16 bytes per pair, and its group words
+  auto read_w = [&](WideW<PAIRS, GM>& w, unsigned slot) {  // this lane's own 16 (+ 16) bytes per pair, and its group words
     const lds_ptr wp = (lds_ptr)(uintptr_t)(wdst + slot + (unsigned)lane * 16u);
     const lds_ptr sp = (lds_ptr)(uintptr_t)(sdst + slot + (unsigned)lane * 4u);
 #pragma unroll
     for (int p = 0; p < PAIRS; ++p) {
-      w.lo[p] = *(const __attribute__((address_space(3))) u32x4*)(wp + (2 * p) * 1024);
-      w.hi[p] = *(const __attribute__((address_space(3))) u32x4*)(wp + (2 * p + 1) * 1024);
+      if constexpr (WK == 2) {
+        w.lo[p] = *(const __attribute__((address_space(3))) u32x4*)(wp + p * 1024);
+        w.hi[p] = w.lo[p];
+      } else {
+        w.lo[p] = *(const __attribute__((address_space(3))) u32x4*)(wp + (2 * p) * 1024);
+        w.hi[p] = *(const __attribute__((address_space(3))) u32x4*)(wp + (2 * p + 1) * 1024);
+      }
 #pragma unroll
       for (int i = 0; i < NG; ++i) w.sz[p][i] = *(const __attribute__((address_space(3))) uint32_t*)(sp + (p * NG + i) * 256);
     }
@@ -429,7 +523,7 @@ __global__ __launch_bounds__(256) void w4a16_ring_kernel(const GemmArgs a) {
   floatx16 acc[PAIRS][MB];
   wide_zero<MB, PAIRS>(acc);
   const DqConsts dq = make_dq_consts();
-  WideW<PAIRS, GM> wc, wn;
+  WideW<PAIRS, GM> wc, wn_;
 
   // prologue: stages 0 .. NBUF - 2 into slots 0 .. NBUF - 2 (past the end of the K range: replays of the last stage)
 #pragma unroll
@@ -441,26 +535,57 @@ __global__ __launch_bounds__(256) void w4a16_ring_kernel(const GemmArgs a) {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory");  // stages 0 and 1 have landed
   __builtin_amdgcn_s_barrier();
   read_w(wc, 0u);
+  WideCarry<MB, PAIRS, GM> carry;
+  wide_prepare<MB, PAIRS, GM, true, WK>(carry, wc, xrd, dq);
 
   unsigned cur = 0u, nxt = (unsigned)SLOT, fill = (unsigned)(NBUF - 1) * SLOT;  // slot offsets of stage s, s + 1, s + NBUF - 1
   for (int s = 0; s < t.nstage; ++s) {
     const int ktf = min(t.kt_lo + s + NBUF - 1, t.kt_hi - 1);
-    wide_compute<MB, PAIRS, GM, ABL>(wc, xrd + cur, dq, acc, [&](int u) {
-      constexpr int PER = (L + NU - 2) / (NU - 1);  // everything issued one unit before the stage ends
+    wide_compute<MB, PAIRS, GM, ABL, true, WK>(wc, wn_, xrd + cur, xrd + nxt, dq, acc, carry, [&](int u) {
+      constexpr int PER = NU > 1 ? (L + NU - 2) / (NU - 1) : L;  // everything issued one unit before the stage ends
 #pragma unroll
       for (int j = 0; j < PER; ++j)
         if constexpr (!(ABL & 2))
           if (u * PER + j < L) issue(u * PER + j, ktf, fill);
-      if (u == NU / 2) read_w(wn, nxt);  // next stage's packed weights: LDS -> registers, half a stage early
+      if (u == NU / 2) read_w(wn_, nxt);  // next stage's packed weights: LDS -> registers, half a stage early
     });
     if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory");  // stage s + 2 has landed ...
     __builtin_amdgcn_s_barrier();                                    // ... in every wave; everybody is done with stage s
-    wc = wn;
+    wc = wn_;
     fill = cur;
     cur = nxt;
     nxt = nxt + SLOT >= (unsigned)(NBUF * SLOT) ? 0u : nxt + SLOT;
   }
-  wide_finish<MB, PAIRS>(a, t, acc, smem, ct0, lane, wave);
+  if constexpr (WK == 2) {  // add the second K half to the first through LDS (the ring is free: drain the replayed DMAs first)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    floatx4* ex = (floatx4*)smem;  // [wn][p][mt][c][lane]
+    if (wk == 1) {
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+        for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            ex[(((wn * PAIRS + p) * MB + mt) * 4 + c) * 64 + lane] =
+                floatx4{acc[p][mt][4 * c], acc[p][mt][4 * c + 1], acc[p][mt][4 * c + 2], acc[p][mt][4 * c + 3]};
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+        for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const floatx4 v = ex[(((wn * PAIRS + p) * MB + mt) * 4 + c) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[p][mt][4 * c + r] += v[r];
+          }
+    }
+    __syncthreads();  // (splitk_arrive writes its flag into the same LDS)
+  }
+  wide_finish<MB, PAIRS>(a, t, acc, smem, ct0, lane, wn, wk == 0);
 }
 
 }  // namespace quick_amd

@@ -115,9 +115,11 @@ def wide(mb, pairs):                  # explicit workgroup tile: mb * 32 tokens 
     return WIDE | (mb << 4) | (pairs << 8)
 
 
+WIDE_8WAVES = 1 << 15                 # ring kernel with eight waves per workgroup (two per SIMD), k16 steps split by parity
 WIDE_NORING = 1 << 12                 # 64- / 128-token tiles on the double-buffered kernel instead of the LDS-DMA ring
 WIDE_IDS = ([WIDE] + [wide(mb, pairs) for mb in (2, 4, 8) for pairs in (1, 2)] + [wide(mb, pairs) | WIDE_NORING for mb in (2, 4) for pairs in (1, 2)]
-            + [wide(2, 1) | (3 << 22), wide(2, 1) | (4 << 22), wide(2, 2) | (3 << 22)])     # shorter rings
+            + [wide(2, 1) | (3 << 22), wide(2, 1) | (4 << 22), wide(2, 2) | (3 << 22)]      # shorter rings
+            + [wide(2, 1) | WIDE_8WAVES, wide(2, 2) | WIDE_8WAVES, wide(4, 1) | WIDE_8WAVES, wide(2, 1) | WIDE_8WAVES | (3 << 22)])
 
 
 @pytest.mark.parametrize("kernel_id", [0, SKINNY_DZ, SKINNY_EXACT, TILED, TILED_MFMA32, TILED_16WAVES, TILED_WIDE, TILED_BIG] + WIDE_IDS)
