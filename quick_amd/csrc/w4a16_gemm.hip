@@ -1333,11 +1333,44 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   const int tiled_tiles = (N / 128) * ((M + 63) / 64);
   const bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= 64);
   p.kernel = family == QUICK_KERNEL_AUTO ? (want_tiled ? QUICK_KERNEL_TILED : QUICK_KERNEL_SKINNY) : family;
+  // Wide kernels (32x32x16 MFMA, one wave per SIMD, LDS-DMA) from 256 tokens, and from 64 tokens once there are enough
+  // 64 x 128 tiles to cover the chip (large N): 13 % ahead of the r01 kernels on average over 45 (M, K, N) shapes between
+  // 64 x 4096 x 12288 and 8192 x 4096 x 22016, never behind by more than 3 % [r02 probes, profiles/r02_planner_probe*.jsonl].
+  // The tile (mb x 32 tokens, pairs x 128 channels) minimises  rounds * tile work / efficiency + K-split reduction:
+  //   efficiency (large-shape asymptote, relative): 64x128 0.90, 64x256 0.92, 128x128 1.00, 128x256 0.985, 256x256 1.025;
+  //   tiles that leave room for two or more workgroups per CU overlap each other's prologue, waits and epilogue (x 1.15
+  //   from the second round); a K split costs slices * tile bytes at ~60 GB/s for the workgroup that arrives last.
+  int wide_mb = 0, wide_pairs = 0;
+  bool wide_ring = false;
+  if (family == QUICK_KERNEL_AUTO && G % 128 == 0 && M >= 64 &&
+      (M >= 256 || (long)((M + 63) / 64) * (N / 128) >= 160)) {
+    static const int cand[5][3] = {{2, 1, 4}, {2, 2, 2}, {4, 1, 2}, {4, 2, 1}, {8, 2, 1}};   // mb, pairs, workgroups per CU
+    static const double eff[5] = {0.90, 0.92, 1.00, 0.985, 1.025};
+    double best = 0;
+    for (int c = 0; c < 5; ++c) {
+      const int mb = cand[c][0], pairs = cand[c][1];
+      if (N % (pairs * 128) != 0) continue;
+      const long T = (long)((M + mb * 32 - 1) / (mb * 32)) * (N / (pairs * 128));
+      int s = 1;
+      while (T * s * 2 <= 256 && KT / (s * 2) >= 4) s *= 2;
+      const double tile = 2.0 * mb * 32 * pairs * 128 * ((double)K / s) / (3.7e6 * eff[c]);   // us, one tile alone on its CU
+      const long n = (T * s + 255) / 256;
+      const double cost = n * tile / (n >= 2 && cand[c][2] >= 2 ? 1.15 : 1.0) + 3.0 +
+                          (s > 1 ? s * mb * 32.0 * pairs * 128 * 4 / 60e3 + 1.0 : 0.0);
+      if (wide_mb == 0 || cost < best) {
+        best = cost;
+        wide_mb = mb;
+        wide_pairs = pairs;
+        wide_ring = mb == 2 && T * s <= 256;   // the ring holds one workgroup per CU: only where there is no second one anyway
+      }
+    }
+    if (wide_mb) p.kernel = QUICK_KERNEL_WIDE;
+  }
   int ks = 1;
   if (p.kernel == QUICK_KERNEL_WIDE && G % 128 != 0) p.kernel = QUICK_KERNEL_TILED;  // small groups: r01's tiled kernel
   if (p.kernel == QUICK_KERNEL_WIDE) {
     // bits 4-7: MB (token tiles of 32 per workgroup: 2, 4, 8), bits 8-11: PAIRS (32-channel pairs per wave: 1, 2); 0 = choose
-    int mb = mt_req, pairs = (kernel >> 8) & 15;
+    int mb = wide_mb ? wide_mb : mt_req, pairs = wide_mb ? wide_pairs : (kernel >> 8) & 15;
     if (mb != 2 && mb != 4 && mb != 8) mb = M > 128 ? 8 : (M > 64 ? 4 : 2);
     if (pairs != 1 && pairs != 2) pairs = 2;
     if (N % (pairs * 128) != 0) pairs = 1;
@@ -1347,7 +1380,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     // bit 15: eight waves per workgroup (two per SIMD, k16 steps split by parity) -- ring kernel, tiles up to 128 x 128 / 64 x 256
     const bool eight = ((kernel >> 15) & 1) && mb * pairs <= 4 && !no_xlds;
     const int nb_req = (kernel >> 22) & 7, nb_max = mb == 8 ? 0 : wide_ring_nbuf(mb, pairs, eight ? 2 : 1);
-    p.wide_nbuf = (no_xlds || nb_max < 3) ? 0 : (nb_req >= 3 ? std::min(nb_req, nb_max) : nb_max);
+    p.wide_nbuf = (no_xlds || nb_max < 3 || (wide_mb && !wide_ring)) ? 0 : (nb_req >= 3 ? std::min(nb_req, nb_max) : nb_max);
     p.waves = (eight && p.wide_nbuf >= 3) ? 8 : 4;
     p.tch = pairs * 128;
     const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / p.tch;

@@ -155,16 +155,27 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "tokens=32 channels=128" in p and "ksplit=2" in p
     assert p.endswith(f"workspace={_lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, 0, 0)}")
     assert "grid=80x3 ksplit=3" in plan(64, 8192, 10240)     # not only powers of two: 240 of 256 CUs
-    # 256-channel tiles by how the tiles quantise onto 256 CUs
-    assert "channels=128" in plan(512, 4096, 4096)           # 128 wide tiles would need a K split
-    assert "channels=256" in plan(576, 4096, 4096)           # 144 wide tiles in one round beat 288 narrow ones
-    assert "tokens=64 channels=256" in plan(1024, 4096, 4096)
-    assert "tokens=128 channels=256 waves=4" in plan(2048, 4096, 4096)   # 256 four-wave tiles: one round
-    assert "tokens=64" in plan(2560, 4096, 4096)                         # 320 of them would be two rounds
-    assert "channels=128" in plan(192, 4096, 22016)          # 258 wide tiles = a second, nearly empty round
-    assert "channels=256" in plan(128, 4096, 22016)
-    assert "channels=128" in plan(512, 4096, 11008) and "channels=256" in plan(640, 4096, 11008)
-    assert "channels=256" in plan(8192, 4096, 22016)
+    # r01's tiled kernel (kernel_id TILED; the planner's own choice for G < 128): 256-channel tiles by how they quantise onto 256 CUs
+    T = kernels.KERNEL_TILED
+    assert "channels=128" in plan(512, 4096, 4096, kernel_id=T)           # 128 wide tiles would need a K split
+    assert "channels=256" in plan(576, 4096, 4096, kernel_id=T)           # 144 wide tiles in one round beat 288 narrow ones
+    assert "tokens=64 channels=256" in plan(1024, 4096, 4096, kernel_id=T)
+    assert "tokens=128 channels=256 waves=4" in plan(2048, 4096, 4096, kernel_id=T)   # 256 four-wave tiles: one round
+    assert "tokens=64" in plan(2560, 4096, 4096, kernel_id=T)                         # 320 of them would be two rounds
+    assert "channels=128" in plan(192, 4096, 22016, kernel_id=T)          # 258 wide tiles = a second, nearly empty round
+    assert "channels=256" in plan(128, 4096, 22016, kernel_id=T)
+    assert "channels=256" in plan(8192, 4096, 22016, kernel_id=T)
+    assert plan(512, 4096, 4096, G=64).startswith("tiled")                # small groups: the wide kernels need G % 128 == 0
+    # r02: the wide kernels (32x32x16 MFMA, LDS-DMA) from 256 tokens, and from 64 once 64 x 128 tiles cover the chip
+    assert plan(512, 4096, 4096).startswith("wide tokens=64 channels=128 waves=4 ring=6 grid=256x1")   # one tile per CU: the LDS-DMA ring
+    assert plan(255, 4096, 4096).startswith("tiled") and plan(256, 4096, 4096).startswith("wide")
+    assert plan(64, 4096, 22016).startswith("wide tokens=64") and not plan(64, 4096, 12288).startswith("wide")
+    assert "tokens=64 channels=128 waves=4 ring=0 grid=512x1" in plan(1024, 4096, 4096)  # two rounds: several workgroups per CU, no ring
+    assert "tokens=128 channels=128" in plan(2048, 4096, 4096) and "tokens=128 channels=128" in plan(8192, 4096, 22016)
+    W = kernels.KERNEL_WIDE
+    assert "tokens=256 channels=256" in plan(4096, 8192, 8192, kernel_id=W | (8 << 4) | (2 << 8))      # explicit tile
+    assert "waves=8 ring=6" in plan(512, 4096, 4096, kernel_id=W | (2 << 4) | (1 << 8) | (1 << 15))   # eight-wave ring
+    assert "ring=0" in plan(512, 4096, 4096, kernel_id=W | (2 << 4) | (1 << 8) | (1 << 12))           # double-buffered instead
     # forcing a family / a split through the kernel id and grid_split_k
     assert plan(512, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny")
     assert "ksplit=4" in plan(64, 4096, 4096, kernel_id=kernels.KERNEL_TILED, grid_split_k=4)
