@@ -133,6 +133,14 @@ int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const v
                              size_t workspace_bytes, int M, int K, int N, int group_size, int kernel,
                              int grid_split_k, int iters, float* kernel_us, void* hip_stream);
 
+/* Measurement aid: the IN-KERNEL wall-clock span of each of `iters` launches -- first wave's start to last wave's end on the
+ * constant 100 MHz counter (s_memrealtime), written by the kernels themselves -- in microseconds to the HOST array
+ * span_us[iters]; weight sets cycled as in quick_w4a16_gemm_profile.  The dispatch-duration clock reads ~4.2 us for an
+ * EMPTY kernel, so launches of a few microseconds (small M) are only visible on this one.  Blocking. */
+int quick_w4a16_gemm_span(const void* x, const void* const* qweights, const void* const* scales, const void* const* qzeros,
+                          int n_sets, void* y, void* workspace, size_t workspace_bytes, int M, int K, int N, int group_size,
+                          int kernel, int grid_split_k, int iters, float* span_us, void* hip_stream);
+
 /* Measurement aid: the same event-pair clock on `iters` dispatches of an EMPTY kernel with the GEMM's launch
  * shape (256 workgroups x 512 threads): the fixed part of every "kernel duration" reading on this stack. */
 int quick_amd_dispatch_floor(int iters, float* kernel_us, void* hip_stream);
@@ -146,7 +154,8 @@ int quick_amd_dispatch_floor(int iters, float* kernel_us, void* hip_stream);
  *                              (rotate-half convention), q -> q_out[B, nh, D], k/v -> caches [B, nkv, L, D] at *pos
  *   quick_decode_attention_f16 single-query attention over cache positions 0..*pos, GQA aware, D == 128
  *   quick_silu_mul_f16         y[m, 8t+i] = silu(gate_up[m, 16t+i]) * gate_up[m, 16t+8+i]  (gate/up interleaved by 8)
- * `pos` is a DEVICE pointer to one int64 (so a captured hipGraph can advance it).
+ * `pos` is a DEVICE pointer to one int64 (so a captured hipGraph can advance it); the caller keeps 0 <= *pos < cache_len
+ * (a device value: the library cannot check it) and batch <= 65535.
  */
 int quick_rmsnorm_f16(const void* x, const void* weight, void* y, int rows, int hidden, float eps, void* hip_stream);
 int quick_rope_kv_append_f16(const void* qkv, const void* cos_table, const void* sin_table, const void* pos,

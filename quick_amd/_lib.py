@@ -22,6 +22,7 @@ _SIGNATURES = {
     "quick_w4a16_gemm_f16_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     "quick_w4a16_workspace_bytes_ex": (_Z, [_I, _I, _I, _I, _I, _I]),
     "quick_w4a16_gemm_profile": (_I, [_P, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "quick_w4a16_gemm_span": (_I, [_P, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "quick_w4a16_gemm_f16_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     "quick_w4a16_can_fuse_rmsnorm": (_I, [_I, _I, _I, _I]),
     "quick_w4a16_plan_describe": (_I, [_I, _I, _I, _I, _I, _I, ctypes.c_char_p, _Z]),

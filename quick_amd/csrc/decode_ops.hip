@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
       }
       roped = true;
     }
+    if (p == 0) break;  // first position: nothing in the cache yet (row 0 is unwritten -- 0 * NaN would poison the sum)
     // scores in the log2 domain (q carries scale * log2 e): 8 rows of this slot
     float d[UNR], mb = m;
 #pragma unroll
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void decode_rope_attention_gqa_kernel(
       }
       roped = true;
     }
+    if (p == 0) break;  // first position: nothing in the cache yet (row 0 is unwritten -- 0 * NaN would poison the sum)
     // scores in the log2 domain (q carries scale * log2 e): UNR rows of this slot x GROUP heads; every cache row is
     // converted to fp32 once for all heads
     float d[GROUP][UNR];
@@ -516,6 +518,7 @@ int quick_rope_kv_append_f16(const void* qkv, const void* cos_table, const void*
                              void* k_cache, void* v_cache, int batch, int n_heads, int n_kv_heads, int head_dim,
                              int cache_len, void* hip_stream) {
   if (batch <= 0 || head_dim % 2 != 0 || head_dim > 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_INVALID_ARGUMENT;
+  if (batch > 65535) return QUICK_ERR_UNSUPPORTED;  // grid.y
   hipLaunchKernelGGL(rope_kv_kernel, dim3(n_heads + 2 * n_kv_heads, batch), dim3(64), 0, (hipStream_t)hip_stream,
                      (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, (const long*)pos,
                      (half_t*)q_out, (half_t*)k_cache, (half_t*)v_cache, n_heads, n_kv_heads, head_dim, cache_len);
@@ -536,7 +539,7 @@ int quick_rope_kv_write_f16(const void* qkv, const void* cos_table, const void* 
 int quick_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* pos, void* out,
                                int batch, int n_heads, int n_kv_heads, int head_dim, int cache_len, float scale,
                                void* hip_stream) {
-  if (batch <= 0 || head_dim != 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_UNSUPPORTED;
+  if (batch <= 0 || batch > 65535 || head_dim != 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_UNSUPPORTED;
   const size_t lds = (((size_t)cache_len + 3) & ~(size_t)3) * 4 + 4 * 128 * 4;
   if (lds > 64 * 1024) return QUICK_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(decode_attention_kernel, dim3(n_heads, batch), dim3(256), (unsigned)lds, (hipStream_t)hip_stream,
@@ -549,6 +552,7 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
                                     void* k_cache, void* v_cache, void* out, int batch, int n_heads, int n_kv_heads,
                                     int head_dim, int cache_len, float scale, void* hip_stream) {
   if (batch <= 0 || head_dim != 128 || n_heads % n_kv_heads != 0) return QUICK_ERR_UNSUPPORTED;
+  if (batch > 65535 || cache_len <= 0) return QUICK_ERR_UNSUPPORTED;  // grid.y; the caller keeps *pos < cache_len (device value)
 #define QA_GQA(GROUP, UNR, GSPLIT)                                                                                 \
   hipLaunchKernelGGL((decode_rope_attention_gqa_kernel<GROUP, UNR>), dim3(n_kv_heads * (GSPLIT), batch), dim3(256), 0, \
                      (hipStream_t)hip_stream, (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, \

@@ -45,7 +45,24 @@ struct GemmArgs {
   unsigned long long* dbg;  // ablation bit 16: per-wave phase cycle totals [workgroup][wave][8]
   const half_t* ln_w;  // deferred-zero skinny kernel: RMSNorm weight [K] applied to x on its way into LDS, or null
   float ln_eps;
+  unsigned long long* span;  // measurement aid: per-wave start / end stamps in s_memrealtime ticks (100 MHz), see span_stamp; or null
 };
+
+// In-kernel wall-clock span of a launch: first wave's start -> last wave's end on the constant 100 MHz counter.  The
+// dispatch-duration clock (event pair / rocprofv3) cannot read below ~4.2 us -- an EMPTY kernel reads that -- so for the
+// microsecond-scale small-M launches this is the clock that can see the kernel (quick_w4a16_gemm_span, bench.py
+// roofline.frac_inkernel).  Every wave stores its own two stamps into its own slot (plain 8-byte stores: 2048 atomics on
+// one word would serialise for tens of microseconds and be the thing measured); the host takes min / max.  Costs one
+// scalar compare per wave when off.
+constexpr unsigned kSpanWaves = 1u << 16;  // slots per launch: [kSpanWaves starts][kSpanWaves ends]
+__device__ __forceinline__ void span_stamp(unsigned long long* span, int end) {
+  if (span != nullptr) {  // wave-uniform branch on purpose (all 64 lanes store the same word): a lane-0 branch at kernel entry
+    // made hipcc treat the buffer descriptors built after it as divergent (VGPRs, "invalid operand" in the LDS-DMA asm)
+    const unsigned w = (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) +
+                        (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) & (kSpanWaves - 1);
+    span[(end ? kSpanWaves : 0u) + w] = __builtin_amdgcn_s_memrealtime();
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // K split across workgroups, reduced inside the launch ("last arriver finishes the tile").
@@ -454,7 +471,7 @@ __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[
 // the cross-block form hipcc needs 141 instead of 121 VGPRs for NTW = 1 (one workgroup per CU instead of two: -9 % on
 // the Llama-2-70B shapes at M = 16 [r01]).
 template <int NTW, int WAVES, int GM, bool XLDS, bool DZ, bool LN = false>
-__global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
+__device__ __forceinline__ void w4a16_skinny_body(const GemmArgs& a) {
   constexpr bool PERSIST = XLDS;
   static_assert(!LN || (DZ && !XLDS && NTW >= 2), "the register-level RMSNorm lives in the fragment deferred-zero flavour");
   static_assert(WAVES >= NTW, "the final reduction assigns one channel tile per wave");
@@ -639,6 +656,12 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
 #undef QA_SKINNY_ADVANCE
 #undef QA_SKINNY_LOAD
 }
+template <int NTW, int WAVES, int GM, bool XLDS, bool DZ, bool LN = false>
+__global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
+  span_stamp(a.span, 0);
+  w4a16_skinny_body<NTW, WAVES, GM, XLDS, DZ, LN>(a);
+  span_stamp(a.span, 1);
+}
 
 // ------------------------------------------------------------------------------------------------
 // tiled kernel
@@ -751,7 +774,7 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK, WN>& c
 // (stores it, skips its compute) -- an `if (s >= nstage) break` gives the waitcnt pass a path from one half-iteration
 // straight into the same half again, on which the weights just requested look like the ones about to be used.
 template <int BMT, int TN, int WK, int GM, int ABL = 0, int WN = 4>
-__global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArgs a) {
+__device__ __forceinline__ void w4a16_tiled_body(const GemmArgs& a) {
   constexpr int XPW = 4 * BMT / WN;
   constexpr int NG = groups_per_tile<GM>();
   constexpr int FRAGS = 4 * WK * BMT;        // 1 KiB fragments per stage
@@ -961,6 +984,13 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArg
       }
     }
   }
+}
+
+template <int BMT, int TN, int WK, int GM, int ABL = 0, int WN = 4>
+__global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArgs a) {
+  span_stamp(a.span, 0);
+  w4a16_tiled_body<BMT, TN, WK, GM, ABL, WN>(a);
+  span_stamp(a.span, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1290,6 +1320,7 @@ struct Plan {
 struct Launch {
   hipStream_t st;
   hipEvent_t start, stop;
+  unsigned long long* span = nullptr;  // device [2]: in-kernel span of this launch (see span_stamp)
 };
 
 static int check_shapes(int M, int K, int N, int G) {
@@ -1779,6 +1810,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
              (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr, (const half_t*)f.ln_w, f.ln_eps};
   if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
+  a.span = L.span;
   if (p.ksplit > 1) {
     if (p.ntiles > kMaxSplitTiles) return fail(QUICK_ERR_UNSUPPORTED, "K split over %d output tiles (limit %d)", p.ntiles, kMaxSplitTiles);
     const size_t need = workspace_need(p);
@@ -1912,6 +1944,46 @@ int quick_w4a16_gemm_profile(const void* x, const void* const* qweights, const v
     kernel_us[i] = ms * 1000.f;
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int quick_w4a16_gemm_span(const void* x, const void* const* qweights, const void* const* scales, const void* const* qzeros,
+                          int n_sets, void* y, void* workspace, size_t workspace_bytes, int M, int K, int N, int group_size,
+                          int kernel, int grid_split_k, int iters, float* span_us, void* hip_stream) {
+  if (n_sets < 1 || iters < 1 || iters > 256 || !span_us) return fail(QUICK_ERR_INVALID_ARGUMENT, "bad span arguments (1..256 launches)");
+  hipStream_t st = (hipStream_t)hip_stream;
+  const size_t per = 2 * (size_t)kSpanWaves;  // u64 words per launch
+  unsigned long long* dev = nullptr;
+  if (hipMalloc(&dev, (size_t)iters * per * 8) != hipSuccess) return fail(QUICK_ERR_LAUNCH, "hipMalloc failed");
+  int rc = QUICK_OK;
+  for (int i = 0; i < iters && rc == QUICK_OK; ++i) {  // starts: all ones, ends: zero
+    if (hipMemsetAsync(dev + i * per, 0xff, kSpanWaves * 8, st) != hipSuccess ||
+        hipMemsetAsync(dev + i * per + kSpanWaves, 0, kSpanWaves * 8, st) != hipSuccess)
+      rc = fail(QUICK_ERR_LAUNCH, "memset failed");
+  }
+  for (int i = 0; i < iters && rc == QUICK_OK; ++i) {
+    const int s = i % n_sets;
+    Launch L{st, nullptr, nullptr};
+    L.span = dev + i * per;
+    rc = run_gemm(x, qweights[s], scales[s], qzeros[s], Fusion{}, y, workspace, workspace_bytes, M, K, N, group_size, kernel,
+                  grid_split_k, L);
+  }
+  std::vector<unsigned long long> host(per);
+  for (int i = 0; i < iters; ++i) {
+    span_us[i] = 0.f;
+    if (rc != QUICK_OK) continue;
+    if (hipMemcpyAsync(host.data(), dev + i * per, per * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      rc = fail(QUICK_ERR_LAUNCH, "reading the span stamps back failed");
+      continue;
+    }
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (unsigned w = 0; w < kSpanWaves; ++w) {
+      lo = std::min(lo, host[w]);
+      hi = std::max(hi, host[kSpanWaves + w]);
+    }
+    span_us[i] = hi > lo ? (float)((double)(hi - lo) * 0.01) : 0.f;  // 100 MHz ticks
+  }
+  (void)hipFree(dev);
   return rc;
 }
 

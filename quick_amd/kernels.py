@@ -35,17 +35,20 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_WORKSPACES = {}
+_WORKSPACES = {}          # (device index, stream handle) -> zero-filled uint8 tensor; insertion order = recency
+_WORKSPACES_MAX = 16      # stream handles are recycled by the runtime: keep the few most recently used, drop the rest
 
 
 def _workspace(device, nbytes):
     """Zero-filled scratch for the in-kernel split-K reduction, one per (device, stream), grown on demand.  The
     library hands it back zeroed after every launch, so it is allocated and cleared only when it has to grow."""
     key = (device.index, _stream())
-    ws = _WORKSPACES.get(key)
+    ws = _WORKSPACES.pop(key, None)
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _WORKSPACES[key] = ws
+    _WORKSPACES[key] = ws                                  # most recently used last
+    while len(_WORKSPACES) > _WORKSPACES_MAX:
+        _WORKSPACES.pop(next(iter(_WORKSPACES)))           # (in-flight launches keep their buffer alive through the allocator's stream ordering)
     return ws
 
 
