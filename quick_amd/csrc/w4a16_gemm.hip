@@ -470,8 +470,11 @@ __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[
 // Only the XLDS variants can be launched persistent.  The fragments-from-L2 variants keep the plain one-block loop: in
 // the cross-block form hipcc needs 141 instead of 121 VGPRs for NTW = 1 (one workgroup per CU instead of two: -9 % on
 // the Llama-2-70B shapes at M = 16 [r01]).
+// (span stamps: written out at the kernel's own two exits -- moving the body into a forceinline device function called between
+// two stamps changed hipcc's code for the deferred-zero paths into something that fails the parity tests [r02])
 template <int NTW, int WAVES, int GM, bool XLDS, bool DZ, bool LN = false>
-__device__ __forceinline__ void w4a16_skinny_body(const GemmArgs& a) {
+__global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
+  span_stamp(a.span, 0);
   constexpr bool PERSIST = XLDS;
   static_assert(!LN || (DZ && !XLDS && NTW >= 2), "the register-level RMSNorm lives in the fragment deferred-zero flavour");
   static_assert(WAVES >= NTW, "the final reduction assigns one channel tile per wave");
@@ -565,6 +568,7 @@ __device__ __forceinline__ void w4a16_skinny_body(const GemmArgs& a) {
       else skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, ls, acc);
     }
     skinny_finish<NTW, WAVES, DZ, LN>(a, acc, red, smem, bx, nblocks, mb, ks, lane, wave, ssq);
+    span_stamp(a.span, 1);
     return;
   }
   QA_SKINNY_LOAD(cA);  // HBM requests first
@@ -651,16 +655,11 @@ __device__ __forceinline__ void w4a16_skinny_body(const GemmArgs& a) {
     QA_SKINNY_STEP(cB, cA);
     QA_SKINNY_STEP(cA, cB);
   }
+  span_stamp(a.span, 1);
 #undef QA_SKINNY_STEP
 #undef QA_SKINNY_COMPUTE
 #undef QA_SKINNY_ADVANCE
 #undef QA_SKINNY_LOAD
-}
-template <int NTW, int WAVES, int GM, bool XLDS, bool DZ, bool LN = false>
-__global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
-  span_stamp(a.span, 0);
-  w4a16_skinny_body<NTW, WAVES, GM, XLDS, DZ, LN>(a);
-  span_stamp(a.span, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -774,7 +773,8 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK, WN>& c
 // (stores it, skips its compute) -- an `if (s >= nstage) break` gives the waitcnt pass a path from one half-iteration
 // straight into the same half again, on which the weights just requested look like the ones about to be used.
 template <int BMT, int TN, int WK, int GM, int ABL = 0, int WN = 4>
-__device__ __forceinline__ void w4a16_tiled_body(const GemmArgs& a) {
+__global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArgs a) {
+  span_stamp(a.span, 0);
   constexpr int XPW = 4 * BMT / WN;
   constexpr int NG = groups_per_tile<GM>();
   constexpr int FRAGS = 4 * WK * BMT;        // 1 KiB fragments per stage
@@ -926,7 +926,10 @@ __device__ __forceinline__ void w4a16_tiled_body(const GemmArgs& a) {
 #pragma unroll
         for (int mt = 0; mt < BMT; ++mt) slab_store(rs, ks * SLAB_BYTES + my + (j * BMT + mt) * 1024, acc[j][mt]);
     }
-    if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
+    if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) {
+      span_stamp(a.span, 1);
+      return;
+    }
     if (wk == 0) {  // slices are added in index order (own partial from registers at its index): the result does not
       floatx4 own[TN][BMT];  // depend on which workgroup happened to arrive last
 #pragma unroll
@@ -962,6 +965,7 @@ __device__ __forceinline__ void w4a16_tiled_body(const GemmArgs& a) {
           }
         }
     }
+    span_stamp(a.span, 1);
     return;
   }
   if (wk == 0) {
@@ -984,12 +988,6 @@ __device__ __forceinline__ void w4a16_tiled_body(const GemmArgs& a) {
       }
     }
   }
-}
-
-template <int BMT, int TN, int WK, int GM, int ABL = 0, int WN = 4>
-__global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArgs a) {
-  span_stamp(a.span, 0);
-  w4a16_tiled_body<BMT, TN, WK, GM, ABL, WN>(a);
   span_stamp(a.span, 1);
 }
 

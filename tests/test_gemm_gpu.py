@@ -445,6 +445,34 @@ def test_function_level_drop_in_takes_reference_order_tensors(qa, device, path):
     assert key not in K_._REPACK_CACHE
 
 
+def test_compiled_quick_kernels_extension(qa, device):
+    """The pybind11 / torch-extension face of the same boundary (quick_amd/csrc/quick_kernels_ext.cpp, the shape of the
+    reference's csrc/pybind.cpp): built in-tree by torch.utils.cpp_extension, called with reference-order tensors."""
+    from quick_amd.build_ext import build_quick_kernels_ext
+    ext = build_quick_kernels_ext()
+    for path in GOLD[:4]:
+        g = load_golden(path)
+        ref = [_dev(g[k], device) for k in ("ref_qweight", "ref_qscales", "ref_qzeros")]
+        x = _dev(g["x"], device)
+        y = ext.gemm_forward_cuda_quick(x, *ref, 8)
+        assert tuple(y.shape) == g["ref_y"].shape and rel_err(y.cpu().numpy(), g["ref_y"]) <= TOL
+        y1 = ext.gemm_forward_cuda_quick(x, *ref, 1)
+        assert tuple(y1.shape) == (1,) + g["ref_y"].shape and torch.equal(y1[0], y)
+        other = oracle.make_synthetic(1, int(g["K"]), int(g["N"]), int(g["G"]), seed=78)[1:]     # in-place rewrite -> repacked again
+        for t, a in zip(ref, oracle.pack_cuda_order(*other)):
+            t.copy_(_dev(a, device))
+        y2 = ext.gemm_forward_cuda_quick(x, *ref, 8)
+        assert rel_err(y2.cpu().numpy(), oracle.w4a16_forward(g["x"], *other, int(g["G"]))) <= TOL
+    K, G = 256, 128
+    bad_n = [torch.zeros(K // 4, 96 // 2, dtype=torch.int32, device=device), torch.zeros(K // G, 192, dtype=torch.float16, device=device),
+             torch.zeros(K // G, 24, dtype=torch.int32, device=device)]
+    xk = torch.zeros(3, K, dtype=torch.float16, device=device)
+    with pytest.raises(ValueError, match="cta_N"):                             # std::invalid_argument, gemm_cuda_quick.cu:1479
+        ext.gemm_forward_cuda_quick(xk, *bad_n, 8)
+    with pytest.raises(RuntimeError):                                          # data_ptr<at::Half>() on a float tensor
+        ext.gemm_forward_cuda_quick(xk.float(), *bad_n, 8)
+
+
 def test_function_level_drop_in_at_baseline_size(qa, device, pin):
     import quick_kernels
     g, iw, s, z = pin

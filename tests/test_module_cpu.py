@@ -192,6 +192,21 @@ def test_quick_kernels_shim_exports_reference_symbol():
                                               torch.zeros(1, 32, dtype=torch.int32), 8)
 
 
+def test_compiled_quick_kernels_extension_builds_and_exports_the_symbol():
+    """quick_amd/csrc/quick_kernels_ext.cpp (pybind11 over the C ABI, the shape of the reference's csrc/pybind.cpp:5-8)
+    builds with torch.utils.cpp_extension -- no GPU needed -- and rejects CPU tensors like the ctypes shim does."""
+    from quick_amd.build_ext import build_quick_kernels_ext
+    ext = build_quick_kernels_ext()
+    assert callable(ext.gemm_forward_cuda_quick)
+    x = torch.zeros(1, 128, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ext.gemm_forward_cuda_quick(x, torch.zeros(32, 64, dtype=torch.int32), torch.zeros(1, 256, dtype=torch.float16),
+                                    torch.zeros(1, 32, dtype=torch.int32), 8)
+    with pytest.raises(ValueError, match="split_k_iters"):
+        ext.gemm_forward_cuda_quick(x, torch.zeros(32, 64, dtype=torch.int32), torch.zeros(1, 256, dtype=torch.float16),
+                                    torch.zeros(1, 32, dtype=torch.int32), 0)
+
+
 # ------------------------------------------------------------------------------------------------
 # quantizer hook-up (quick/awq/quantize/quantizer.py:46-72, 141-174)
 # ------------------------------------------------------------------------------------------------
