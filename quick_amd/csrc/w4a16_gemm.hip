@@ -57,7 +57,9 @@ struct GemmArgs {
 constexpr unsigned kSpanWaves = 1u << 16;  // slots per launch: [kSpanWaves starts][kSpanWaves ends]
 __device__ __forceinline__ void span_stamp(unsigned long long* span, int end) {
   if (span != nullptr) {  // wave-uniform branch on purpose (all 64 lanes store the same word): a lane-0 branch at kernel entry
-    // made hipcc treat the buffer descriptors built after it as divergent (VGPRs, "invalid operand" in the LDS-DMA asm)
+    // made hipcc treat the buffer descriptors built after it as divergent (VGPRs, "invalid operand" in the LDS-DMA asm).
+    // Only the SPAN = true instantiations contain this at all: even switched off, the branch and the longer kernarg cost
+    // the M = 1 launch 7 % in an A/B session [r02].
     const unsigned w = (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) +
                         (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) & (kSpanWaves - 1);
     span[(end ? kSpanWaves : 0u) + w] = __builtin_amdgcn_s_memrealtime();
@@ -472,9 +474,9 @@ __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[
 // the Llama-2-70B shapes at M = 16 [r01]).
 // (span stamps: written out at the kernel's own two exits -- moving the body into a forceinline device function called between
 // two stamps changed hipcc's code for the deferred-zero paths into something that fails the parity tests [r02])
-template <int NTW, int WAVES, int GM, bool XLDS, bool DZ, bool LN = false>
+template <int NTW, int WAVES, int GM, bool XLDS, bool DZ, bool LN = false, bool SPAN = false>
 __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
-  span_stamp(a.span, 0);
+  if constexpr (SPAN) span_stamp(a.span, 0);
   constexpr bool PERSIST = XLDS;
   static_assert(!LN || (DZ && !XLDS && NTW >= 2), "the register-level RMSNorm lives in the fragment deferred-zero flavour");
   static_assert(WAVES >= NTW, "the final reduction assigns one channel tile per wave");
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
       else skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, ls, acc);
     }
     skinny_finish<NTW, WAVES, DZ, LN>(a, acc, red, smem, bx, nblocks, mb, ks, lane, wave, ssq);
-    span_stamp(a.span, 1);
+    if constexpr (SPAN) span_stamp(a.span, 1);
     return;
   }
   QA_SKINNY_LOAD(cA);  // HBM requests first
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     QA_SKINNY_STEP(cB, cA);
     QA_SKINNY_STEP(cA, cB);
   }
-  span_stamp(a.span, 1);
+  if constexpr (SPAN) span_stamp(a.span, 1);
 #undef QA_SKINNY_STEP
 #undef QA_SKINNY_COMPUTE
 #undef QA_SKINNY_ADVANCE
@@ -774,7 +776,6 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK, WN>& c
 // straight into the same half again, on which the weights just requested look like the ones about to be used.
 template <int BMT, int TN, int WK, int GM, int ABL = 0, int WN = 4>
 __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArgs a) {
-  span_stamp(a.span, 0);
   constexpr int XPW = 4 * BMT / WN;
   constexpr int NG = groups_per_tile<GM>();
   constexpr int FRAGS = 4 * WK * BMT;        // 1 KiB fragments per stage
@@ -926,10 +927,7 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArg
 #pragma unroll
         for (int mt = 0; mt < BMT; ++mt) slab_store(rs, ks * SLAB_BYTES + my + (j * BMT + mt) * 1024, acc[j][mt]);
     }
-    if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) {
-      span_stamp(a.span, 1);
-      return;
-    }
+    if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
     if (wk == 0) {  // slices are added in index order (own partial from registers at its index): the result does not
       floatx4 own[TN][BMT];  // depend on which workgroup happened to arrive last
 #pragma unroll
@@ -965,7 +963,6 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArg
           }
         }
     }
-    span_stamp(a.span, 1);
     return;
   }
   if (wk == 0) {
@@ -988,7 +985,6 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArg
       }
     }
   }
-  span_stamp(a.span, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1333,6 +1329,7 @@ static int check_shapes(int M, int K, int N, int G) {
 }
 
 static constexpr size_t kLdsPerCu = 160 * 1024;  // gfx950
+static thread_local bool g_span_unsupported = false;  // set by a launcher asked for span stamps its kernel does not carry
 
 // LDS of one skinny workgroup: reduction buffer(s), the x copy, the deferred-zero table
 static size_t skinny_lds_bytes(int M, int G, int ntw, int waves, int kt_per_split, bool persistent, bool xlds, bool dz) {
@@ -1583,6 +1580,19 @@ template <int NTW, int WAVES, bool XLDS, bool DZ, bool LN = false>
 static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) {
   dim3 grid(p.grid_x, (a.M + 15) / 16, p.ksplit), block(WAVES * 64);
   const size_t lds = skinny_lds_bytes(a.M, a.G, NTW, WAVES, p.kt_per_split, p.grid_x < a.N / (16 * NTW), XLDS, DZ) + (LN ? 1024 : 0);
+  if (a.span) {  // in-kernel span stamps: separate instantiations, for the small-M kernels the BASELINE sweep and the decode shapes run
+    constexpr bool stamped = WAVES == 8 && !LN && ((NTW == 1 && XLDS && DZ) || (NTW == 1 && !XLDS && !DZ) || (NTW == 4 && !XLDS && DZ));
+    if constexpr (stamped) {
+      if (group_mode(a.G) == 0) {
+        auto kfn = w4a16_skinny_kernel<NTW, WAVES, 0, XLDS, DZ, LN, true>;
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+        hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)lds, L.st, L.start, L.stop, 0, a);
+        return;
+      }
+    }
+    g_span_unsupported = true;
+    return;
+  }
 #define QA_SKINNY(GMV)                                                                                             \
   do {                                                                                                             \
     auto kfn = w4a16_skinny_kernel<NTW, WAVES, GMV, XLDS, DZ, LN>;                                                 \
@@ -1642,6 +1652,10 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
   constexpr int TN = TCH / 16 / WN;  // channel tiles per wave
   dim3 grid((a.N / TCH) * ((a.M + BMT * 16 - 1) / (BMT * 16)), p.ksplit), block(64 * WN * WK);
   const unsigned lds = 2 * 4 * WK * BMT * 1024;
+  if (a.span) {
+    g_span_unsupported = true;
+    return;
+  }
 #define QA_TILED_K(GMV, ABLV)                                                                                      \
   do {                                                                                                             \
     auto kfn = w4a16_tiled_kernel<BMT, TN, WK, GMV, ABLV, WN>;                                                        \
@@ -1735,6 +1749,18 @@ static void launch_ring(const Plan& p, const GemmArgs& a, const Launch& L) {
       hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
       return;
     }
+  if (a.span) {
+    if constexpr (MB == 2 && PAIRS == 1 && NBUF == 6 && WK == 1) {
+      if (group_mode(a.G) == 0) {
+        auto kfn = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 32, WK>;   // ABL bit 32 = span stamps, nothing else
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
+        return;
+      }
+    }
+    g_span_unsupported = true;
+    return;
+  }
   if (group_mode(a.G) == 0) QA_RING_K(0);
   else QA_RING_K(1);
 #undef QA_RING_K
@@ -1762,6 +1788,10 @@ static void launch_wide(const Plan& p, const GemmArgs& a, const Launch& L) {
   }
   dim3 grid(p.ntiles, p.ksplit), block(256);
   const unsigned lds = 2 * MB * 32 * 256;
+  if (a.span) {
+    g_span_unsupported = true;
+    return;
+  }
 #define QA_WIDE_K(GMV)                                                                                             \
   do {                                                                                                             \
     auto kfn = w4a16_wide_kernel<MB, PAIRS, GMV>;                                                                  \
@@ -1809,6 +1839,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
              (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr, (const half_t*)f.ln_w, f.ln_eps};
   if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
   a.span = L.span;
+  g_span_unsupported = false;
   if (p.ksplit > 1) {
     if (p.ntiles > kMaxSplitTiles) return fail(QUICK_ERR_UNSUPPORTED, "K split over %d output tiles (limit %d)", p.ntiles, kMaxSplitTiles);
     const size_t need = workspace_need(p);
@@ -1843,6 +1874,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     else if (p.waves == 8) launch_tiled<4, 2>(p, a, L);
     else launch_tiled<4, 4>(p, a, L);
   }
+  if (g_span_unsupported) return fail(QUICK_ERR_UNSUPPORTED, "no span-stamped build of the kernel this shape runs");
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(QUICK_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
   return QUICK_OK;
