@@ -1362,16 +1362,16 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   // Wide kernels (32x32x16 MFMA, one wave per SIMD, LDS-DMA) from 256 tokens, and from 64 tokens once there are enough
   // 64 x 128 tiles to cover the chip (large N): 13 % ahead of the r01 kernels on average over 45 (M, K, N) shapes between
   // 64 x 4096 x 12288 and 8192 x 4096 x 22016, never behind by more than 3 % [r02 probes, profiles/r02_planner_probe*.jsonl].
-  // The tile (mb x 32 tokens, pairs x 128 channels) minimises  rounds * tile work / efficiency + K-split reduction:
-  //   efficiency (large-shape asymptote, relative): 64x128 0.90, 64x256 0.92, 128x128 1.00, 128x256 0.985, 256x256 1.025;
-  //   tiles that leave room for two or more workgroups per CU overlap each other's prologue, waits and epilogue (x 1.15
-  //   from the second round); a K split costs slices * tile bytes at ~60 GB/s for the workgroup that arrives last.
+  // The tile (mb x 32 tokens, pairs x 128 channels) minimises  rounds * tile work / efficiency + K-split reduction -- a
+  // quantisation model: how many tiles the busiest CU runs, times what a tile costs.  Efficiencies (relative) fitted to the
+  // probes: 64x128 0.86, 64x256 0.90, 128x128 1.00, 128x256 1.03, 256x256 1.04 (the fit picks within 0.3 % of the best
+  // measured variant on average, 3.3 % at worst); a K split costs slices * tile bytes at ~60 GB/s for the last arriver.
   int wide_mb = 0, wide_pairs = 0;
   bool wide_ring = false;
   if (family == QUICK_KERNEL_AUTO && G % 128 == 0 && M >= 64 &&
       (M >= 256 || (long)((M + 63) / 64) * (N / 128) >= 160)) {
     static const int cand[5][3] = {{2, 1, 4}, {2, 2, 2}, {4, 1, 2}, {4, 2, 1}, {8, 2, 1}};   // mb, pairs, workgroups per CU
-    static const double eff[5] = {0.90, 0.92, 1.00, 0.985, 1.025};
+    static const double eff[5] = {0.86, 0.90, 1.00, 1.03, 1.04};
     double best = 0;
     for (int c = 0; c < 5; ++c) {
       const int mb = cand[c][0], pairs = cand[c][1];
@@ -1381,8 +1381,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
       while (T * s * 2 <= 256 && KT / (s * 2) >= 4) s *= 2;
       const double tile = 2.0 * mb * 32 * pairs * 128 * ((double)K / s) / (3.7e6 * eff[c]);   // us, one tile alone on its CU
       const long n = (T * s + 255) / 256;
-      const double cost = n * tile / (n >= 2 && cand[c][2] >= 2 ? 1.15 : 1.0) + 3.0 +
-                          (s > 1 ? s * mb * 32.0 * pairs * 128 * 4 / 60e3 + 1.0 : 0.0);
+      const double cost = n * tile + 3.0 + (s > 1 ? s * mb * 32.0 * pairs * 128 * 4 / 60e3 + 1.0 : 0.0);
       if (wide_mb == 0 || cost < best) {
         best = cost;
         wide_mb = mb;

@@ -170,8 +170,9 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(512, 4096, 4096).startswith("wide tokens=64 channels=128 waves=4 ring=6 grid=256x1")   # one tile per CU: the LDS-DMA ring
     assert plan(255, 4096, 4096).startswith("tiled") and plan(256, 4096, 4096).startswith("wide")
     assert plan(64, 4096, 22016).startswith("wide tokens=64") and not plan(64, 4096, 12288).startswith("wide")
-    assert "tokens=64 channels=128 waves=4 ring=0 grid=512x1" in plan(1024, 4096, 4096)  # two rounds: several workgroups per CU, no ring
-    assert "tokens=128 channels=128" in plan(2048, 4096, 4096) and "tokens=128 channels=128" in plan(8192, 4096, 22016)
+    assert "tokens=128 channels=128 waves=4 ring=0 grid=256x1" in plan(1024, 4096, 4096)  # 256 tiles of 128 x 128: one round
+    assert "tokens=128 channels=256" in plan(2048, 4096, 4096) and "tokens=256 channels=256" in plan(8192, 4096, 22016)
+    assert "tokens=64 channels=128 waves=4 ring=0 grid=576x1" in plan(384, 4096, 12288)   # several rounds: the double-buffered kernel
     W = kernels.KERNEL_WIDE
     assert "tokens=256 channels=256" in plan(4096, 8192, 8192, kernel_id=W | (8 << 4) | (2 << 8))      # explicit tile
     assert "waves=8 ring=6" in plan(512, 4096, 4096, kernel_id=W | (2 << 4) | (1 << 8) | (1 << 15))   # eight-wave ring

@@ -87,7 +87,7 @@ def main():
                 print(f"{spec:>18} {name:>10}: {type(e).__name__}: {e}", flush=True)
                 continue
             torch.cuda.synchronize()
-            diff = float((got - ref).abs().max()) / scale
+            diff = float((got - ref).abs().max()) / max(scale, 1e-30)
             wsb = lib.quick_w4a16_workspace_bytes_ex(M, K, N, G, kid, split)
             ws = torch.zeros(max(wsb, 1), dtype=torch.uint8, device=dev)
             meds = []
