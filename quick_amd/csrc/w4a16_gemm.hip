@@ -664,6 +664,10 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
 #undef QA_SKINNY_LOAD
 }
 
+}  // namespace quick_amd
+#include "w4a16_chain.hpp"
+namespace quick_amd {
+
 // ------------------------------------------------------------------------------------------------
 // tiled kernel
 // ------------------------------------------------------------------------------------------------
@@ -1879,6 +1883,83 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   return QUICK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// chained small-batch GEMMs (w4a16_chain.hpp)
+// ------------------------------------------------------------------------------------------------
+static int chain_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
+static size_t chain_lds_bytes(int M, int K, int G) {  // both reduction buffers, the x rows, the unit-sum table
+  return skinny_lds_bytes(M, G, 1, 8, K / 128, true, true, true);
+}
+
+static int check_chain(const quick_chain_task* tasks, int n) {
+  if (!tasks || n < 1 || n > kChainMax) return fail(QUICK_ERR_INVALID_ARGUMENT, "chain of %d tasks (1..%d)", n, kChainMax);
+  for (int i = 0; i < n; ++i) {
+    const quick_chain_task& t = tasks[i];
+    if (int rc = check_shapes(t.M, t.K, t.N, t.group_size)) return rc;
+    if (!t.x || !t.qweight || !t.scales || !t.qzeros || !t.y) return fail(QUICK_ERR_INVALID_ARGUMENT, "null tensor pointer (task %d)", i);
+    if (t.fusion.silu_mul && (t.fusion.bias || t.fusion.residual))
+      return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual (task %d)", i);
+    if (t.M > 16) return fail(QUICK_ERR_UNSUPPORTED, "chained GEMMs: at most 16 tokens (task %d has %d)", i, t.M);
+    if (t.group_size != tasks[0].group_size) return fail(QUICK_ERR_UNSUPPORTED, "chained GEMMs: one group size per chain");
+    if (chain_lds_bytes(t.M, t.K, t.group_size) > kLdsPerCu)
+      return fail(QUICK_ERR_UNSUPPORTED, "chained GEMMs: %d rows of K = %d do not fit LDS (task %d)", t.M, t.K, i);
+  }
+  return QUICK_OK;
+}
+
+static int run_chain(const quick_chain_task* tasks, int n, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (int rc = check_chain(tasks, n)) return rc;
+  if (!workspace || workspace_bytes < (size_t)kMaxSplitTiles * 4)
+    return fail(QUICK_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", (size_t)kMaxSplitTiles * 4, workspace_bytes);
+  const int cus = chain_cu_count();
+  if (cus <= 0) return fail(QUICK_ERR_LAUNCH, "cannot read the device's CU count");
+  ChainArgs ca{};
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    const quick_chain_task& t = tasks[i];
+    ca.t[i] = GemmArgs{(const half_t*)t.x, (const u32x4*)t.qweight, (const half_t*)t.scales, (const uint32_t*)t.qzeros,
+                       (const half_t*)t.fusion.bias, (const half_t*)t.fusion.residual, t.fusion.silu_mul, (half_t*)t.y, nullptr,
+                       nullptr, t.M, t.K, t.N, t.group_size, std::max(1, t.group_size / 128), 1, t.K / 128, 0, nullptr,
+                       (const half_t*)t.fusion.rmsnorm_weight, t.fusion.rmsnorm_eps, nullptr};
+    lds = std::max(lds, chain_lds_bytes(t.M, t.K, t.group_size));
+  }
+  ca.n = n;
+  ca.barrier = (unsigned*)workspace;  // zero on entry (caller's contract), zero again when the launch completes
+  // one workgroup per CU, all co-resident (the barrier polls); a multiple of 8 keeps the XCD-aware block order
+  const dim3 grid((unsigned)(cus >= 8 ? cus & ~7 : cus)), block(512);
+#define QA_CHAIN(GMV)                                                                                              \
+  do {                                                                                                             \
+    auto kfn = w4a16_chain_kernel<GMV>;                                                                            \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);     \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipLaunchKernelGGL(kfn, grid, block, (unsigned)lds, st, ca);                                                   \
+  } while (0)
+  switch (group_mode(tasks[0].group_size)) {
+    case 0: QA_CHAIN(0); break;
+    case 1: QA_CHAIN(1); break;
+    case 2: QA_CHAIN(2); break;
+    case 3: QA_CHAIN(3); break;
+    default: QA_CHAIN(4); break;
+  }
+#undef QA_CHAIN
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QUICK_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+  return QUICK_OK;
+}
+
 }  // namespace quick_amd
 
 using namespace quick_amd;
@@ -1921,6 +2002,11 @@ int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* s
     f.silu_mul = fusion->silu_mul;
   }
   return run_gemm(x, qweight, scales, qzeros, f, y, workspace, workspace_bytes, M, K, N, group_size, kernel, grid_split_k, L);
+}
+
+int quick_w4a16_gemm_chain_f16(const quick_chain_task* tasks, int ntasks, void* workspace, size_t workspace_bytes,
+                               void* hip_stream) {
+  return run_chain(tasks, ntasks, workspace, workspace_bytes, (hipStream_t)hip_stream);
 }
 
 int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size) {
