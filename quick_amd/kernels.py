@@ -67,25 +67,20 @@ def plan_describe(M, K, N, G, kernel_id=KERNEL_AUTO, grid_split_k=0):
     return buf.value.decode()
 
 
-def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=KERNEL_AUTO, grid_split_k=0, residual=None,
-                 out=None, rmsnorm_weight=None, rmsnorm_eps=1e-5, silu_mul=False):
-    """y [M, N] fp16 = in_feats [M, K] @ dequant(kernel, scaling_factors, zeros) (+ bias) (+ residual), MI355X-order
-    weights.  ``out`` (optional, may be ``residual``) receives the result.  ``rmsnorm_weight`` [K] normalises in_feats on
-    the way in (see can_fuse_rmsnorm); ``silu_mul`` treats the output channels as gate/up interleaved in blocks of 8 and
-    returns silu(gate) * up, [M, N/2]."""
+def _check_gemm(in_feats, kernel, scaling_factors, zeros, bias, residual, out, rmsnorm_weight, silu_mul):
+    """The library takes raw pointers: everything it will dereference is checked here (dtype, device, contiguity, shape).
+    Returns (M, K, N, G, out) with ``out`` allocated if it was None."""
     _expect(in_feats, torch.float16, "in_feats")
     _expect(kernel, torch.int32, "kernel")
     _expect(scaling_factors, torch.float16, "scaling_factors")
     _expect(zeros, torch.int32, "zeros")
     if in_feats.dim() != 2:
         raise RuntimeError("in_feats must be 2-D [M, K]")
-    lib = _lib.load()
     M, K = in_feats.shape
     N = kernel.shape[1] // 4 * 8                      # gemm_cuda_quick.cu:1468
     if kernel.shape[0] * 4 != K:
         raise ValueError(f"kernel has {kernel.shape[0] * 4} input channels, in_feats has {K}")
     G = K // scaling_factors.shape[0]                 # gemm_cuda_quick.cu:1477
-    # the library takes raw pointers: everything it will dereference is checked here (dtype, device, contiguity, shape)
     if tuple(scaling_factors.shape) != (K // G, 2 * N) or tuple(zeros.shape) != (K // G, N // 4):
         raise ValueError(f"scaling_factors / zeros must be [{K // G}, {2 * N}] / [{K // G}, {N // 4}] for K={K} N={N} G={G}, "
                          f"got {tuple(scaling_factors.shape)} / {tuple(zeros.shape)}")
@@ -102,6 +97,17 @@ def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=
             raise RuntimeError(f"{name} is on {t.device}, in_feats on {in_feats.device}")
     if out is None:
         out = torch.empty((M, n_out), dtype=torch.float16, device=in_feats.device)
+    return M, K, N, G, out
+
+
+def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=KERNEL_AUTO, grid_split_k=0, residual=None,
+                 out=None, rmsnorm_weight=None, rmsnorm_eps=1e-5, silu_mul=False):
+    """y [M, N] fp16 = in_feats [M, K] @ dequant(kernel, scaling_factors, zeros) (+ bias) (+ residual), MI355X-order
+    weights.  ``out`` (optional, may be ``residual``) receives the result.  ``rmsnorm_weight`` [K] normalises in_feats on
+    the way in (see can_fuse_rmsnorm); ``silu_mul`` treats the output channels as gate/up interleaved in blocks of 8 and
+    returns silu(gate) * up, [M, N/2]."""
+    M, K, N, G, out = _check_gemm(in_feats, kernel, scaling_factors, zeros, bias, residual, out, rmsnorm_weight, silu_mul)
+    lib = _lib.load()
     if M == 0:
         return out
     with torch.cuda.device(in_feats.device):          # OptionalCUDAGuard, gemm_cuda_quick.cu:1465
@@ -118,6 +124,58 @@ def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=
     if rc != _OK:
         _raise(rc)
     return out
+
+
+_CHAIN_WORKSPACES = {}
+
+
+def _chain_workspace(device, nbytes):
+    """The buffer chained launches keep their flagged cells and launch epoch in: one per (device, stream), zero-filled when
+    (re)allocated, never touched by anything else (not the split-K workspace: that one is rewritten by other launches)."""
+    key = (device.index, _stream())
+    ws = _CHAIN_WORKSPACES.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(max(nbytes, 4 << 20), dtype=torch.uint8, device=device)
+        _CHAIN_WORKSPACES[key] = ws
+    return ws
+
+
+def gemm_chain(tasks, trace=None):
+    """Up to CHAIN_MAX DEPENDENT small-batch GEMMs (M <= 16) in one launch (quick_w4a16_gemm_chain_f16): ``tasks`` is a list
+    of dicts with the keyword arguments of gemm_forward (in_feats, kernel, scaling_factors, zeros, and optionally bias,
+    residual, out, rmsnorm_weight, rmsnorm_eps, silu_mul); a task may read what an earlier one writes.  Returns the list of
+    outputs -- bit for bit what the same gemm_forward calls return at M = 1.  Raises NotImplementedError when the library
+    cannot chain these shapes (launch them one by one then)."""
+    if not 1 <= len(tasks) <= _lib.CHAIN_MAX:
+        raise ValueError(f"a chain holds 1..{_lib.CHAIN_MAX} tasks, got {len(tasks)}")
+    arr = (_lib.ChainTask * len(tasks))()
+    outs, dev = [], tasks[0]["in_feats"].device
+    for i, t in enumerate(tasks):
+        x, bias, residual, ln_w = t["in_feats"], t.get("bias"), t.get("residual"), t.get("rmsnorm_weight")
+        silu = bool(t.get("silu_mul", False))
+        M, K, N, G, out = _check_gemm(x, t["kernel"], t["scaling_factors"], t["zeros"], bias, residual, t.get("out"), ln_w, silu)
+        if x.device != dev:
+            raise RuntimeError("the tasks of a chain live on one device")
+        if M == 0:
+            raise ValueError("empty task in a chain")
+        ptr = lambda v: v.data_ptr() if v is not None else None
+        arr[i] = _lib.ChainTask(x.data_ptr(), t["kernel"].data_ptr(), t["scaling_factors"].data_ptr(), t["zeros"].data_ptr(),
+                                out.data_ptr(), _lib.GemmFusion(ptr(bias), ptr(residual), ptr(ln_w), float(t.get("rmsnorm_eps", 1e-5)),
+                                                                int(silu)), M, K, N, G)
+        outs.append(out)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        need = lib.quick_w4a16_chain_workspace_bytes(arr, len(tasks))
+        if need == 0:
+            _raise(lib.quick_w4a16_gemm_chain_f16(arr, len(tasks), None, 0, _stream()))   # says why these tasks do not chain
+        ws = _chain_workspace(dev, need)
+        if trace is not None:     # measurement aid: int64 device tensor [CUs, CHAIN_MAX, 8] of 100 MHz stamps (tools/chain_trace.py)
+            rc = lib.quick_w4a16_gemm_chain_trace(arr, len(tasks), ws.data_ptr(), ws.numel(), trace.data_ptr(), _stream())
+        else:
+            rc = lib.quick_w4a16_gemm_chain_f16(arr, len(tasks), ws.data_ptr(), ws.numel(), _stream())
+    if rc != _OK:
+        _raise(rc)
+    return outs
 
 
 def _tensor_version(t):
