@@ -27,7 +27,6 @@ def main():
     ap.add_argument("--ctx", type=int, default=128)
     ap.add_argument("--gen", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-chain", action="store_true", help="one launch per GEMM also at batch <= 4 (default there: chained launches)")
     ap.add_argument("--torch-glue", action="store_true", help="eager torch ops around the GEMMs instead of the HIP glue kernels")
     args = ap.parse_args()
     import torch
@@ -39,15 +38,13 @@ def main():
             model = SyntheticDecoder(cfg, bs, args.ctx + args.gen, dev)
             torch.cuda.synchronize()
             fused = not args.torch_glue and cfg.head_dim == 128
-            from quick_amd import decoder as _dec
-            chain = fused and not args.no_chain and bs <= _dec.CHAIN_MAX_BATCH
-            run_generation(model, args.ctx, min(args.gen, 8), use_graph=False, fused=fused, chain=chain)   # warm-up (allocator, lazy init)
-            prefill, steps = run_generation(model, args.ctx, args.gen, use_graph=not args.no_graph, fused=fused, chain=chain)
+            run_generation(model, args.ctx, min(args.gen, 8), use_graph=False, fused=fused)   # warm-up (allocator, lazy init)
+            prefill, steps = run_generation(model, args.ctx, args.gen, use_graph=not args.no_graph, fused=fused)
             med = float(np.median(steps))
             out = {"metric": "decode_tok_s", "model": cfg.name, "batch": bs, "prefill_len": args.ctx, "decode_len": args.gen,
                    "prefill_tok_s": args.ctx * bs / prefill, "decode_tok_s": bs / med, "decode_ms_per_step": med * 1e3,
                    "weights_GB": model.weight_bytes() / 1e9, "weight_stream_GBs_at_decode": model.weight_bytes() / med / 1e9,
-                   "launch": "eager" if args.no_graph else "hipgraph", "glue": "hip kernels" if fused else "torch ops", "chained_gemms": bool(chain),
+                   "launch": "eager" if args.no_graph else "hipgraph", "glue": "hip kernels" if fused else "torch ops",
                    "data": "synthetic random weights",
                    "vram_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
             print(json.dumps(out), flush=True)

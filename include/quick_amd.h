@@ -114,43 +114,6 @@ int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* s
                                int M, int K, int N, int group_size, int kernel, int grid_split_k, void* hip_stream);
 int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size);
 
-/*
- * Chained small-batch GEMMs (M <= 16): `ntasks` (1..QUICK_CHAIN_MAX) DEPENDENT GEMMs in one launch -- task t >= 1 takes the y of
- * task t - 1 as its x (same pointer), and a residual may be the y of any earlier task.  What it replaces on the reference
- * side is the run of separate `gemm_forward_cuda_quick` launches of a decoder layer at batch 1 (quick/awq/modules/fused/
- * block.py: o_proj, then the MLP's gate / up / down, then the next layer's qkv): on MI355X the kernel boundary between two of
- * those costs more than the smaller weight streams themselves.  One persistent grid walks the tasks; a workgroup requests
- * the next task's first weights before it looks for that task's x, and finds x in flagged cells the producers write beside
- * the ordinary y (quick_amd/csrc/w4a16_chain.hpp).  Each task computes exactly what quick_w4a16_gemm_f16_fused computes for
- * it at M = 1 (same kernel code, same summation order: bit-identical results); every y is also written in the ordinary
- * layout.  Tensors in MI355X order; fusion fields as in quick_gemm_fusion.  Every task needs K % 128 == 0, the same
- * group_size as the others, M <= 16, and its x rows + unit-sum table must fit LDS (M * (2 K + 16) + K / min(group_size, 128) *
- * 128 + 16 KiB <= 160 KiB) -- otherwise QUICK_ERR_UNSUPPORTED and the caller launches the GEMMs one by one.
- * `workspace`: a buffer of quick_w4a16_chain_workspace_bytes(tasks, ntasks) bytes used ONLY by chained launches (not the
- * split-K workspace of the other entry points), zero-filled once before its first use and left alone between launches: it
- * holds the launch epoch the cell tags are derived from.
- * The launch occupies one workgroup per CU and polls: nothing that it waits for may be queued behind it.
- */
-#define QUICK_CHAIN_MAX 6
-typedef struct quick_chain_task {
-  const void* x;
-  const void* qweight;
-  const void* scales;
-  const void* qzeros;
-  void* y;
-  quick_gemm_fusion fusion;
-  int M, K, N, group_size;
-} quick_chain_task;
-size_t quick_w4a16_chain_workspace_bytes(const quick_chain_task* tasks, int ntasks);
-int quick_w4a16_gemm_chain_f16(const quick_chain_task* tasks, int ntasks, void* workspace, size_t workspace_bytes,
-                               void* hip_stream);
-/* Measurement aid (tools/chain_trace.py): the same launch from a build that stamps the 100 MHz s_memrealtime counter into
- * trace[workgroup][QUICK_CHAIN_MAX][8] (device memory, >= CUs * QUICK_CHAIN_MAX * 8 words) at four points of every task:
- * 0 task begins (first weights requested), 1 the previous task's cells have all arrived, 2 x staged, 3 last block finished.
- * group_size 128 only. */
-int quick_w4a16_gemm_chain_trace(const quick_chain_task* tasks, int ntasks, void* workspace, size_t workspace_bytes,
-                                 unsigned long long* trace, void* hip_stream);
-
 /* What a launch of this shape will run, as one line of text (host-only, no GPU needed): kernel family, tile shape,
  * grid, K split and workspace, e.g. "tiled tokens=64 channels=128 waves=8 grid=256x1 ksplit=1 xcd_rows=2 workspace=0" or
  * "skinny ntw=1 waves=8 x=lds dequant=deferred-zero-table grid=256x1x1 ksplit=1 workspace=0".  For logs and for tests of

@@ -14,14 +14,6 @@ class GemmFusion(ctypes.Structure):
     _fields_ = [("bias", _P), ("residual", _P), ("rmsnorm_weight", _P), ("rmsnorm_eps", ctypes.c_float), ("silu_mul", _I)]
 
 
-class ChainTask(ctypes.Structure):
-    """struct quick_chain_task (include/quick_amd.h)."""
-    _fields_ = [("x", _P), ("qweight", _P), ("scales", _P), ("qzeros", _P), ("y", _P), ("fusion", GemmFusion),
-                ("M", _I), ("K", _I), ("N", _I), ("group_size", _I)]
-
-
-CHAIN_MAX = 6
-
 _SIGNATURES = {
     "quick_amd_abi_version": (_I, []),
     "quick_amd_last_error": (ctypes.c_char_p, []),
@@ -32,9 +24,6 @@ _SIGNATURES = {
     "quick_w4a16_gemm_profile": (_I, [_P, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "quick_w4a16_gemm_span": (_I, [_P, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "quick_w4a16_gemm_f16_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
-    "quick_w4a16_chain_workspace_bytes": (_Z, [_P, _I]),
-    "quick_w4a16_gemm_chain_f16": (_I, [_P, _I, _P, _Z, _P]),
-    "quick_w4a16_gemm_chain_trace": (_I, [_P, _I, _P, _Z, _P, _P]),
     "quick_w4a16_can_fuse_rmsnorm": (_I, [_I, _I, _I, _I]),
     "quick_w4a16_plan_describe": (_I, [_I, _I, _I, _I, _I, _I, ctypes.c_char_p, _Z]),
     "quick_rmsnorm_f16": (_I, [_P, _P, _P, _I, _I, ctypes.c_float, _P]),

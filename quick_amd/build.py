@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libquick_amd.so")
 SOURCES = ["w4a16_gemm.hip", "repack.hip", "decode_ops.hip"]
-HEADERS = ["w4a16_common.hpp", "w4a16_wide.hpp", "w4a16_chain.hpp", os.path.join("..", "..", "include", "quick_amd.h")]
+HEADERS = ["w4a16_common.hpp", "w4a16_wide.hpp", os.path.join("..", "..", "include", "quick_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
 
 

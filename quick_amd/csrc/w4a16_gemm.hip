@@ -664,10 +664,6 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
 #undef QA_SKINNY_LOAD
 }
 
-}  // namespace quick_amd
-#include "w4a16_chain.hpp"
-namespace quick_amd {
-
 // ------------------------------------------------------------------------------------------------
 // tiled kernel
 // ------------------------------------------------------------------------------------------------
@@ -1883,132 +1879,6 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   return QUICK_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// chained small-batch GEMMs (w4a16_chain.hpp)
-// ------------------------------------------------------------------------------------------------
-static int chain_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    cus = prop.multiProcessorCount;
-  }
-  return cus;
-}
-
-static size_t chain_lds_bytes(int M, int K, int G) {  // the argument copy, both reduction buffers, the x rows, the unit-sum table
-  return 2048 + skinny_lds_bytes(M, G, 1, 8, K / 128, true, true, true);
-}
-
-static size_t chain_cells_bytes(const quick_chain_task& t) {  // rows x blocks x cell, rounded up to 256 B
-  const size_t cell = t.fusion.silu_mul ? 32 : 64;
-  return ((size_t)t.M * (t.N / 16) * cell + 255) & ~(size_t)255;
-}
-
-// shapes, and how the tasks hang together: x of task t >= 1 must be the y of task t - 1 (that is what orders the tasks), a
-// residual may be the y of any earlier task
-static int check_chain(const quick_chain_task* tasks, int n, ChainLink* link) {
-  if (!tasks || n < 1 || n > kChainMax) return fail(QUICK_ERR_INVALID_ARGUMENT, "chain of %d tasks (1..%d)", n, kChainMax);
-  size_t off = kChainHeaderBytes;
-  for (int i = 0; i < n; ++i) {
-    const quick_chain_task& t = tasks[i];
-    if (int rc = check_shapes(t.M, t.K, t.N, t.group_size)) return rc;
-    if (!t.x || !t.qweight || !t.scales || !t.qzeros || !t.y) return fail(QUICK_ERR_INVALID_ARGUMENT, "null tensor pointer (task %d)", i);
-    if (t.fusion.silu_mul && (t.fusion.bias || t.fusion.residual))
-      return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual (task %d)", i);
-    if (t.M > 16) return fail(QUICK_ERR_UNSUPPORTED, "chained GEMMs: at most 16 tokens (task %d has %d)", i, t.M);
-    if (t.group_size != tasks[0].group_size) return fail(QUICK_ERR_UNSUPPORTED, "chained GEMMs: one group size per chain");
-    if (chain_lds_bytes(t.M, t.K, t.group_size) > kLdsPerCu)
-      return fail(QUICK_ERR_UNSUPPORTED, "chained GEMMs: %d rows of K = %d do not fit LDS (task %d)", t.M, t.K, i);
-    ChainLink& l = link[i];
-    l.x_src = l.res_src = -1;
-    for (int j = 0; j < i; ++j) {
-      if (tasks[j].y == t.x) l.x_src = j;
-      if (t.fusion.residual && tasks[j].y == t.fusion.residual) l.res_src = j;
-    }
-    if (i > 0) {
-      const quick_chain_task& p = tasks[i - 1];
-      if (l.x_src != i - 1) return fail(QUICK_ERR_UNSUPPORTED, "chained GEMMs: task %d must take the y of task %d as its x", i, i - 1);
-      if (p.M != t.M || t.K != (p.fusion.silu_mul ? p.N / 2 : p.N))
-        return fail(QUICK_ERR_INVALID_ARGUMENT, "chained GEMMs: task %d is [%d, %d], the y it reads is [%d, %d]", i, t.M, t.K, p.M,
-                    p.fusion.silu_mul ? p.N / 2 : p.N);
-    }
-    if (t.fusion.residual && t.N / 16 > 2 * (chain_cu_count() & ~7))
-      return fail(QUICK_ERR_UNSUPPORTED, "chained GEMMs: a residual needs N <= 32 x CUs (task %d has N = %d)", i, t.N);
-    if (l.res_src >= 0) {
-      const quick_chain_task& p = tasks[l.res_src];
-      if (p.fusion.silu_mul || p.M != t.M || p.N != t.N)
-        return fail(QUICK_ERR_INVALID_ARGUMENT, "chained GEMMs: the residual of task %d is the y of task %d, which is not [%d, %d]", i,
-                    l.res_src, t.M, t.N);
-    }
-    l.cells_off = (unsigned)off;
-    off += chain_cells_bytes(t);
-    l.x_cells_off = l.x_src >= 0 ? link[l.x_src].cells_off : 0;
-    l.x_cell_bytes = l.x_src >= 0 && tasks[l.x_src].fusion.silu_mul ? 32 : 64;
-    l.res_cells_off = l.res_src >= 0 ? link[l.res_src].cells_off : 0;
-  }
-  return QUICK_OK;
-}
-
-static size_t chain_workspace_need(const quick_chain_task* tasks, int n) {
-  size_t need = kChainHeaderBytes;
-  for (int i = 0; i < n; ++i) need += chain_cells_bytes(tasks[i]);
-  return need;
-}
-
-static int run_chain(const quick_chain_task* tasks, int n, void* workspace, size_t workspace_bytes, hipStream_t st,
-                     unsigned long long* trace = nullptr) {
-  ChainArgs ca{};
-  if (int rc = check_chain(tasks, n, ca.link)) return rc;
-  const size_t need = chain_workspace_need(tasks, n);
-  if (!workspace || workspace_bytes < need)
-    return fail(QUICK_ERR_WORKSPACE, "chain workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
-  const int cus = chain_cu_count();
-  if (cus <= 0) return fail(QUICK_ERR_LAUNCH, "cannot read the device's CU count");
-  size_t lds = 0;
-  for (int i = 0; i < n; ++i) {
-    const quick_chain_task& t = tasks[i];
-    ca.t[i] = GemmArgs{(const half_t*)t.x, (const u32x4*)t.qweight, (const half_t*)t.scales, (const uint32_t*)t.qzeros,
-                       (const half_t*)t.fusion.bias, (const half_t*)t.fusion.residual, t.fusion.silu_mul, (half_t*)t.y, nullptr,
-                       nullptr, t.M, t.K, t.N, t.group_size, std::max(1, t.group_size / 128), 1, t.K / 128, 0, nullptr,
-                       (const half_t*)t.fusion.rmsnorm_weight, t.fusion.rmsnorm_eps, nullptr};
-    lds = std::max(lds, chain_lds_bytes(t.M, t.K, t.group_size));
-  }
-  ca.n = n;
-  ca.scratch = (char*)workspace;                // word 0: launch epoch
-  ca.exits = (unsigned*)((char*)workspace + 4);  // word 1: exit counter, zero between launches
-  ca.trace = trace;
-  // one workgroup per CU, all co-resident (tasks poll for each other's cells); a multiple of 8 keeps the XCD-aware block order
-  const dim3 grid((unsigned)(cus >= 8 ? cus & ~7 : cus)), block(512);
-#define QA_CHAIN(GMV)                                                                                              \
-  do {                                                                                                             \
-    auto kfn = w4a16_chain_kernel<GMV>;                                                                            \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);     \
-      attr_set = true;                                                                                             \
-    }                                                                                                              \
-    hipLaunchKernelGGL(kfn, grid, block, (unsigned)lds, st, ca);                                                   \
-  } while (0)
-  if (trace) {
-    if (group_mode(tasks[0].group_size) != 0) return fail(QUICK_ERR_UNSUPPORTED, "chain trace: group size 128 only");
-    auto kfn = w4a16_chain_kernel<0, true>;
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
-    hipLaunchKernelGGL(kfn, grid, block, (unsigned)lds, st, ca);
-  } else switch (group_mode(tasks[0].group_size)) {
-    case 0: QA_CHAIN(0); break;
-    case 1: QA_CHAIN(1); break;
-    case 2: QA_CHAIN(2); break;
-    case 3: QA_CHAIN(3); break;
-    default: QA_CHAIN(4); break;
-  }
-#undef QA_CHAIN
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(QUICK_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
-  return QUICK_OK;
-}
-
 }  // namespace quick_amd
 
 using namespace quick_amd;
@@ -2051,23 +1921,6 @@ int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* s
     f.silu_mul = fusion->silu_mul;
   }
   return run_gemm(x, qweight, scales, qzeros, f, y, workspace, workspace_bytes, M, K, N, group_size, kernel, grid_split_k, L);
-}
-
-size_t quick_w4a16_chain_workspace_bytes(const quick_chain_task* tasks, int ntasks) {
-  ChainLink link[kChainMax];
-  if (check_chain(tasks, ntasks, link) != QUICK_OK) return 0;
-  return chain_workspace_need(tasks, ntasks);
-}
-
-int quick_w4a16_gemm_chain_f16(const quick_chain_task* tasks, int ntasks, void* workspace, size_t workspace_bytes,
-                               void* hip_stream) {
-  return run_chain(tasks, ntasks, workspace, workspace_bytes, (hipStream_t)hip_stream);
-}
-
-int quick_w4a16_gemm_chain_trace(const quick_chain_task* tasks, int ntasks, void* workspace, size_t workspace_bytes,
-                                 unsigned long long* trace, void* hip_stream) {
-  if (!trace) return fail(QUICK_ERR_INVALID_ARGUMENT, "null trace buffer");
-  return run_chain(tasks, ntasks, workspace, workspace_bytes, (hipStream_t)hip_stream, trace);
 }
 
 int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size) {

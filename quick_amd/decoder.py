@@ -162,55 +162,30 @@ def _gemm(m: WQLinear_QUICK, x, out, residual=None):
     return kernels.gemm_forward(x, m.qweight, m.scales, m.qzeros, residual=residual, out=out)
 
 
-def _task(m: WQLinear_QUICK, x, out, **kw):
-    return dict(in_feats=x, kernel=m.qweight, scaling_factors=m.scales, zeros=m.qzeros, out=out, **kw)
-
-
-CHAIN_MAX_BATCH = 4     # chained launches up to this batch (where measured ahead of the per-GEMM launches; needs the x rows in LDS)
-
-
 @torch.no_grad()
-def decode_step_fused(model: SyntheticDecoder, tok, pos, chain=None):
+def decode_step_fused(model: SyntheticDecoder, tok, pos):
     """One decode step (T = 1) with the glue around the GEMMs fused.  Per layer
          qkv GEMM (RMSNorm prologue) | RoPE + KV append + single-query attention | o GEMM (+ residual) |
          gate_up GEMM (RMSNorm prologue, SiLU*mul epilogue) | down GEMM (+ residual)
-    -- 5 launches (7 where the planner's kernel for the shape cannot take the RMSNorm prologue), or, with ``chain`` (default at
-    batch <= CHAIN_MAX_BATCH), 2: the attention kernel and ONE chained launch running o, gate_up, down and the NEXT layer's
-    qkv back to back (kernels.gemm_chain: the weights of each GEMM are already streaming while the barrier before it is
-    waited on).  Same arithmetic as ``SyntheticDecoder.forward`` up to fp16 rounding order.
-    Returns (next tokens [B], hidden [B, H])."""
+    -- 5 launches, 7 where the planner's kernel for the shape cannot take the RMSNorm prologue.  (Running the four GEMMs
+    between two attention kernels as ONE persistent launch was built and measured in r02 and is slower than the four
+    launches: profiles/r02_chain_experiment.txt.)  Same arithmetic as ``SyntheticDecoder.forward`` up to fp16 rounding
+    order.  Returns (next tokens [B], hidden [B, H])."""
     cfg = model.cfg
     nh, nkv, D, H, I, G = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden, cfg.intermediate, cfg.group_size
     B = tok.shape[0]
     x = model.embed.index_select(0, tok.view(-1))                  # [B, H], a fresh buffer: the residual stream
     fuse_qkv = kernels.can_fuse_rmsnorm(B, H, H + 2 * nkv * D, G)
     fuse_gu = kernels.can_fuse_rmsnorm(B, H, 2 * I, G)
-    if chain is None:
-        chain = B <= CHAIN_MAX_BATCH
-    for i, l in enumerate(model.layers):
+    for l in model.layers:
         qkv, gu = l["qkv"], l["gate_up"]
-        if not (chain and i > 0):                                   # chained: layer i's qkv ran at the end of layer i-1's chain
-            if fuse_qkv:
-                kernels.gemm_forward(x, qkv.qweight, qkv.scales, qkv.qzeros, out=model._qkv, rmsnorm_weight=l["ln1"])
-            else:
-                kernels.rmsnorm(x, l["ln1"], out=model._h)
-                _gemm(qkv, model._h, model._qkv)
+        if fuse_qkv:
+            kernels.gemm_forward(x, qkv.qweight, qkv.scales, qkv.qzeros, out=model._qkv, rmsnorm_weight=l["ln1"])
+        else:
+            kernels.rmsnorm(x, l["ln1"], out=model._h)
+            _gemm(qkv, model._h, model._qkv)
         kernels.rope_attention(model._qkv, model.cos, model.sin, pos, l["k"], l["v"], model._att, nh, nkv, D)
-        if chain:
-            tasks = [_task(l["o"], model._att, x, residual=x),      # x += o_proj(att), added in the GEMM epilogue
-                     _task(gu, x, model._act, rmsnorm_weight=l["ln2"], silu_mul=True),
-                     _task(l["down"], model._act, x, residual=x)]
-            if i + 1 < len(model.layers):
-                nxt = model.layers[i + 1]
-                tasks.append(_task(nxt["qkv"], x, model._qkv, rmsnorm_weight=nxt["ln1"]))
-            try:
-                kernels.gemm_chain(tasks)
-                continue
-            except NotImplementedError:                             # rows do not fit LDS at this batch: launch them one by one
-                if i > 0:
-                    raise
-                chain = False
-        _gemm(l["o"], model._att, x, residual=x)
+        _gemm(l["o"], model._att, x, residual=x)                    # x += o_proj(att), added in the GEMM epilogue
         if fuse_gu:
             kernels.gemm_forward(x, gu.qweight, gu.scales, gu.qzeros, out=model._act, rmsnorm_weight=l["ln2"], silu_mul=True)
         else:
@@ -222,7 +197,7 @@ def decode_step_fused(model: SyntheticDecoder, tok, pos, chain=None):
 
 
 @torch.no_grad()
-def run_generation(model: SyntheticDecoder, ctx, n_generate, use_graph=True, fused=True, chain=None):
+def run_generation(model: SyntheticDecoder, ctx, n_generate, use_graph=True, fused=True):
     """examples/benchmark.py:38-67 methodology: events around every forward; prefill = iteration 0, decode = the rest.
     Returns (prefill_seconds, [decode step seconds])."""
     B, dev, L = model.B, model.dev, model.max_len
@@ -244,7 +219,7 @@ def run_generation(model: SyntheticDecoder, ctx, n_generate, use_graph=True, fus
 
     def step():
         if fused:
-            out, _ = decode_step_fused(model, tok, pos, chain=chain)
+            out, _ = decode_step_fused(model, tok, pos)
         else:
             mask.index_fill_(3, pos, 0.0)
             out = model.forward(tok, pos, mask)

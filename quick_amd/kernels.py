@@ -126,58 +126,6 @@ def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=
     return out
 
 
-_CHAIN_WORKSPACES = {}
-
-
-def _chain_workspace(device, nbytes):
-    """The buffer chained launches keep their flagged cells and launch epoch in: one per (device, stream), zero-filled when
-    (re)allocated, never touched by anything else (not the split-K workspace: that one is rewritten by other launches)."""
-    key = (device.index, _stream())
-    ws = _CHAIN_WORKSPACES.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(nbytes, 4 << 20), dtype=torch.uint8, device=device)
-        _CHAIN_WORKSPACES[key] = ws
-    return ws
-
-
-def gemm_chain(tasks, trace=None):
-    """Up to CHAIN_MAX DEPENDENT small-batch GEMMs (M <= 16) in one launch (quick_w4a16_gemm_chain_f16): ``tasks`` is a list
-    of dicts with the keyword arguments of gemm_forward (in_feats, kernel, scaling_factors, zeros, and optionally bias,
-    residual, out, rmsnorm_weight, rmsnorm_eps, silu_mul); a task may read what an earlier one writes.  Returns the list of
-    outputs -- bit for bit what the same gemm_forward calls return at M = 1.  Raises NotImplementedError when the library
-    cannot chain these shapes (launch them one by one then)."""
-    if not 1 <= len(tasks) <= _lib.CHAIN_MAX:
-        raise ValueError(f"a chain holds 1..{_lib.CHAIN_MAX} tasks, got {len(tasks)}")
-    arr = (_lib.ChainTask * len(tasks))()
-    outs, dev = [], tasks[0]["in_feats"].device
-    for i, t in enumerate(tasks):
-        x, bias, residual, ln_w = t["in_feats"], t.get("bias"), t.get("residual"), t.get("rmsnorm_weight")
-        silu = bool(t.get("silu_mul", False))
-        M, K, N, G, out = _check_gemm(x, t["kernel"], t["scaling_factors"], t["zeros"], bias, residual, t.get("out"), ln_w, silu)
-        if x.device != dev:
-            raise RuntimeError("the tasks of a chain live on one device")
-        if M == 0:
-            raise ValueError("empty task in a chain")
-        ptr = lambda v: v.data_ptr() if v is not None else None
-        arr[i] = _lib.ChainTask(x.data_ptr(), t["kernel"].data_ptr(), t["scaling_factors"].data_ptr(), t["zeros"].data_ptr(),
-                                out.data_ptr(), _lib.GemmFusion(ptr(bias), ptr(residual), ptr(ln_w), float(t.get("rmsnorm_eps", 1e-5)),
-                                                                int(silu)), M, K, N, G)
-        outs.append(out)
-    lib = _lib.load()
-    with torch.cuda.device(dev):
-        need = lib.quick_w4a16_chain_workspace_bytes(arr, len(tasks))
-        if need == 0:
-            _raise(lib.quick_w4a16_gemm_chain_f16(arr, len(tasks), None, 0, _stream()))   # says why these tasks do not chain
-        ws = _chain_workspace(dev, need)
-        if trace is not None:     # measurement aid: int64 device tensor [CUs, CHAIN_MAX, 8] of 100 MHz stamps (tools/chain_trace.py)
-            rc = lib.quick_w4a16_gemm_chain_trace(arr, len(tasks), ws.data_ptr(), ws.numel(), trace.data_ptr(), _stream())
-        else:
-            rc = lib.quick_w4a16_gemm_chain_f16(arr, len(tasks), ws.data_ptr(), ws.numel(), _stream())
-    if rc != _OK:
-        _raise(rc)
-    return outs
-
-
 def _tensor_version(t):
     return 0 if t.is_inference() else t._version     # inference tensors have no version counter (and cannot be rewritten in place outside inference mode)
 

@@ -738,29 +738,6 @@ def test_fused_decode_step_matches_torch_glue(qa, device):
             mask[..., ctx + step + 1] = 0
 
 
-def test_chained_decode_step_matches_per_gemm_launches(qa, device):
-    """decode_step_fused with the o / gate_up / down / next-qkv GEMMs of every layer in one chained launch: at batch 1 the
-    same bits as one launch per GEMM (the planner runs the same kernel there), at batch 3 the same up to the rounding of the
-    exact kernel the planner prefers for single launches."""
-    from quick_amd.decoder import CONFIGS, SyntheticDecoder, decode_step_fused
-    for batch in (1, 3):
-        ms = [SyntheticDecoder(CONFIGS["tiny"], batch=batch, max_len=40, device=device, seed=3) for _ in range(2)]
-        ctx = 12
-        tokens = torch.randint(0, 512, (batch, ctx), device=device)
-        t0 = [m.forward(tokens, torch.arange(ctx, device=device), None) for m in ms]
-        pos = torch.full((1,), ctx, dtype=torch.int64, device=device)
-        tok = t0[0].view(batch, 1)
-        for step in range(3):
-            ta, ha = decode_step_fused(ms[0], tok, pos, chain=True)
-            tb, hb = decode_step_fused(ms[1], tok, pos, chain=False)
-            if batch == 1:
-                assert torch.equal(ha, hb), step
-            else:
-                assert (ha.float() - hb.float()).abs().max() <= 5e-3 * hb.float().abs().max(), step
-            tok = tb.view(batch, 1)
-            pos += 1
-
-
 def _torch_decode_hidden(model, tok, pos, mask):
     """SyntheticDecoder.forward for T = 1, returning the final normed hidden state instead of the argmax."""
     import torch.nn.functional as F
@@ -854,118 +831,3 @@ def test_wide_tiles_epilogues_and_k_split(qa, device, M, K, N, G, kernel_id):
     y_act = qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kernel_id)
     torch.testing.assert_close(y_act, K_.silu_mul(qa.gemm_forward(xd, *packed, kernel_id=kernel_id)), rtol=2e-3, atol=2e-3)
 
-
-# ------------------------------------------------------------------------------------------------
-# chained small-batch GEMMs: several dependent GEMMs in one launch (quick_w4a16_gemm_chain_f16)
-# ------------------------------------------------------------------------------------------------
-CHAIN_SINGLE = SKINNY_DZ | (1 << 4) | (2 << 8)   # what a chain task runs when launched alone: table deferred-zero, ntw = 1, 8 waves
-
-
-def _decoder_layer_chain(qa, device, M, H, I, NQKV, G, seed):
-    """The GEMMs of one decoder layer after attention -- o (+ residual), gate_up (RMSNorm prologue, SiLU * mul epilogue),
-    down (+ residual), the next layer's qkv (RMSNorm prologue) -- as chain tasks, each reading what the one before wrote."""
-    layers = {}
-    for i, (name, K, N) in enumerate((("o", H, H), ("gate_up", H, 2 * I), ("down", I, H), ("qkv", H, NQKV))):
-        _, iw, s, z = oracle.make_synthetic(1, K, N, G, seed=seed + i)
-        layers[name] = dict(iw=iw, s=s, z=z, packed=_pack_dev(iw, s, z, device))
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    attn = (torch.randn(M, H, generator=g) * 0.5).half().to(device)
-    h0 = torch.randn(M, H, generator=g).half().to(device)
-    ln1 = (torch.rand(H, generator=g) + 0.5).half().to(device)
-    ln2 = (torch.rand(H, generator=g) + 0.5).half().to(device)
-    bufs = dict(h1=torch.empty(M, H, dtype=torch.float16, device=device), act=torch.empty(M, I, dtype=torch.float16, device=device),
-                h2=torch.empty(M, H, dtype=torch.float16, device=device), qkv=torch.empty(M, NQKV, dtype=torch.float16, device=device))
-
-    def tasks(b):
-        w = lambda n: dict(zip(("kernel", "scaling_factors", "zeros"), layers[n]["packed"]))
-        return [dict(in_feats=attn, residual=h0, out=b["h1"], **w("o")),
-                dict(in_feats=b["h1"], rmsnorm_weight=ln1, rmsnorm_eps=1e-5, silu_mul=True, out=b["act"], **w("gate_up")),
-                dict(in_feats=b["act"], residual=b["h1"], out=b["h2"], **w("down")),
-                dict(in_feats=b["h2"], rmsnorm_weight=ln2, rmsnorm_eps=1e-5, out=b["qkv"], **w("qkv"))]
-    return layers, tasks, bufs, (attn, h0, ln1, ln2)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,H,I,NQKV,G", [(1, 4096, 11008, 12288, 128), (1, 4096, 14336, 6144, 128), (2, 512, 1408, 768, 64),
-                                          (5, 1024, 2816, 1536, 32), (16, 512, 1024, 128, 128), (1, 8192, 28672, 10240, 128),
-                                          (3, 256, 512, 384, 256)])
-def test_chain_is_bit_identical_to_single_launches(qa, device, M, H, I, NQKV, G):
-    """One launch, four dependent GEMMs (with every epilogue / prologue the decoder uses) == the same four launched one by one
-    through the kernel a chain task runs.  Covers tasks with fewer channel blocks than workgroups (N = 128 .. 768), more
-    (N = 22016: five to six blocks per workgroup), several rows, every group mode, in-place residuals, a residual that is the y of
-    an earlier task, and the launch epoch moving on (three chains in a row over the same cells, poisoned outputs)."""
-    from quick_amd import kernels as K_
-    layers, tasks, bufs, _ = _decoder_layer_chain(qa, device, M, H, I, NQKV, G, seed=H + I + M)
-    ref = {k: torch.empty_like(v) for k, v in bufs.items()}
-    for t in tasks(ref):
-        t = dict(t)
-        qa.gemm_forward(t.pop("in_feats"), t.pop("kernel"), t.pop("scaling_factors"), t.pop("zeros"), kernel_id=CHAIN_SINGLE, grid_split_k=1, **t)
-    for rep in range(3):
-        for v in bufs.values():
-            v.fill_(float("nan"))
-        outs = K_.gemm_chain(tasks(bufs))
-        assert [o.data_ptr() for o in outs] == [bufs[k].data_ptr() for k in ("h1", "act", "h2", "qkv")]
-        for k in bufs:
-            assert torch.equal(bufs[k], ref[k]), (k, rep)
-    # a K-split launch in between (its own workspace) and another chain after it
-    x, iw, s, z = oracle.make_synthetic(16, 1024, 256, 128, seed=5)
-    y = qa.gemm_forward(_dev(x, device), *_pack_dev(iw, s, z, device), kernel_id=SKINNY, grid_split_k=4)
-    assert rel_err(y.cpu().numpy(), oracle.w4a16_forward(x, iw, s, z, 128)) <= TOL
-    K_.gemm_chain(tasks(bufs))
-    for k in bufs:
-        assert torch.equal(bufs[k], ref[k]), k
-
-
-@pytest.mark.gpu
-def test_chain_against_oracle(qa, device):
-    """The chain end to end against torch glue + the CPU oracle (not only against the library's own single launches)."""
-    from quick_amd import kernels as K_
-    M, H, I, NQKV, G = 2, 512, 1408, 768, 128
-    layers, tasks, bufs, (attn, h0, ln1, ln2) = _decoder_layer_chain(qa, device, M, H, I, NQKV, G, seed=77)
-    K_.gemm_chain(tasks(bufs))
-    f = lambda n, x: oracle.w4a16_forward(x, layers[n]["iw"], layers[n]["s"], layers[n]["z"], G).astype(np.float32)
-    norm = lambda x, w: ((x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-5)).half() * w.cpu()).numpy()
-    h1 = torch.from_numpy(f("o", attn.cpu().numpy()) + h0.cpu().numpy().astype(np.float32)).half()
-    assert rel_err(bufs["h1"].cpu().numpy(), h1.numpy()) <= TOL
-    gu = torch.from_numpy(f("gate_up", norm(bufs["h1"].cpu(), ln1))).half().view(M, -1, 2, 8)   # gate / up interleaved by 8
-    act = (torch.nn.functional.silu(gu[:, :, 0].float()).half() * gu[:, :, 1]).reshape(M, I)
-    assert rel_err(bufs["act"].cpu().numpy(), act.numpy()) <= 2 * TOL
-    h2 = f("down", bufs["act"].cpu().numpy()) + bufs["h1"].cpu().numpy().astype(np.float32)
-    assert rel_err(bufs["h2"].cpu().numpy(), h2) <= TOL
-    assert rel_err(bufs["qkv"].cpu().numpy(), f("qkv", norm(bufs["h2"].cpu(), ln2))) <= TOL
-
-
-@pytest.mark.gpu
-def test_chain_errors_and_graph_capture(qa, device):
-    from quick_amd import kernels as K_
-    layers, tasks, bufs, _ = _decoder_layer_chain(qa, device, 1, 512, 1024, 768, 128, seed=3)
-    with pytest.raises(ValueError):
-        K_.gemm_chain([])
-    with pytest.raises(ValueError):
-        K_.gemm_chain(tasks(bufs) * 2)                           # 8 > QUICK_CHAIN_MAX
-    x17, iw, s, z = oracle.make_synthetic(17, 512, 512, 128, seed=1)
-    with pytest.raises(NotImplementedError):                     # more than 16 tokens: launch them one by one
-        K_.gemm_chain([dict(in_feats=_dev(x17, device), **dict(zip(("kernel", "scaling_factors", "zeros"), _pack_dev(iw, s, z, device))))])
-    x8, iw, s, z = oracle.make_synthetic(8, 16384, 128, 128, seed=2)
-    with pytest.raises(NotImplementedError):                     # 8 rows of K = 16384 do not fit LDS
-        K_.gemm_chain([dict(in_feats=_dev(x8, device), **dict(zip(("kernel", "scaling_factors", "zeros"), _pack_dev(iw, s, z, device))))])
-    broken = tasks(bufs)
-    broken[2]["in_feats"] = broken[2]["in_feats"].clone()        # task 2 no longer reads the y of task 1: nothing orders them
-    with pytest.raises(NotImplementedError):
-        K_.gemm_chain(broken)
-    # captured in a hipGraph and replayed (what the decoder does)
-    K_.gemm_chain(tasks(bufs))
-    want = {k: v.clone() for k, v in bufs.items()}
-    st = torch.cuda.Stream()
-    with torch.cuda.stream(st):
-        K_.gemm_chain(tasks(bufs))
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st):
-            K_.gemm_chain(tasks(bufs))
-    for _ in range(5):
-        for v in bufs.values():
-            v.zero_()
-        g.replay()
-        torch.cuda.synchronize()
-        for k in bufs:
-            assert torch.equal(bufs[k], want[k])
