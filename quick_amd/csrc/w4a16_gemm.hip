@@ -1542,6 +1542,13 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
       if (M <= 2 || ((kernel >> 26) & 1) || (rounds >= 2 && balanced && p.ksplit == 1)) {  // bit 26: tests force the path
         p.dz = p.xlds = true;
         if (!flip && p.ksplit == 1 && rounds >= 2) p.grid_x = std::min(nblocks, ((nblocks + rounds - 1) / rounds + 7) & ~7);
+        // One workgroup per CU and a long K: 16 waves instead of 8 -- twice the bytes in flight per CU and half the chain of
+        // k-tiles a wave still has to compute after its last load lands.  M = 1, one session [r02]: 11008 x 4096 8.08 -> 7.12 us,
+        // 14336 x 4096 8.80 -> 8.44, 28672 x 8192 25.0 -> 23.4 (M = 2: 8.92 -> 7.64); nothing at K = 4096 (4096 x 12288 7.40 ->
+        // 7.36), and slower wherever two 8-wave workgroups share a CU (4096 x 22016 10.4 -> 13.0, 8192 x 8192 8.9 -> 11.6).
+        if (!waves_req && p.waves == 8 && p.grid_x <= 256 && p.kt_per_split >= 64 &&
+            skinny_lds_bytes(M, G, 1, 16, p.kt_per_split, true, true, true) <= kLdsPerCu)
+          p.waves = 16;
       }
     }
     if (!p.dz && !exact && !((kernel >> 28) & 1) && p.mt >= 2 && G % 128 == 0 &&  // (G < 128: 4 units per tile, spills)
@@ -1580,7 +1587,8 @@ static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) 
   dim3 grid(p.grid_x, (a.M + 15) / 16, p.ksplit), block(WAVES * 64);
   const size_t lds = skinny_lds_bytes(a.M, a.G, NTW, WAVES, p.kt_per_split, p.grid_x < a.N / (16 * NTW), XLDS, DZ) + (LN ? 1024 : 0);
   if (a.span) {  // in-kernel span stamps: separate instantiations, for the small-M kernels the BASELINE sweep and the decode shapes run
-    constexpr bool stamped = WAVES == 8 && !LN && ((NTW == 1 && XLDS && DZ) || (NTW == 1 && !XLDS && !DZ) || (NTW == 4 && !XLDS && DZ));
+    constexpr bool stamped = !LN && ((WAVES == 8 && ((NTW == 1 && XLDS && DZ) || (NTW == 1 && !XLDS && !DZ) || (NTW == 4 && !XLDS && DZ))) ||
+                                     (WAVES == 16 && NTW == 1 && XLDS && DZ));
     if constexpr (stamped) {
       if (group_mode(a.G) == 0) {
         auto kfn = w4a16_skinny_kernel<NTW, WAVES, 0, XLDS, DZ, LN, true>;
