@@ -1356,8 +1356,11 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   // skinny: one workgroup per 16 tokens x 16..64 channels for all of K (x re-read per channel block, no cross-workgroup
   // reduction); tiled: 32..64 tokens x 128 channels through LDS.  Measured crossover [r01]: the tiled kernel wins from
   // M = 65, and from M = 17 once there are >= 64 tiles of 128 channels (N >= 8192) so that it needs no K split.
+  // [r02] ... and at M = 57..64 on a small layer with a long K: 32-token tiles with a 4-way K split (64 x 11008 x 4096 17.7-18.9 ->
+  // 17.0-17.3 us, 64 x 14336 x 4096 22.2 -> 19.8, 64 x 16384 x 4096 24.8 -> 21.0; a tie at M = 49..56, and up to K = 8192 the
+  // skinny kernel stays ahead: 64 x 8192 x 4096 13.9 against 14.5 us, 64 x 4096 x 4096 8.3 against 10.9)
   const int tiled_tiles = (N / 128) * ((M + 63) / 64);
-  const bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= 64);
+  const bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= 64) || (M > 56 && K >= 10240);
   p.kernel = family == QUICK_KERNEL_AUTO ? (want_tiled ? QUICK_KERNEL_TILED : QUICK_KERNEL_SKINNY) : family;
   // Wide kernels (32x32x16 MFMA, one wave per SIMD, LDS-DMA) from 256 tokens, and from 64 tokens once there are enough
   // 64 x 128 tiles to cover the chip (large N): 13 % ahead of the r01 kernels on average over 45 (M, K, N) shapes between
@@ -1368,8 +1371,12 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   // measured variant on average, 3.3 % at worst); a K split costs slices * tile bytes at ~60 GB/s for the last arriver.
   int wide_mb = 0, wide_pairs = 0;
   bool wide_ring = false;
-  if (family == QUICK_KERNEL_AUTO && G % 128 == 0 && M >= 64 &&
-      (M >= 256 || (long)((M + 63) / 64) * (N / 128) >= 160)) {
+  // [r02] ... or, with fewer tiles, once the K slices that fill the chip are still >= 32 stages long (64 x 28672 x 8192: 64 tiles
+  // x 4 slices of 56 stages, 46.6 us against the tiled kernel's 54.6-58; M = 80 / 96 / 128 / 200 there: 70.6 / 72.4 / 73.8 / 126.9
+  // against 78.4 / 80.0 / 79.3 / 150.8; at 16-22 stages per slice the r01 kernels stay ahead)
+  const long wide_tiles64 = (long)((M + 63) / 64) * (N / 128);
+  const bool wide_long_k = wide_tiles64 <= 128 && KT / std::max<long>(1, 256 / wide_tiles64) >= 32;
+  if (family == QUICK_KERNEL_AUTO && G % 128 == 0 && M >= 64 && (M >= 256 || wide_tiles64 >= 160 || wide_long_k)) {
     static const int cand[5][3] = {{2, 1, 4}, {2, 2, 2}, {4, 1, 2}, {4, 2, 1}, {8, 2, 1}};   // mb, pairs, workgroups per CU
     static const double eff[5] = {0.86, 0.90, 1.00, 1.03, 1.04};
     double best = 0;
