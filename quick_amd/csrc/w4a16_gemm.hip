@@ -1360,7 +1360,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   // 17.0-17.3 us, 64 x 14336 x 4096 22.2 -> 19.8, 64 x 16384 x 4096 24.8 -> 21.0; a tie at M = 49..56, and up to K = 8192 the
   // skinny kernel stays ahead: 64 x 8192 x 4096 13.9 against 14.5 us, 64 x 4096 x 4096 8.3 against 10.9)
   const int tiled_tiles = (N / 128) * ((M + 63) / 64);
-  const bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= 64) || (M > 56 && K >= 10240);
+  // [r02 audit, profiles/r02_planner_audit_*.jsonl] 48 tiles are enough (4096 x 6144, M = 24..64: 10.4-12.8 against the skinny
+  // kernel's 11.4-14.2 us); and the long-K rule starts at M = 33 from K = 12288 (48 x 14336 x 4096: 22.2 -> 19.2)
+  const bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= 48) || (M > 56 && K >= 10240) || (M > 32 && K >= 12288);
   p.kernel = family == QUICK_KERNEL_AUTO ? (want_tiled ? QUICK_KERNEL_TILED : QUICK_KERNEL_SKINNY) : family;
   // Wide kernels (32x32x16 MFMA, one wave per SIMD, LDS-DMA) from 256 tokens, and from 64 tokens once there are enough
   // 64 x 128 tiles to cover the chip (large N): 13 % ahead of the r01 kernels on average over 45 (M, K, N) shapes between
@@ -1375,8 +1377,10 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   // x 4 slices of 56 stages, 46.6 us against the tiled kernel's 54.6-58; M = 80 / 96 / 128 / 200 there: 70.6 / 72.4 / 73.8 / 126.9
   // against 78.4 / 80.0 / 79.3 / 150.8; at 16-22 stages per slice the r01 kernels stay ahead)
   const long wide_tiles64 = (long)((M + 63) / 64) * (N / 128);
-  const bool wide_long_k = wide_tiles64 <= 128 && KT / std::max<long>(1, 256 / wide_tiles64) >= 32;
-  if (family == QUICK_KERNEL_AUTO && G % 128 == 0 && M >= 64 && (M >= 256 || wide_tiles64 >= 160 || wide_long_k)) {
+  // (audit: from 24 stages -- 96 / 128 x 14336 x 4096, 4 slices of 28: 27.3 / 28.0 against 29.0 / 29.3 us; at 21 stages it is a toss-up,
+  // 96 x 11008 x 4096 22.8 against 23.6 but 48 x 8192 x 10240 25.2 against 22.3 -- and from M = 33: 48 x 28672 x 8192 54.6 -> 45.5)
+  const bool wide_long_k = wide_tiles64 <= 128 && KT / std::max<long>(1, 256 / wide_tiles64) >= 24;
+  if (family == QUICK_KERNEL_AUTO && G % 128 == 0 && ((M >= 64 && (M >= 256 || wide_tiles64 >= 160)) || (M > 32 && wide_long_k))) {
     static const int cand[5][3] = {{2, 1, 4}, {2, 2, 2}, {4, 1, 2}, {4, 2, 1}, {8, 2, 1}};   // mb, pairs, workgroups per CU
     static const double eff[5] = {0.86, 0.90, 1.00, 1.03, 1.04};
     double best = 0;
@@ -1440,13 +1444,23 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     // 65 -> 36 us [r01]).  Small layers keep NTW = 1 (more workgroups); from 1024 channel blocks the deferred-zero path
     // (x in LDS) is as fast or faster and stays.
     if (!mt_req && M > 8 && M <= 32 && (long)K * N >= 40L * 1000 * 1000) {  // (M = 17..32: 11008 x 4096 16.6 -> 13.5 us)
-      const bool dz_ok = mblocks == 1 && !no_xlds && !((kernel >> 25) & 1) && N / 16 >= 1024 &&
+      // (the table flavour up to M = 12: at M = 16 the 4-tile fragment flavour is ahead, 4096 x 22016 18.3 -> 16.9 us, 4096 x
+      // 28672 20.3 -> 19.3 [r02 audit])
+      const bool dz_ok = mblocks == 1 && M <= 12 && !no_xlds && !((kernel >> 25) & 1) && N / 16 >= 1024 &&
                          skinny_lds_bytes(M, G, 1, 8, KT, true, true, true) <= kLdsPerCu;
       if (!dz_ok) mt_auto = 4;
     } else if (!mt_req && M >= 6 && M <= 8 && N >= 8192 && N / 16 < 1024 && (size_t)M * (K * 2 + 16) > (size_t)64 * 1024) {
       // (only where the 4-tile kernel takes its fragments straight from L2: its LDS-copy flavour is slower, M = 6, 7 at K = 4096)
       mt_auto = 4;  // at M = 8: 4096 x 12288 11.0 -> 10.3 us, 8192 x 10240 18.7 -> 16.6 us, 28672 x 8192 49 -> 34 us; from
     }               // 1024 blocks (4096 x 22016, 8192 x 57344) the deferred-zero path stays ahead, and so it does at M <= 4
+    // 257..512 channel blocks (N = 6144, 8192) at M = 4..16: one-tile workgroups come in 1.5 or 2 per CU -- two tiles per
+    // workgroup are one round of <= 256 and share every x fragment [r02 audit: 4096 x 6144 M = 4 / 8 / 16 7.6 / 8.2 / 10.9 -> 6.4 /
+    // 6.3 / 7.6 us, 8192 x 8192 M = 6 14.7 -> 10.1, 28672 x 8192 M = 3, 4 33.5 -> 25.4]; large layers keep the 4 tiles from M = 9
+    if (!mt_req && mblocks == 1 && N / 16 > 256 && N / 16 <= 512 && G % 128 == 0) {
+      if (KT >= 128) mt_auto = M >= 3 ? 4 : mt_auto;  // (a very long K: four tiles and a 2-way K split, 28672 x 8192 M = 3..8 24.8-25.1 us)
+      else if (M >= 4 && M <= 8) mt_auto = 2;
+      else if (M > 8 && (long)K * N < 40L * 1000 * 1000) mt_auto = 2;
+    }
     p.mt = mt_req ? mt_req : mt_auto;
     if (p.mt != 1 && p.mt != 2) p.mt = 4;
     while (p.mt > 1 && (N / 16) % p.mt != 0) p.mt /= 2;
@@ -1464,6 +1478,12 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     // 32-token tiles once 64-token tiles would need a 4-way K split to cover the CUs (twice the tiles, half the slices
     // to reduce): M = 65..128 at N = 4096, 15.5 us instead of 16.5 us at M = 128 [r01]
     if (!mt_req && p.mt == 4 && (N / 128) * ((M + 63) / 64) * 4 <= 256 && (KT + wk - 1) / wk >= 8) p.mt = 2;
+    // ... and at K <= 4096 already where they would need a 2-way split: twice the tiles and nothing to reduce (64 x 4096 x 12288
+    // 18.1 -> 17.0 us, 192 x 4096 x 4096 18.2 -> 17.1, 96 / 128 x 4096 x 6144 17.9 -> 16.9 [r02 audit]; with a longer K the split
+    // tiles stay ahead: 48 x 8192 x 10240 22.3 against 29.4)
+    if (!mt_req && p.mt == 4 && K <= 4096 && !((kernel >> 27) & 1) && !((kernel >> 29) & 1) && (N / 128) * ((M + 63) / 64) * 2 <= 256 &&
+        (N / 128) * ((M + 31) / 32) <= 256)
+      p.mt = 2;
     // 256-channel tiles (4 channel tiles per wave: one LDS fragment read per four MFMAs instead of two, 2/3 of the L2 -> CU
     // bytes per MAC): M = 1024 at N = 4096 59 -> 50 us, M = 8192 x 22016 772 -> 845 TFLOP/s [r01].  Whether they pay is a
     // matter of how the tiles quantise onto the 256 CUs.  In units of one 128-channel tile alone on its CU: two

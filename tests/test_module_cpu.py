@@ -177,6 +177,17 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "tokens=256 channels=256" in plan(4096, 8192, 8192, kernel_id=W | (8 << 4) | (2 << 8))      # explicit tile
     assert "waves=8 ring=6" in plan(512, 4096, 4096, kernel_id=W | (2 << 4) | (1 << 8) | (1 << 15))   # eight-wave ring
     assert "ring=0" in plan(512, 4096, 4096, kernel_id=W | (2 << 4) | (1 << 8) | (1 << 12))           # double-buffered instead
+    # r02 planner audit (profiles/r02_planner_audit_*.jsonl): the rules it added
+    assert "waves=16" in plan(1, 11008, 4096) and "waves=8" in plan(1, 4096, 4096) and "waves=8" in plan(1, 4096, 22016)   # long K, one workgroup per CU
+    assert plan(16, 4096, 6144).startswith("skinny ntw=2") and "deferred-zero-fragment" in plan(16, 4096, 6144)    # 384 blocks: one round of 192
+    assert plan(6, 8192, 8192).startswith("skinny ntw=2") and plan(4, 28672, 8192).startswith("skinny ntw=4")
+    assert "deferred-zero-table" in plan(12, 4096, 22016) and plan(16, 4096, 22016).startswith("skinny ntw=4")
+    assert plan(32, 4096, 6144).startswith("tiled tokens=32") and plan(32, 4096, 4096).startswith("skinny")       # 48 tiles are enough, 32 are not
+    assert "tokens=32 channels=128 waves=8 grid=192x1 ksplit=1" in plan(64, 4096, 12288)                           # twice the tiles, nothing to reduce
+    assert "tokens=64" in plan(48, 8192, 10240) and "ksplit=3" in plan(48, 8192, 10240)                            # ... only at K <= 4096
+    assert plan(64, 11008, 4096).startswith("tiled tokens=32") and plan(48, 11008, 4096).startswith("skinny") and plan(48, 14336, 4096).startswith("tiled")
+    assert plan(64, 28672, 8192).startswith("wide tokens=64 channels=128 waves=4 ring=6 grid=64x4 ksplit=4")      # slices of 56 stages
+    assert plan(48, 28672, 8192).startswith("wide") and plan(64, 8192, 8192).startswith("tiled")                  # ... of 16 stages: no
     # forcing a family / a split through the kernel id and grid_split_k
     assert plan(512, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny")
     assert "ksplit=4" in plan(64, 4096, 4096, kernel_id=kernels.KERNEL_TILED, grid_split_k=4)
