@@ -1380,7 +1380,12 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   // (audit: from 24 stages -- 96 / 128 x 14336 x 4096, 4 slices of 28: 27.3 / 28.0 against 29.0 / 29.3 us; at 21 stages it is a toss-up,
   // 96 x 11008 x 4096 22.8 against 23.6 but 48 x 8192 x 10240 25.2 against 22.3 -- and from M = 33: 48 x 28672 x 8192 54.6 -> 45.5)
   const bool wide_long_k = wide_tiles64 <= 128 && KT / std::max<long>(1, 256 / wide_tiles64) >= 24;
-  if (family == QUICK_KERNEL_AUTO && G % 128 == 0 && ((M >= 64 && (M >= 256 || wide_tiles64 >= 160)) || (M > 32 && wide_long_k))) {
+  // ... except where 32-token tiles fit the token count exactly, fill one round and the 64- / 128-token tiles would run a quarter
+  // empty (M = 65..96 on Llama-2-70B's qkv: 96 x 8192 x 10240 = 240 tiles of 32 x 128, 30.2 us against 38.6 [r02 audit])
+  const long tiles32 = (long)((M + 31) / 32) * (N / 128);
+  const bool exact32 = M < 128 && ((M + 63) / 64) * 64 - M >= 32 && tiles32 >= 208 && tiles32 <= 256 && !wide_long_k;
+  if (family == QUICK_KERNEL_AUTO && G % 128 == 0 && !exact32 &&
+      ((M >= 64 && (M >= 256 || wide_tiles64 >= 160)) || (M > 32 && wide_long_k))) {
     static const int cand[5][3] = {{2, 1, 4}, {2, 2, 2}, {4, 1, 2}, {4, 2, 1}, {8, 2, 1}};   // mb, pairs, workgroups per CU
     static const double eff[5] = {0.86, 0.90, 1.00, 1.03, 1.04};
     double best = 0;
@@ -1481,6 +1486,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     // ... and at K <= 4096 already where they would need a 2-way split: twice the tiles and nothing to reduce (64 x 4096 x 12288
     // 18.1 -> 17.0 us, 192 x 4096 x 4096 18.2 -> 17.1, 96 / 128 x 4096 x 6144 17.9 -> 16.9 [r02 audit]; with a longer K the split
     // tiles stay ahead: 48 x 8192 x 10240 22.3 against 29.4)
+    if (!mt_req && p.mt == 4 && exact32 && !((kernel >> 27) & 1) && !((kernel >> 29) & 1)) p.mt = 2;  // (see exact32 above)
     if (!mt_req && p.mt == 4 && K <= 4096 && !((kernel >> 27) & 1) && !((kernel >> 29) & 1) && (N / 128) * ((M + 63) / 64) * 2 <= 256 &&
         (N / 128) * ((M + 31) / 32) <= 256)
       p.mt = 2;
