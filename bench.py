@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--split-k", type=int, default=0, help="K slices across workgroups (0 = the planner's choice; tuning only)")
     ap.add_argument("--layers", default="1x4096x12288,1x4096x22016,1x11008x4096",
                     help="MxKxN shapes (Llama-2-7B fused qkv, gate_up, down at bs=1) timed kernel-only into 'decode_layers'; '' = none")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=14.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--decode-seconds", type=float, default=40.0, help="budget of the decode tok/s leg (Llama-2-7B bs=1,64; 0 = skip)")
     args = ap.parse_args()
 
