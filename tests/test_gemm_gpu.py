@@ -793,9 +793,10 @@ def test_random_shapes_against_dequantised_matmul(qa, device):
     for case in range(int(os.environ.get("QUICK_AMD_RANDOM_CASES", "60"))):   # (a longer soak: set the variable)
         G = int(rng.choice([32, 64, 128, 128, 128, 256]))
         unit = max(G, 128)                                   # K is a multiple of 128 and of the group size
-        K = int(rng.integers(1, 8192 // unit + 1)) * unit
+        kmax = 28672 if case % 5 == 4 else 8192              # every fifth draw may have a long K (the planner's long-K rules)
+        K = int(rng.integers(1, kmax // unit + 1)) * unit
         N = int(rng.integers(1, 97)) * 128
-        M = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 24, 32, 40, 63, 64, 65, 100, 128, 200, 257, 384, 520, 700]))
+        M = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 13, 16, 17, 24, 32, 40, 48, 57, 63, 64, 65, 96, 100, 128, 200, 257, 384, 520, 700]))
         if M * N * K > 2.5e10:
             M = max(1, int(2.5e10 // (N * K)))
         gen.manual_seed(case)
@@ -808,6 +809,51 @@ def test_random_shapes_against_dequantised_matmul(qa, device):
         err = (y1.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
         assert err <= TOL, (case, M, K, N, G, err, K_.plan_describe(M, K, N, G))
     print(f"{case + 1} random shapes checked")
+
+
+def test_random_shapes_with_fused_epilogues_and_prologue(qa, device):
+    """The same kind of net for the fusions: seeded random shapes through whatever kernel the planner picks, with a random
+    one of {bias, residual, bias + residual, SiLU*mul, RMSNorm prologue (where the planner's kernel takes it) + residual},
+    against torch ops around the fp32 matmul over the GPU-dequantised weights."""
+    from quick_amd import kernels as K_, packing
+    rng = np.random.default_rng(77)
+    gen = torch.Generator(device=device)
+    seen = set()
+    for case in range(int(os.environ.get("QUICK_AMD_RANDOM_CASES", "80"))):
+        G = int(rng.choice([64, 128, 128, 128, 256]))
+        unit = max(G, 128)
+        K = int(rng.integers(1, (16384 if case % 4 == 3 else 4096) // unit + 1)) * unit
+        N = int(rng.integers(1, 65)) * 256                   # (SiLU*mul pairs gate / up channels: N / 2 must stay a multiple of 128)
+        M = int(rng.choice([1, 2, 4, 6, 8, 12, 16, 24, 48, 64, 96, 130, 300, 520]))
+        if M * N * K > 1.2e10:
+            M = max(1, int(1.2e10 // (N * K)))
+        gen.manual_seed(1000 + case)
+        qw, sc, qz = packing.random_mi355x(K, N, G, device, generator=gen)
+        x = (torch.randn(M, K, device=device, generator=gen) * 0.5).half()
+        w = K_.dequantize_mi355x(qw, sc, qz).float()
+        bias = (torch.randn(N, device=device, generator=gen) * 0.5).half()
+        res = torch.randn(M, N, device=device, generator=gen).half()
+        kind = int(rng.integers(0, 5))
+        if kind == 4 and not K_.can_fuse_rmsnorm(M, K, N, G):
+            kind = 1
+        seen.add(kind)
+        if kind == 0:
+            y, ref = qa.gemm_forward(x, qw, sc, qz, bias=bias), x.float() @ w + bias.float()
+        elif kind == 1:
+            y, ref = qa.gemm_forward(x, qw, sc, qz, residual=res), x.float() @ w + res.float()
+        elif kind == 2:
+            y, ref = qa.gemm_forward(x, qw, sc, qz, bias=bias, residual=res), x.float() @ w + bias.float() + res.float()
+        elif kind == 3:
+            gu = (x.float() @ w).half().view(M, N // 16, 2, 8)                 # gate / up interleaved by 8
+            ref = (torch.nn.functional.silu(gu[:, :, 0].float()).half() * gu[:, :, 1]).reshape(M, N // 2).float()
+            y = qa.gemm_forward(x, qw, sc, qz, silu_mul=True)
+        else:
+            lnw = (torch.rand(K, device=device, generator=gen) + 0.5).half()
+            xn = ((x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-5)).half() * lnw)
+            y, ref = qa.gemm_forward(x, qw, sc, qz, rmsnorm_weight=lnw, rmsnorm_eps=1e-5, residual=res), xn.float() @ w + res.float()
+        err = (y.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+        assert err <= (2 if kind == 3 else 1) * TOL, (case, kind, M, K, N, G, err, K_.plan_describe(M, K, N, G))
+    assert len(seen) == 5
 
 
 @pytest.mark.parametrize("kernel_id", [TILED_WIDE, TILED_BIG], ids=["64x256", "128x256"])
