@@ -188,6 +188,17 @@ int quick_repack_mi355x_to_cuda(const void* qweight_in, const void* scales_in, c
                                 void* qweight_out, void* scales_out, void* qzeros_out,
                                 int K, int N, int group_size, void* hip_stream);
 
+/* in_features that the MI355X weight order cannot tile (K % 128 != 0; the reference accepts K % 32 == 0,
+ * csrc/gemm_cuda_quick.cu:1479-1484 -- only possible with a group size that is not a multiple of 128): the layer runs on a copy
+ * padded along K to quick_padded_in_features(K, G) = the next multiple of lcm(128, G), with weights 0, zero points 0 and
+ * scales 0 in the added rows / groups (they contribute exactly 0), and on activations zero-padded to that width by the
+ * caller.  quick_repack_cuda_to_mi355x_padded writes that copy: outputs are sized for the padded K
+ * (qweight [Kp/4, N/2], scales [Kp/G, 2N], qzeros [Kp/G, N/4]).  quick_padded_in_features returns 0 for shapes the
+ * reference rejects too. */
+int quick_padded_in_features(int K, int group_size);
+int quick_repack_cuda_to_mi355x_padded(const void* qweight_in, const void* scales_in, const void* qzeros_in, void* qweight_out,
+                                       void* scales_out, void* qzeros_out, int K, int N, int group_size, void* hip_stream);
+
 /* Dequantise an MI355X-order layer to a dense fp16 [K, N] row-major matrix (debug / parity aid;
  * counterpart of the reference CPU path quick/awq/utils/packing_utils.py:82-97). */
 int quick_dequantize_mi355x_f16(const void* qweight, const void* scales, const void* qzeros,

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "quick_amd_dispatch_floor": (_I, [_I, _P, _P]),
     "quick_repack_cuda_to_mi355x": (_I, [_P] * 6 + [_I, _I, _I, _P]),
     "quick_repack_mi355x_to_cuda": (_I, [_P] * 6 + [_I, _I, _I, _P]),
+    "quick_padded_in_features": (_I, [_I, _I]),
+    "quick_repack_cuda_to_mi355x_padded": (_I, [_P] * 6 + [_I, _I, _I, _P]),
     "quick_dequantize_mi355x_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -62,11 +62,15 @@ torch::Tensor gemm_forward_cuda_quick(torch::Tensor in_feats, torch::Tensor kern
   const int G = K / (int)scaling_factors.size(0);              // gemm_cuda_quick.cu:1477
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(in_feats.device());   // OptionalCUDAGuard, gemm_cuda_quick.cu:1465
   hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  // in_features % 128 != 0 (the reference takes % 32): the MI355X-order copy is padded along K, the activations with zeros
+  const int padded = (K % 128 != 0) ? quick_padded_in_features(K, G) : 0;
+  const int Kp = padded > 0 ? padded : K;
   {  // the reference's shape errors, before any repack
     char text[8];
-    const int rc = quick_w4a16_plan_describe(M > 0 ? M : 1, K, N, G, QUICK_KERNEL_AUTO, 0, text, sizeof(text));
+    const int rc = quick_w4a16_plan_describe(M > 0 ? M : 1, Kp, N, G, QUICK_KERNEL_AUTO, 0, text, sizeof(text));
     if (rc != QUICK_OK) raise(rc);
   }
+  if (Kp != K) in_feats = torch::constant_pad_nd(in_feats, {0, Kp - K}, 0);
   torch::Tensor packed[3];
   torch::Tensor ws;
   size_t ws_bytes = 0;
@@ -85,17 +89,20 @@ torch::Tensor gemm_forward_cuda_quick(torch::Tensor in_feats, torch::Tensor kern
       for (int i = 0; i < 3; ++i) {
         e.ref.emplace_back(src[i].getIntrusivePtr());
         e.version[i] = version_of(src[i]);
-        e.packed[i] = torch::empty_like(src[i]);
       }
-      const int rc = quick_repack_cuda_to_mi355x(kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), e.packed[0].data_ptr(),
-                                                 e.packed[1].data_ptr(), e.packed[2].data_ptr(), K, N, G, stream);
+      e.packed[0] = torch::empty({Kp / 4, N / 2}, kernel.options());
+      e.packed[1] = torch::empty({Kp / G, 2 * N}, scaling_factors.options());
+      e.packed[2] = torch::empty({Kp / G, N / 4}, zeros.options());
+      const int rc = (Kp != K ? quick_repack_cuda_to_mi355x_padded : quick_repack_cuda_to_mi355x)(
+          kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), e.packed[0].data_ptr(), e.packed[1].data_ptr(),
+          e.packed[2].data_ptr(), K, N, G, stream);
       if (rc != QUICK_OK) raise(rc);
       for (auto d = g_cache.begin(); d != g_cache.end();)  // drop entries whose tensors died
         d = (d->second.ref[0].expired() || d->second.ref[1].expired() || d->second.ref[2].expired()) ? g_cache.erase(d) : std::next(d);
       it = g_cache.insert_or_assign(key, std::move(e)).first;
     }
     for (int i = 0; i < 3; ++i) packed[i] = it->second.packed[i];
-    ws_bytes = M > 0 ? quick_w4a16_workspace_bytes(M, K, N, G, split_k_iters) : 0;
+    ws_bytes = M > 0 ? quick_w4a16_workspace_bytes(M, Kp, N, G, split_k_iters) : 0;
     if (ws_bytes) {  // ZERO-FILLED on first use (the arrival counters of the in-kernel split-K reduction), reused afterwards
       auto& slot = g_workspace[{(int)in_feats.get_device(), (void*)stream}];
       if (!slot.defined() || (size_t)slot.numel() < ws_bytes)
@@ -106,7 +113,7 @@ torch::Tensor gemm_forward_cuda_quick(torch::Tensor in_feats, torch::Tensor kern
   auto y = torch::empty({M, N}, in_feats.options());
   if (M > 0) {
     const int rc = quick_w4a16_gemm_f16(in_feats.data_ptr(), packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr(), y.data_ptr(),
-                                        ws_bytes ? ws.data_ptr() : nullptr, ws_bytes ? (size_t)ws.numel() : 0, M, K, N, G, split_k_iters, stream);
+                                        ws_bytes ? ws.data_ptr() : nullptr, ws_bytes ? (size_t)ws.numel() : 0, M, Kp, N, G, split_k_iters, stream);
     if (rc != QUICK_OK) raise(rc);
   }
   return split_k_iters > 1 ? y : y.unsqueeze(0);               // gemm_cuda_quick.cu:1515-1516

@@ -33,13 +33,18 @@ __device__ __forceinline__ void mi355x_dword_coord(size_t d, int K, int& k0, int
   k0 = kt * 128 + t * 32 + 8 * (lane >> 4);
 }
 
+// K = rows of the OUTPUT (a multiple of 128); rows >= K_in (a multiple of 32: a dword is all inside or all outside) are padding
 __global__ __launch_bounds__(256) void repack_weight_cuda_to_mi355x(const uint32_t* __restrict__ in,
-                                                                    uint32_t* __restrict__ out, int K, int N) {
+                                                                    uint32_t* __restrict__ out, int K, int N, int K_in) {
   const size_t d = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (d >= (size_t)K * N / 8) return;
   int k0, n;
   mi355x_dword_coord(d, K, k0, n);
   uint32_t v = 0;
+  if (k0 >= K_in) {
+    out[d] = 0u;
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     size_t idx;
@@ -72,10 +77,14 @@ __global__ __launch_bounds__(256) void repack_weight_mi355x_to_cuda(const uint32
 __global__ __launch_bounds__(256) void repack_sz_cuda_to_mi355x(const half_t* __restrict__ s_in,
                                                                 const uint32_t* __restrict__ z_in,
                                                                 uint32_t* __restrict__ sz_out, uint32_t* __restrict__ z_out,
-                                                                int NG, int N) {
+                                                                int NG, int N, int NG_in) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)NG * N) return;
   const int g = (int)(i / N), n = (int)(i % N);
+  if (g >= NG_in) {  // a padding group: scale 0, zero point 0 (z_out was zeroed)
+    sz_out[group_word_index(g, n, NG)] = 0u;
+    return;
+  }
   const int x = cuda_order_slot(n, N);
   const uint32_t z = (z_in[(size_t)g * (N >> 2) + (x >> 2)] >> (4 * (x & 3))) & 15u;
   const uint32_t sbits = __builtin_bit_cast(unsigned short, s_in[(size_t)g * 2 * N + 2 * x]);
@@ -110,18 +119,42 @@ using namespace quick_amd;
 
 extern "C" {
 
-int quick_repack_cuda_to_mi355x(const void* qweight_in, const void* scales_in, const void* qzeros_in, void* qweight_out,
-                                void* scales_out, void* qzeros_out, int K, int N, int group_size, void* hip_stream) {
-  if (int rc = check(K, N, group_size)) return rc;
-  hipStream_t st = (hipStream_t)hip_stream;
+static int repack_to_mi355x(const void* qweight_in, const void* scales_in, const void* qzeros_in, void* qweight_out,
+                            void* scales_out, void* qzeros_out, int K_in, int K, int N, int group_size, hipStream_t st) {
   const int NG = K / group_size;
   const size_t nd = (size_t)K * N / 8;
   if (hipMemsetAsync(qzeros_out, 0, (size_t)NG * (N / 4) * 4, st) != hipSuccess) return QUICK_ERR_LAUNCH;
   hipLaunchKernelGGL(repack_weight_cuda_to_mi355x, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st,
-                     (const uint32_t*)qweight_in, (uint32_t*)qweight_out, K, N);
+                     (const uint32_t*)qweight_in, (uint32_t*)qweight_out, K, N, K_in);
   hipLaunchKernelGGL(repack_sz_cuda_to_mi355x, dim3((unsigned)(((size_t)NG * N + 255) / 256)), dim3(256), 0, st,
-                     (const half_t*)scales_in, (const uint32_t*)qzeros_in, (uint32_t*)scales_out, (uint32_t*)qzeros_out, NG, N);
+                     (const half_t*)scales_in, (const uint32_t*)qzeros_in, (uint32_t*)scales_out, (uint32_t*)qzeros_out, NG, N,
+                     K_in / group_size);
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+}
+
+int quick_repack_cuda_to_mi355x(const void* qweight_in, const void* scales_in, const void* qzeros_in, void* qweight_out,
+                                void* scales_out, void* qzeros_out, int K, int N, int group_size, void* hip_stream) {
+  if (int rc = check(K, N, group_size)) return rc;
+  return repack_to_mi355x(qweight_in, scales_in, qzeros_in, qweight_out, scales_out, qzeros_out, K, K, N, group_size, (hipStream_t)hip_stream);
+}
+
+int quick_padded_in_features(int K, int group_size) {
+  if (K <= 0 || group_size <= 0 || group_size % 32 != 0 || K % 32 != 0 || K % group_size != 0) return 0;
+  int a = 128, b = group_size;
+  while (b) {
+    const int t = a % b;
+    a = b;
+    b = t;
+  }
+  const long unit = 128L * group_size / a;  // lcm(128, group_size)
+  return (int)(((long)K + unit - 1) / unit * unit);
+}
+
+int quick_repack_cuda_to_mi355x_padded(const void* qweight_in, const void* scales_in, const void* qzeros_in, void* qweight_out,
+                                       void* scales_out, void* qzeros_out, int K, int N, int group_size, void* hip_stream) {
+  const int Kp = quick_padded_in_features(K, group_size);
+  if (Kp == 0 || N <= 0 || N % 128 != 0) return QUICK_ERR_INVALID_ARGUMENT;
+  return repack_to_mi355x(qweight_in, scales_in, qzeros_in, qweight_out, scales_out, qzeros_out, K, Kp, N, group_size, (hipStream_t)hip_stream);
 }
 
 int quick_repack_mi355x_to_cuda(const void* qweight_in, const void* scales_in, const void* qzeros_in, void* qweight_out,

@@ -154,12 +154,52 @@ def reference_to_mi355x_cached(kernel, scaling_factors, zeros):
     if ent is not None and ent.versions == versions and all(r() is t for r, t in zip(ent.refs, tensors)):
         return ent.packed
     ent = _Repacked()
-    ent.packed = repack_cuda_to_mi355x(kernel, scaling_factors, zeros)
+    if kernel.shape[0] * 4 % 128 == 0:
+        ent.packed = repack_cuda_to_mi355x(kernel, scaling_factors, zeros)
+    else:
+        ent.packed = _padded_mi355x(kernel, scaling_factors, zeros)
     ent.versions = versions
     drop = lambda _ref, key=key: _REPACK_CACHE.pop(key, None)
     ent.refs = tuple(weakref.ref(t, drop) for t in tensors)
     _REPACK_CACHE[key] = ent
     return ent.packed
+
+
+def padded_in_features(K, G):
+    """The reference accepts in_features % 32 == 0 (csrc/gemm_cuda_quick.cu:1479-1484); the MI355X weight order is made of
+    128-k tiles.  A layer in between (only possible with group sizes that are not multiples of 128) runs on a copy padded
+    along K to the next multiple of lcm(128, G): weights 0, zero points 0, scales 0 in the added groups -- they contribute
+    exactly 0 -- and the activations padded with zeros per call."""
+    import math
+    unit = 128 * G // math.gcd(128, G)
+    return (K + unit - 1) // unit * unit
+
+
+def _padded_mi355x(kernel, scaling_factors, zeros):
+    """MI355X-order tensors of a reference-order layer whose K is not a multiple of 128, once per layer: the HIP repack
+    kernel's padded flavour on the GPU, torch ops on CPU tensors (tests)."""
+    from . import packing
+    if kernel.is_cuda:
+        K, N = kernel.shape[0] * 4, kernel.shape[1] * 2
+        G = K // scaling_factors.shape[0]
+        lib = _lib.load()
+        Kp = lib.quick_padded_in_features(K, G)
+        if Kp == 0:
+            raise ValueError(f"quick_repack_cuda_to_mi355x_padded: invalid shape K={K} N={N} G={G}")
+        outs = [torch.empty((Kp // 4, N // 2), dtype=torch.int32, device=kernel.device),
+                torch.empty((Kp // G, 2 * N), dtype=torch.float16, device=kernel.device),
+                torch.empty((Kp // G, N // 4), dtype=torch.int32, device=kernel.device)]
+        with torch.cuda.device(kernel.device):
+            rc = lib.quick_repack_cuda_to_mi355x_padded(kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
+                                                        outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), K, N, G, _stream())
+        if rc != _OK:
+            _raise(rc)
+        return tuple(outs)
+    iw, s, z = packing.unpack_cuda_order(kernel, scaling_factors, zeros)
+    K, G = iw.shape[0], iw.shape[0] // s.shape[0]
+    Kp = padded_in_features(K, G)
+    pad = lambda t, rows: torch.cat([t, torch.zeros((rows - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)])
+    return packing.pack_mi355x(pad(iw, Kp), pad(s, Kp // G), pad(z, Kp // G))
 
 
 def gemm_forward_cuda_quick(in_feats, kernel, scaling_factors, zeros, split_k_iters):
@@ -184,7 +224,11 @@ def gemm_forward_cuda_quick(in_feats, kernel, scaling_factors, zeros, split_k_it
     K, N = kernel.shape[0] * 4, kernel.shape[1] // 4 * 8       # gemm_cuda_quick.cu:1468
     if in_feats.shape[1] != K:
         raise ValueError(f"kernel has {K} input channels, in_feats has {in_feats.shape[1]}")
-    plan_describe(max(int(in_feats.shape[0]), 1), K, N, K // scaling_factors.shape[0])   # the reference's shape errors, before any repack
+    G = K // scaling_factors.shape[0]
+    Kp = K if K % 128 == 0 or K % 32 != 0 or G % 32 != 0 or K % G != 0 else padded_in_features(K, G)
+    plan_describe(max(int(in_feats.shape[0]), 1), Kp, N, G)   # the reference's shape errors, before any repack
+    if Kp != K:                                              # in_features % 128 != 0: the padded copy, zero-padded activations
+        in_feats = torch.nn.functional.pad(in_feats, (0, Kp - K))
     out = gemm_forward(in_feats, *reference_to_mi355x_cached(kernel, scaling_factors, zeros))
     return out if split_k_iters > 1 else out.unsqueeze(0)
 

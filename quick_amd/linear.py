@@ -86,7 +86,7 @@ class WQLinear_QUICK(nn.Module):
 
     def prepare(self):
         """Permute reference-order buffers into MI355X order (HIP repack kernels on the GPU)."""
-        if self.is_prepared:
+        if self.is_prepared or self.in_features % 128 != 0:   # (K % 128 != 0: stays in reference order, see forward)
             return self
         if self.qweight.is_cuda:
             out = kernels.repack_cuda_to_mi355x(self.qweight.contiguous(), self.scales.contiguous(), self.qzeros.contiguous())
@@ -133,7 +133,7 @@ class WQLinear_QUICK(nn.Module):
         z = zeros.t().contiguous().to(torch.int32)
         if awq_linear.in_features % 128 == 0:
             awq_linear._set_packed(*packing.pack_mi355x(intweight, s, z), prepared=True)
-        else:   # representable in the checkpoint format only; forward() will refuse it
+        else:   # not tileable in the MI355X order: the buffers keep the checkpoint order, forward() runs on a padded copy
             awq_linear._set_packed(*packing.pack_cuda_order(intweight, s, z), prepared=False)
         return awq_linear
 
@@ -141,6 +141,14 @@ class WQLinear_QUICK(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         out_shape = x.shape[:-1] + (self.out_features,)
+        if self.in_features % 128 != 0:
+            # Accepted by the reference (in_features % 32 == 0), not tileable in the MI355X order: the buffers stay in the
+            # reference's order and the GEMM runs on a zero-padded MI355X-order copy (kernels.padded_in_features), cached
+            # like the function-level drop-in's.
+            out = kernels.gemm_forward_cuda_quick(x.reshape(-1, x.shape[-1]), self.qweight, self.scales, self.qzeros, 2)
+            if self.bias is not None:
+                out = out + self.bias
+            return out.reshape(out_shape)
         if not self.is_prepared:
             self.prepare()
         out = kernels.gemm_forward(x.reshape(-1, x.shape[-1]), self.qweight, self.scales, self.qzeros, bias=self.bias)

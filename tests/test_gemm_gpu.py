@@ -445,6 +445,35 @@ def test_function_level_drop_in_takes_reference_order_tensors(qa, device, path):
     assert key not in K_._REPACK_CACHE
 
 
+@pytest.mark.parametrize("M,K,N,G", [(1, 96, 128, 32), (7, 320, 256, 64), (40, 192, 128, 96), (130, 1056, 384, 32), (16, 4160, 512, 64)])
+def test_in_features_not_a_multiple_of_128(qa, device, M, K, N, G):
+    """Shapes the reference accepts (in_features % 32 == 0) and the MI355X weight order does not tile: the function-level
+    drop-in and the module both run them on a zero-padded copy (kernels.padded_in_features) -- against the oracle."""
+    import quick_kernels
+    from quick_amd import WQLinear_QUICK
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + K + N + G)
+    want = oracle.w4a16_forward(x, iw, s, z, G)
+    ref = [_dev(a, device) for a in oracle.pack_cuda_order(iw, s, z)]
+    y = quick_kernels.gemm_forward_cuda_quick(_dev(x, device), *ref, 8)
+    assert tuple(y.shape) == (M, N) and rel_err(y.cpu().numpy(), want) <= TOL
+    m = WQLinear_QUICK(4, G, K, N, True, device)
+    bias = torch.linspace(-1, 1, N, device=device).half()
+    m.load_state_dict({"qweight": ref[0], "scales": ref[1], "qzeros": ref[2], "bias": bias})
+    ym = m(_dev(x, device))
+    assert rel_err(ym.cpu().numpy(), want.astype(np.float32) + bias.cpu().numpy().astype(np.float32)) <= TOL
+    sd = m.state_dict()                                                 # still the reference's bits
+    assert all(torch.equal(sd[k], r) for k, r in zip(("qweight", "scales", "qzeros"), ref))
+    # the HIP repack kernel's padded flavour writes the bits of the torch packer on the padded logical tensors
+    from quick_amd import kernels as K_
+    hip = K_._padded_mi355x(*ref)
+    cpu = K_._padded_mi355x(*[t.cpu() for t in ref])
+    assert torch.equal(hip[0].cpu(), cpu[0]) and torch.equal(hip[1].cpu(), cpu[1])
+    # ... and the compiled extension takes the same path
+    from quick_amd.build_ext import build_quick_kernels_ext
+    ye = build_quick_kernels_ext().gemm_forward_cuda_quick(_dev(x, device), *ref, 8)
+    assert torch.equal(ye, y)
+
+
 def test_compiled_quick_kernels_extension(qa, device):
     """The pybind11 / torch-extension face of the same boundary (quick_amd/csrc/quick_kernels_ext.cpp, the shape of the
     reference's csrc/pybind.cpp): built in-tree by torch.utils.cpp_extension, called with reference-order tensors."""

@@ -81,8 +81,8 @@ def test_from_linear_k64_stays_in_checkpoint_format():
     m = _from_golden(g)
     assert not m.is_prepared
     assert np.array_equal(m.qweight.numpy(), g["ref_qweight"])
-    with pytest.raises(ValueError):
-        m.prepare()
+    assert m.prepare() is m and not m.is_prepared     # K = 64 is not tileable in the MI355X order: forward() runs on a padded copy
+    assert np.array_equal(m.qweight.numpy(), g["ref_qweight"])
 
 
 def test_fuse_qkv_unequal_widths_cpu():
@@ -193,6 +193,28 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "ksplit=4" in plan(64, 4096, 4096, kernel_id=kernels.KERNEL_TILED, grid_split_k=4)
     with pytest.raises(ValueError, match="cta_N"):
         plan(4, 4096, 4100)
+
+
+@pytest.mark.parametrize("K,N,G", [(96, 128, 32), (320, 256, 64), (192, 128, 96), (480, 128, 32)])
+def test_in_features_not_a_multiple_of_128_runs_on_a_zero_padded_copy(K, N, G):
+    """The reference takes in_features % 32 == 0 (csrc/gemm_cuda_quick.cu:1479-1484); the MI355X weight order needs 128-k tiles.
+    Such a layer (only possible with a group size that is not a multiple of 128) keeps its buffers in the checkpoint order and
+    computes on a copy padded along K with weights 0 / zero points 0 / scales 0: the copy dequantises to the layer's weights
+    followed by exact zeros."""
+    from quick_amd import kernels
+    x, iw, s, z = oracle.make_synthetic(3, K, N, G, seed=K + N + G)
+    ref = [torch.from_numpy(np.ascontiguousarray(a)) for a in oracle.pack_cuda_order(iw, s, z)]
+    Kp = kernels.padded_in_features(K, G)
+    assert Kp % 128 == 0 and Kp % G == 0 and Kp >= K and Kp - K < 128 * G // np.gcd(128, G)
+    packed = kernels._padded_mi355x(*ref)
+    assert packed[0].shape[0] * 4 == Kp
+    iwp, sp, zp = oracle.unpack_mi355x(*[t.numpy() for t in packed])
+    w = oracle.dequantize(iwp, sp, zp, G)
+    assert np.array_equal(w[:K], oracle.dequantize(iw, s, z, G)) and not w[K:].any()
+    m = WQLinear_QUICK(4, G, K, N, False, "cpu")
+    m.load_state_dict({"qweight": ref[0], "scales": ref[1], "qzeros": ref[2]})
+    assert m.prepare() is m and not m.is_prepared                      # stays in the reference's order
+    assert all(torch.equal(a, b) for a, b in zip((m.qweight, m.scales, m.qzeros), ref))
 
 
 def test_quick_kernels_shim_exports_reference_symbol():
