@@ -107,9 +107,6 @@ __host__ __device__ __forceinline__ size_t group_word_index(int g, int n, int NG
   return ((size_t)(n >> 4) * NG + g) * 16 + (n & 15);
 }
 
-// kept for the call sites' sake: nothing lane-dependent is needed to pick a lane's constants any more
-struct LaneSel {};
-__device__ __forceinline__ LaneSel lane_sel(int) { return LaneSel{}; }
 
 // group index of k-step t of 128-k tile kt.  GM: 0 -> G == 128, 1 -> G % 128 == 0 (tpg = G / 128),
 // 2 -> G == 64, 3 -> G == 32, 4 -> any other multiple of 32 (runtime division).
@@ -135,7 +132,7 @@ __device__ __forceinline__ GroupRaw load_group_raw(const half_t* __restrict__ S,
 __device__ __forceinline__ float group_scale_f32(const GroupRaw& r) { return (float)as_h2(r.sz)[0]; }
 __device__ __forceinline__ float group_zero_f32(const GroupRaw& r) { return (float)(r.sz >> 16); }
 // 4 VALU: v_perm (scale pair), v_lshrrev + v_lshl_or (zero point twice), 2 v_or (bias constants) -- minus what hipcc folds
-__device__ __forceinline__ GroupQ make_group(const GroupRaw& r, const LaneSel&) {
+__device__ __forceinline__ GroupQ make_group(const GroupRaw& r) {
   GroupQ g;
   g.s2 = as_h2(__builtin_amdgcn_perm(r.sz, r.sz, 0x01000100u));
   const uint32_t z = r.sz >> 16;

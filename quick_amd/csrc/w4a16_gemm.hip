@@ -182,7 +182,7 @@ __device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS, LN>& c
 
 template <int NTW, int GM, int U, bool XLDS>
 __device__ __forceinline__ void skinny_compute(const SkinnyChunk<NTW, GM, U, XLDS>& c, int kt, int kt_end, const char* xl,
-                                               const LaneSel& ls, floatx4 (&acc)[NTW]) {
+                                               floatx4 (&acc)[NTW]) {
   constexpr int NG = groups_per_tile<GM>();
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -191,7 +191,7 @@ __device__ __forceinline__ void skinny_compute(const SkinnyChunk<NTW, GM, U, XLD
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
-        for (int i = 0; i < NG; ++i) grp[j][i] = make_group(c.raw[u][j][i], ls);  // n and n + 16 j select alike
+        for (int i = 0; i < NG; ++i) grp[j][i] = make_group(c.raw[u][j][i]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         half8_t bf;
@@ -230,7 +230,7 @@ __device__ __forceinline__ void skinny_compute(const SkinnyChunk<NTW, GM, U, XLD
 // (2^-11 relative per weight) -- see DESIGN.md for the bound and tests/test_gemm_gpu.py for the comparison.
 template <int NTW, int GM, int U>
 __device__ __forceinline__ void skinny_compute_dz(const SkinnyChunk<NTW, GM, U, true>& c, int kt, int kt_end,
-                                                  const char* xl, const float* tab, const LaneSel& ls,
+                                                  const char* xl, const float* tab,
                                                   floatx4 (&acc)[NTW]) {
   constexpr int NG = groups_per_tile<GM>();  // units per 128-k tile
   constexpr int TPU = 4 / NG;                // k-steps per unit
@@ -280,7 +280,7 @@ __device__ __forceinline__ void skinny_compute_dz(const SkinnyChunk<NTW, GM, U, 
 // fp32 result in skinny_finish: gemm(x * w) * rstd instead of gemm(fp16(fp16(x * rstd) * w)).
 template <int NTW, int GM, int U, bool LN = false>
 __device__ __forceinline__ void skinny_compute_dzf(const SkinnyChunk<NTW, GM, U, false, LN>& c, int kt, int kt_end,
-                                                   const LaneSel& ls, half8_t bconst, bool odd, floatx4 (&acc)[NTW],
+                                                   half8_t bconst, bool odd, floatx4 (&acc)[NTW],
                                                    float* ssq = nullptr) {
   constexpr int NG = groups_per_tile<GM>();  // units per 128-k tile
   constexpr int TPU = 4 / NG;                // k-steps per unit
@@ -501,7 +501,6 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   const int cnt = wg_end - wg_begin;
   const int kt_begin = wg_begin + cnt * wave / WAVES, kt_end = wg_begin + cnt * (wave + 1) / WAVES;
   const int kt_last = max(kt_end - 1, kt_begin);  // clamp for replayed loads (a wave may own no k-tile at all)
-  const LaneSel ls = lane_sel(n16);               // channel n = 16 * tile + n16: n % 8 and n % 2 are those of n16
 
   const SkinnyBufs bufs = skinny_bufs(a, lane);
   const int row = min(mb * 16 + n16, a.M - 1);  // rows >= M replay row M-1; never stored
@@ -527,8 +526,8 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     }                                                                                                              \
   } while (0)
 #define QA_SKINNY_COMPUTE(ccomp)                                                                                   \
-  if constexpr (DZ && XLDS) skinny_compute_dz<NTW, GM, U>(ccomp, kt_cur, kt_end, xl, tab, ls, acc);                \
-  else if constexpr (!DZ) skinny_compute<NTW, GM, U, XLDS>(ccomp, kt_cur, kt_end, xl, ls, acc);                    \
+  if constexpr (DZ && XLDS) skinny_compute_dz<NTW, GM, U>(ccomp, kt_cur, kt_end, xl, tab, acc);                    \
+  else if constexpr (!DZ) skinny_compute<NTW, GM, U, XLDS>(ccomp, kt_cur, kt_end, xl, acc);                        \
   if (kt_cur + U >= kt_end) {                                                                                      \
     skinny_finish<NTW, WAVES, DZ>(a, acc, red + parity * (WAVES * NTW * 64), smem, nb_cur, nblocks, mb, ks, lane,  \
                                   wave);                                                                           \
@@ -561,13 +560,13 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
       if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS, LN>(cB, kt + U, kt_end - 1, bufs, cb, xp, a, gp);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DZ) skinny_compute_dzf<NTW, GM, U, LN>(cA, kt, kt_end, ls, bconst, (lane & 1) != 0, acc, &ssq);
-      else skinny_compute<NTW, GM, U, XLDS>(cA, kt, kt_end, nullptr, ls, acc);
+      if constexpr (DZ) skinny_compute_dzf<NTW, GM, U, LN>(cA, kt, kt_end, bconst, (lane & 1) != 0, acc, &ssq);
+      else skinny_compute<NTW, GM, U, XLDS>(cA, kt, kt_end, nullptr, acc);
       if (kt + U >= kt_end) break;
       if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS, LN>(cA, kt + 2 * U, kt_end - 1, bufs, cb, xp, a, gp);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DZ) skinny_compute_dzf<NTW, GM, U, LN>(cB, kt + U, kt_end, ls, bconst, (lane & 1) != 0, acc, &ssq);
-      else skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, ls, acc);
+      if constexpr (DZ) skinny_compute_dzf<NTW, GM, U, LN>(cB, kt + U, kt_end, bconst, (lane & 1) != 0, acc, &ssq);
+      else skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, acc);
     }
     skinny_finish<NTW, WAVES, DZ, LN>(a, acc, red, smem, bx, nblocks, mb, ks, lane, wave, ssq);
     if constexpr (SPAN) span_stamp(a.span, 1);
@@ -701,8 +700,7 @@ __device__ __forceinline__ void tiled_store_x(const TiledCtx<BMT, TN, WK, WN>& c
 // weights + raw group constants of this wave's k-tile of stage s (no dependent ALU: see GroupRaw)
 template <int BMT, int TN, int WK, int GM, int WN>
 __device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN, WK, WN>& c, const GemmArgs& a, int s, u32x4 (&w)[TN],
-                                             uint32_t (&gs)[TN][groups_per_tile<GM>()],
-                                             uint32_t (&gz)[TN][groups_per_tile<GM>()]) {
+                                             uint32_t (&gs)[TN][groups_per_tile<GM>()]) {
   constexpr int NG = groups_per_tile<GM>();
   const int kt = min(c.kt_lo + WK * s + c.wk, c.kt_hi - 1);
 #pragma unroll
@@ -712,8 +710,7 @@ __device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN, WK, WN>& c,
     for (int i = 0; i < NG; ++i) {
       const int g = group_index<GM>(kt, i * (4 / NG), a.tpg, a.G);
       const GroupRaw r = load_group_raw(a.S, a.QZ, g, c.ncol[j], a.N, a.K / a.G);
-      gs[j][i] = r.sz;
-      gz[j][i] = 0;  // (the zero point travels in the same word; the second array is kept for the call sites and folds away)
+      gs[j][i] = r.sz;  // (the zero point travels in the same word)
     }
   }
 }
@@ -723,7 +720,6 @@ __device__ __forceinline__ void tiled_load_w(const TiledCtx<BMT, TN, WK, WN>& c,
 template <int BMT, int TN, int WK, int GM, int ABL, int WN>
 __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK, WN>& c, const char* sb, int s, const u32x4 (&w)[TN],
                                               const uint32_t (&gs)[TN][groups_per_tile<GM>()],
-                                              const uint32_t (&gz)[TN][groups_per_tile<GM>()],
                                               floatx4 (&acc)[TN][BMT]) {
   constexpr int NG = groups_per_tile<GM>();
   if (c.kt_lo + WK * s + c.wk >= c.kt_hi) {  // wave-uniform: a ragged last stage has no tile for this wave
@@ -739,7 +735,7 @@ __device__ __forceinline__ void tiled_compute(const TiledCtx<BMT, TN, WK, WN>& c
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < NG; ++i) grp[j][i] = make_group(GroupRaw{gs[j][i]}, lane_sel(c.ncol[j]));
+    for (int i = 0; i < NG; ++i) grp[j][i] = make_group(GroupRaw{gs[j][i]});
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     half8_t bf[BMT];
@@ -836,7 +832,7 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArg
   }
   u32x4 xr[XPW];
   u32x4 w[2][TN];
-  uint32_t gs[2][TN][NG], gz[2][TN][NG];
+  uint32_t gs[2][TN][NG];
   const int rd = wk * (4 * BMT * 1024) + lane * 16;  // this wave reads its k-tile's part of a stage
 
   if (nstage > 0) {
@@ -846,13 +842,13 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArg
     // s_waitcnt vmcnt(7..4) into vmcnt(3..0) -- a full drain of the weight prefetch once per stage [r01: -4 %].
     tiled_load_x<BMT, TN, WK, WN>(c, 0, xr);
     __builtin_amdgcn_sched_barrier(0);
-    tiled_load_w<BMT, TN, WK, GM, WN>(c, a, 0, w[0], gs[0], gz[0]);
+    tiled_load_w<BMT, TN, WK, GM, WN>(c, a, 0, w[0], gs[0]);
     __builtin_amdgcn_sched_barrier(0);
     tiled_store_x<BMT, TN, WK, WN>(c, smem, lane, xr);
     __builtin_amdgcn_sched_barrier(0);
     tiled_load_x<BMT, TN, WK, WN>(c, 1, xr);
     __builtin_amdgcn_sched_barrier(0);
-    tiled_load_w<BMT, TN, WK, GM, WN>(c, a, 1, w[1], gs[1], gz[1]);
+    tiled_load_w<BMT, TN, WK, GM, WN>(c, a, 1, w[1], gs[1]);
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
@@ -878,9 +874,9 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArg
       QA_STAMP(0)
       if constexpr (!(ABL & 1)) tiled_load_x<BMT, TN, WK, WN>(c, s + 2, xr);
       QA_STAMP(1)
-      tiled_compute<BMT, TN, WK, GM, ABL, WN>(c, cur + rd, s, w[u], gs[u], gz[u], acc);
+      tiled_compute<BMT, TN, WK, GM, ABL, WN>(c, cur + rd, s, w[u], gs[u], acc);
       QA_STAMP(2)
-      if constexpr (!(ABL & 1)) tiled_load_w<BMT, TN, WK, GM, WN>(c, a, s + 2, w[u], gs[u], gz[u]);
+      if constexpr (!(ABL & 1)) tiled_load_w<BMT, TN, WK, GM, WN>(c, a, s + 2, w[u], gs[u]);
       QA_STAMP(3)
       if constexpr (!(ABL & 8)) __syncthreads();
       QA_STAMP(4)
@@ -1019,7 +1015,6 @@ __device__ __forceinline__ void tiled32_store_x(const TiledCtx<BMT, TN, WK>& c, 
 template <int BMT, int TN, int WK, int GM>
 __device__ __forceinline__ void tiled32_compute(const TiledCtx<BMT, TN, WK>& c, const char* sb, int s, const u32x4 (&w)[TN],
                                                 const uint32_t (&gs)[TN][groups_per_tile<GM>()],
-                                                const uint32_t (&gz)[TN][groups_per_tile<GM>()],
                                                 floatx16 (&acc)[TN / 2][BMT / 2], int lane) {
   constexpr int NG = groups_per_tile<GM>();
   if (c.kt_lo + WK * s + c.wk >= c.kt_hi) {  // wave-uniform: a ragged last stage has no tile for this wave
@@ -1039,7 +1034,7 @@ __device__ __forceinline__ void tiled32_compute(const TiledCtx<BMT, TN, WK>& c, 
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
       const GroupRaw r{second ? gs[2 * p + 1][i] : gs[2 * p][i]};
-      grp[p][i] = make_group(r, lane_sel(c.ncol[2 * p]));  // n%8 and n%2 are the same for both tiles of a pair
+      grp[p][i] = make_group(r);
     }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -1125,13 +1120,13 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled32_kernel(const GemmArgs 
 
   u32x4 xr[BMT];
   u32x4 w[2][TN];
-  uint32_t gs[2][TN][NG], gz[2][TN][NG];
+  uint32_t gs[2][TN][NG];
   const int rd = wk * (4 * BMT * 1024) + lane * 16;
 
   if (nstage > 0) {
-    tiled_load_w<BMT, TN, WK, GM, 4>(c, a, 0, w[0], gs[0], gz[0]);
+    tiled_load_w<BMT, TN, WK, GM, 4>(c, a, 0, w[0], gs[0]);
     tiled_load_x<BMT, TN, WK, 4>(c, 0, xr);
-    tiled_load_w<BMT, TN, WK, GM, 4>(c, a, 1, w[1], gs[1], gz[1]);
+    tiled_load_w<BMT, TN, WK, GM, 4>(c, a, 1, w[1], gs[1]);
     tiled32_store_x<BMT, TN, WK>(c, smem, lane, xr);
     tiled_load_x<BMT, TN, WK, 4>(c, 1, xr);
   }
@@ -1146,8 +1141,8 @@ __global__ __launch_bounds__(256 * WK) void w4a16_tiled32_kernel(const GemmArgs 
       char* const nxt = smem + (u ^ 1) * STAGE_BYTES;
       tiled32_store_x<BMT, TN, WK>(c, nxt, lane, xr);
       tiled_load_x<BMT, TN, WK, 4>(c, s + 2, xr);
-      tiled32_compute<BMT, TN, WK, GM>(c, cur + rd, s, w[u], gs[u], gz[u], acc, lane);
-      tiled_load_w<BMT, TN, WK, GM, 4>(c, a, s + 2, w[u], gs[u], gz[u]);
+      tiled32_compute<BMT, TN, WK, GM>(c, cur + rd, s, w[u], gs[u], acc, lane);
+      tiled_load_w<BMT, TN, WK, GM, 4>(c, a, s + 2, w[u], gs[u]);
       __syncthreads();
     }
   }
@@ -1262,7 +1257,7 @@ __global__ __launch_bounds__(64) void w4a16_dequant_kernel(const u32x4* __restri
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int k0 = kt * 128 + 32 * t + 8 * q;
-    const GroupQ g = make_group(load_group_raw(S, QZ, k0 / G, n, N, K / G), lane_sel(n));
+    const GroupQ g = make_group(load_group_raw(S, QZ, k0 / G, n, N, K / G));
     const half8_t af = dequant8(w[t], g);
 #pragma unroll
     for (int j = 0; j < 8; ++j) W[(size_t)(k0 + j) * N + n] = af[j];

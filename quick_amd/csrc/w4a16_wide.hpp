@@ -166,7 +166,7 @@ __device__ __forceinline__ void wide_prepare(WideCarry<MB, PAIRS, GM>& c, const 
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p)
 #pragma unroll
-    for (int i = 0; i < NG; ++i) c.grp[p][i] = make_group(GroupRaw{w.sz[p][i]}, LaneSel{});
+    for (int i = 0; i < NG; ++i) c.grp[p][i] = make_group(GroupRaw{w.sz[p][i]});
   c.af = wide_frag<PAIRS, GM, WK>(w, c.grp, 0, dq);
   if constexpr (PRE_B) {
 #pragma unroll
@@ -228,7 +228,7 @@ __device__ __forceinline__ void wide_compute(const WideW<PAIRS, GM>& w, const Wi
 #pragma unroll
       for (int pp = 0; pp < PAIRS; ++pp)
 #pragma unroll
-        for (int i = 0; i < NG; ++i) carry.grp[pp][i] = make_group(GroupRaw{wnext.sz[pp][i]}, LaneSel{});
+        for (int i = 0; i < NG; ++i) carry.grp[pp][i] = make_group(GroupRaw{wnext.sz[pp][i]});
       carry.af = wide_frag<PAIRS, GM, WK>(wnext, carry.grp, 0, dq);
     }
 #pragma unroll
