@@ -1574,7 +1574,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
         // k-tiles a wave still has to compute after its last load lands.  M = 1, one session [r02]: 11008 x 4096 8.08 -> 7.12 us,
         // 14336 x 4096 8.80 -> 8.44, 28672 x 8192 25.0 -> 23.4 (M = 2: 8.92 -> 7.64); nothing at K = 4096 (4096 x 12288 7.40 ->
         // 7.36), and slower wherever two 8-wave workgroups share a CU (4096 x 22016 10.4 -> 13.0, 8192 x 8192 8.9 -> 11.6).
-        if (!waves_req && p.waves == 8 && p.grid_x <= 256 && p.kt_per_split >= 64 &&
+        // (G = 32: four units per k-tile, 1 x 11008 x 4096 15.1 us with 16 waves against 9.3 -- not there)
+        if (!waves_req && p.waves == 8 && G >= 64 && p.grid_x <= 256 && p.kt_per_split >= 64 &&
             skinny_lds_bytes(M, G, 1, 16, p.kt_per_split, true, true, true) <= kLdsPerCu)
           p.waves = 16;
       }

@@ -179,6 +179,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "ring=0" in plan(512, 4096, 4096, kernel_id=W | (2 << 4) | (1 << 8) | (1 << 12))           # double-buffered instead
     # r02 planner audit (profiles/r02_planner_audit_*.jsonl): the rules it added
     assert "waves=16" in plan(1, 11008, 4096) and "waves=8" in plan(1, 4096, 4096) and "waves=8" in plan(1, 4096, 22016)   # long K, one workgroup per CU
+    assert "waves=16" in plan(1, 11008, 4096, G=64) and "waves=8" in plan(1, 11008, 4096, G=32)                            # (not with four units per k-tile)
     assert plan(16, 4096, 6144).startswith("skinny ntw=2") and "deferred-zero-fragment" in plan(16, 4096, 6144)    # 384 blocks: one round of 192
     assert plan(6, 8192, 8192).startswith("skinny ntw=2") and plan(4, 28672, 8192).startswith("skinny ntw=4")
     assert "deferred-zero-table" in plan(12, 4096, 22016) and plan(16, 4096, 22016).startswith("skinny ntw=4")
