@@ -1357,7 +1357,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   const int tiled_tiles = (N / 128) * ((M + 63) / 64);
   // [r02 audit, profiles/r02_planner_audit_*.jsonl] 48 tiles are enough (4096 x 6144, M = 24..64: 10.4-12.8 against the skinny
   // kernel's 11.4-14.2 us); and the long-K rule starts at M = 33 from K = 12288 (48 x 14336 x 4096: 22.2 -> 19.2)
-  const bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= 48) || (M > 56 && K >= 10240) || (M > 32 && K >= 12288);
+  // (the 48-tile rule with G % 128 == 0 only: at G = 64 / 32 the four-tile exact skinny kernel is ahead there, 32 x 4096 x 6144 9.4 /
+  // 10.0 against 11.1 / 11.5 us)
+  const bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= (G % 128 == 0 ? 48 : 64)) || (M > 56 && K >= 10240) || (M > 32 && K >= 12288);
   p.kernel = family == QUICK_KERNEL_AUTO ? (want_tiled ? QUICK_KERNEL_TILED : QUICK_KERNEL_SKINNY) : family;
   // Wide kernels (32x32x16 MFMA, one wave per SIMD, LDS-DMA) from 256 tokens, and from 64 tokens once there are enough
   // 64 x 128 tiles to cover the chip (large N): 13 % ahead of the r01 kernels on average over 45 (M, K, N) shapes between
