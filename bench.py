@@ -39,6 +39,27 @@ def log(*a):
 
 
 
+def algorithmic_bytes(M, K, N, G):
+    """int4 weights + fp16 scales + int4 zero points (both un-duplicated) + x + y."""
+    return K * N // 2 + (K // G) * N * 2 + (K // G) * N // 2 + 2 * M * K + 2 * M * N
+
+
+def algorithmic_flops(M, K, N):
+    return 2 * M * K * N
+
+
+def synthetic_layer(M, K, N, G, seed=0):
+    """SURVEY.md 8(d) synthetic inputs: integer weights and zero points ~ U{0..15}, scales ~ U(0.005, 0.025) fp16, x ~ N(0, 1)
+    fp16 -> (x [M, K], iw [K, N] uint8, s [K/G, N] fp16, z [K/G, N] uint8)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    iw = rng.integers(0, 16, size=(K, N), dtype=np.uint8)
+    z = rng.integers(0, 16, size=(K // G, N), dtype=np.uint8)
+    s = rng.uniform(0.005, 0.025, size=(K // G, N)).astype(np.float16)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    return x, iw, s, z
+
+
 def pmc_traffic(M, K, N, G, kernel, plan):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 counter pass for this shape
     (profiles/rNN_pmc_m<M>_*.txt, written by tools/prof_passes.sh on K=N=4096, g=128): counters need their own rocprofv3
@@ -141,9 +162,9 @@ def main():
     set_bytes = K * N // 2 + (K // G) * 2 * N * 2 + (K // G) * (N // 4) * 4
     n_sets = args.sets or max(2, -(-(320 << 20) // set_bytes))
 
-    # ---- synthetic data: set 0 from logical tensors (shared with the CPU baseline), the rest raw bits
-    import oracle
-    x_np, iw, s, z = oracle.make_synthetic(max(Ms), K, N, G, seed=0)
+    # ---- synthetic data: set 0 from logical tensors (shared with the CPU baseline), the rest raw bits.
+    # (Made here, not by oracle/: the oracle is the checker of the cpu_baseline leg below and of the tests, nothing the GPU legs use.)
+    x_np, iw, s, z = synthetic_layer(max(Ms), K, N, G, seed=0)
     x_full = torch.from_numpy(x_np).to(dev)
     sets = [tuple(t.contiguous() for t in packing.pack_mi355x(torch.from_numpy(iw).to(dev), torch.from_numpy(s).to(dev),
                                                               torch.from_numpy(z.astype(np.int32)).to(dev)))]
@@ -227,7 +248,7 @@ def main():
                                        M, K, N, G, args.kernel, args.split_k, nspan, sus, stream.cuda_stream)
         k_us_span = float(np.median(np.asarray(sus[:])[min(5, nspan - 1):])) if rc == 0 else None
 
-        flops, nbytes = oracle.algorithmic_flops(M, K, N), oracle.algorithmic_bytes(M, K, N, G)
+        flops, nbytes = algorithmic_flops(M, K, N), algorithmic_bytes(M, K, N, G)
         ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
         if flops / nbytes < ridge:
             roof = {"bound": "hbm", "achieved": nbytes / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
@@ -307,7 +328,7 @@ def main():
             rc = lib.quick_w4a16_gemm_span(xl.data_ptr(), larr(0), larr(1), larr(2), ns, yl.data_ptr(), wsl.data_ptr(), wsb,
                                            Ml, Kl, Nl, G, args.kernel, 0, 40, kus, stream.cuda_stream)
             s_us = float(np.median(np.asarray(kus[:40])[5:])) if rc == 0 else None
-            nb = oracle.algorithmic_bytes(Ml, Kl, Nl, G)
+            nb = algorithmic_bytes(Ml, Kl, Nl, G)
             ach = nb / (k_us * 1e-6) / 1e9
             out["decode_layers"].append({"M": Ml, "K": Kl, "N": Nl, "kernel_us": k_us, "weight_sets_cycled": ns,
                                          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -356,7 +377,7 @@ def main():
         reps, total = len(times), sum(times)
         dt = float(np.median(times))
         out["cpu_baseline"] = {
-            "value": oracle.algorithmic_flops(args.M, K, n_cpu) / dt / 1e12, "unit": "TFLOP/s", "cores": cores,
+            "value": algorithmic_flops(args.M, K, n_cpu) / dt / 1e12, "unit": "TFLOP/s", "cores": cores,
             "kind": "port", "ms_per_call": dt * 1e3, "calls": reps, "ms_per_call_min_max": [min(times) * 1e3, max(times) * 1e3],
             "sample": f"{reps} call(s) of the reference CPU path (dequantize_gemm + torch.matmul, dequant redone per call, "
                       f"oracle/cpu_path.py) on output channels 0..{n_cpu - 1} of the M={args.M} K={K} N={N} g={G} layer, "
