@@ -1844,7 +1844,8 @@ static void launch_wide(const Plan& p, const GemmArgs& a, const Launch& L) {
     if (p.ablate && a.G == 128) {  // timing experiments (results are wrong on purpose)
       auto kfn1 = w4a16_wide_kernel<MB, PAIRS, 0, 1>;
       auto kfn2 = w4a16_wide_kernel<MB, PAIRS, 0, 2>;
-      auto kfn = p.ablate == 1 ? kfn1 : kfn2;
+      auto kfn64 = w4a16_wide_kernel<MB, PAIRS, 0, 64>;  // phase stamps into the workspace, nothing else changes
+      auto kfn = p.ablate == 1 ? kfn1 : (p.ablate == 16 ? kfn64 : kfn2);
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
       return;

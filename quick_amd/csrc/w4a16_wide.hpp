@@ -270,13 +270,100 @@ __device__ __forceinline__ WideTile wide_tile(const GemmArgs& a) {
   return t;
 }
 
+template <int MB, int PAIRS>
+__device__ __forceinline__ void wide_zero(floatx16 (&acc)[PAIRS][MB]) {
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+    for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][mt][r] = 0.f;
+}
+
+// The tile's way out: accumulators (+ bias, or SiLU(gate) * up) -> f16 image of the tile in LDS -> whole rows to y (+ residual).
+// Image: row m of the tile, 16-byte chunk q (8 channels) at byte (m * CPR + (q ^ (m % 8))) * 16 -- a lane group of the
+// ds_write_b64 is 16 rows of one chunk column, the XOR spreads them over the eight chunks of a 128-byte bank row (2-way
+// instead of 16-way); the read-back of a wave covers 64 / CPR rows that share m % 8, so the XOR is one constant for it.
+// The residual is added to the ROUNDED product, which is what the unfused sequence (GEMM, then y + residual) computes.
+// SiLU * mul: gate / up interleaved by 8 channels (c = 0, 2 gate of the two 16-channel tiles, c = 1, 3 their up), the
+// image and y have half the channels.  All 4 * WK waves store; waves with active == false hold no accumulators.
+template <int MB, int PAIRS, int WK, bool SILU>
+__device__ __forceinline__ void wide_store_tile(const GemmArgs& a, const WideTile& t, floatx16 (&acc)[PAIRS][MB], char* smem, int lane,
+                                                int wave, bool active) {
+  constexpr int CPR = SILU ? PAIRS * 8 : PAIRS * 16;  // 16-byte chunks per tile row
+  constexpr int R = 64 / CPR;                         // rows per wave-instruction of the read-back
+  constexpr int ROWS = MB * 32, NWV = 4 * WK, NIT = ROWS / R / NWV;
+  static_assert(ROWS % (8 * R) == 0 && ROWS % (R * NWV) == 0, "tile rows vs the read-back pattern");
+  const int rho = lane & 31, h = lane >> 5;
+  if (active) {
+    const unsigned r7 = (unsigned)rho & 7u;
+    char* wrow = smem + rho * (CPR * 16) + h * 8;
+    const unsigned q0 = (unsigned)wave * (SILU ? PAIRS * 2 : PAIRS * 4);
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; c += SILU ? 2 : 1) {
+        const unsigned q = q0 + (SILU ? p * 2 + c / 2 : p * 4 + c);
+        char* wp = wrow + ((q ^ r7) << 4);
+        half4_t bv = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        if constexpr (!SILU)
+          if (a.bias) bv = *(const half4_t*)(a.bias + (t.nb * 4 + wave) * PAIRS * 32 + 32 * p + 8 * c + 4 * h);
+#pragma unroll
+        for (int mt = 0; mt < MB; ++mt) {
+          half4_t o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (SILU) o[r] = silu_mul_f16((half_t)acc[p][mt][4 * c + r], (half_t)acc[p][mt][4 * c + 4 + r]);
+            else o[r] = (half_t)(acc[p][mt][4 * c + r] + (float)bv[r]);
+          }
+          *(half4_t*)(wp + mt * 32 * (CPR * 16)) = o;
+        }
+      }
+  }
+  __syncthreads();
+  const int wv = uniform((int)(threadIdx.x >> 6));
+  const int ldy = SILU ? a.N >> 1 : a.N;
+  const int q = lane % CPR, k = lane / CPR;
+  half_t* ycol = a.Y + (SILU ? t.nb * PAIRS * 64 : t.nb * PAIRS * 128) + q * 8;
+  const half_t* rcol = (!SILU && a.residual) ? a.residual + t.nb * PAIRS * 128 + q * 8 : nullptr;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int base = it * NWV + wv;
+    const int row = (base >> 3) * (8 * R) + (base & 7) + 8 * k;
+    half8_t v = *(const half8_t*)(smem + (row * CPR + (q ^ (base & 7))) * 16);
+    const int m = t.m0 + row;
+    if (m < a.M) {
+      if (rcol) {
+        const half8_t res = *(const half8_t*)(rcol + (size_t)m * a.N);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = (half_t)((float)v[r] + (float)res[r]);
+      }
+      *(half8_t*)(ycol + (size_t)m * ldy) = v;
+    }
+  }
+}
+
 // K split across workgroups (slab = [(p, mt, c)][wave][lane] floatx4) and the fused epilogue.
 // `wave` = the wave's index along N (0..3); waves with active == false (the second K half of an eight-wave workgroup, whose
 // partial was already added in) only take part in the workgroup barriers.
-template <int MB, int PAIRS>
+template <int MB, int PAIRS, int WK>
+__device__ __forceinline__ void wide_epilogue(const GemmArgs& a, const WideTile& t, floatx16 (&acc)[PAIRS][MB], char* smem, int lane, int wave,
+                                              bool active) {
+  // The accumulators hold token rho, channels 8 c + 4 h .. + 3 per lane: stored from here, a wave's store instruction
+  // touches 32 rows x 16 bytes.  So the tile goes through LDS (free now) and leaves in whole rows, 16 bytes per lane.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (ring kernels: the replayed LDS-DMA of the last stages has landed)
+  __builtin_amdgcn_s_barrier();                     // everybody is done with the ring / the split-K flag
+  if (a.silu_mul) wide_store_tile<MB, PAIRS, WK, true>(a, t, acc, smem, lane, wave, active);
+  else wide_store_tile<MB, PAIRS, WK, false>(a, t, acc, smem, lane, wave, active);
+}
+
+template <int MB, int PAIRS, int WK = 1>
 __device__ __forceinline__ void wide_finish(const GemmArgs& a, const WideTile& t, floatx16 (&acc)[PAIRS][MB], char* smem, int ct0,
                                             int lane, int wave, bool active = true) {
-  const int rho = lane & 31, h = lane >> 5;
+  // Two separate ways out on purpose.  With one epilogue behind "if (ksplit > 1) acc = sum of the slabs", the accumulators
+  // that arrive from the K loop (AGPRs) and the sums (VGPRs) meet in one set of registers, and hipcc makes that set the
+  // scratch memory: 52 scratch_store_dwordx4 + 52 loads per lane on the path that splits nothing -- 14-16 us per 256 x 256
+  // tile, 20-30 us of the 133 us 4096^3 launch [r02, tools/wide_phases.py].
   if (a.ksplit > 1) {
     constexpr unsigned SLAB_BYTES = PAIRS * MB * 16384;
     const __amdgpu_buffer_rsrc_t rs = slab_rsrc(a.slabs + (size_t)blockIdx.x * a.ksplit * (SLAB_BYTES / 4), a.ksplit * SLAB_BYTES);
@@ -292,10 +379,11 @@ __device__ __forceinline__ void wide_finish(const GemmArgs& a, const WideTile& t
                        floatx4{acc[p][mt][4 * c], acc[p][mt][4 * c + 1], acc[p][mt][4 * c + 2], acc[p][mt][4 * c + 3]});
     }
     if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
-    if (!active) return;
     // every slice is read back from its slab (the own one too) and added in index order: the sum does not depend on
-    // who arrived last, and no second copy of the accumulators is needed
-    for (int o = 0; o < a.ksplit; ++o) {
+    // who arrived last
+    floatx16 sum[PAIRS][MB];
+    wide_zero<MB, PAIRS>(sum);
+    for (int o = 0; active && o < a.ksplit; ++o) {
 #pragma unroll
       for (int p = 0; p < PAIRS; ++p)
 #pragma unroll
@@ -304,62 +392,13 @@ __device__ __forceinline__ void wide_finish(const GemmArgs& a, const WideTile& t
           for (int c = 0; c < 4; ++c) {
             const floatx4 part = slab_load(rs, o * SLAB_BYTES + ((p * MB + mt) * 4 + c) * 4096 + my);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[p][mt][4 * c + r] = o == 0 ? part[r] : acc[p][mt][4 * c + r] + part[r];
+            for (int r = 0; r < 4; ++r) sum[p][mt][4 * c + r] += part[r];
           }
     }
-  }
-
-  if (!active) return;
-  // lane = token m0 + 32 mt + rho, channels ch0 + 32 p + 8 c + 4 h .. + 3 (c = r / 4)
-  const int ch0 = ct0 * 16;
-  if (a.silu_mul) {  // gate / up interleaved by 8: c = 0, 2 gate of the two 16-channel tiles, c = 1, 3 their up
-#pragma unroll
-    for (int p = 0; p < PAIRS; ++p)
-#pragma unroll
-      for (int mt = 0; mt < MB; ++mt) {
-        const int m = t.m0 + mt * 32 + rho;
-        if (m < a.M) {
-#pragma unroll
-          for (int c = 0; c < 4; c += 2) {
-            half4_t o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = silu_mul_f16((half_t)acc[p][mt][4 * c + r], (half_t)acc[p][mt][4 * c + 4 + r]);
-            *(half4_t*)(a.Y + (size_t)m * (a.N >> 1) + ((ch0 + 32 * p) >> 1) + 4 * c + 4 * h) = o;
-          }
-        }
-      }
+    wide_epilogue<MB, PAIRS, WK>(a, t, sum, smem, lane, wave, active);
     return;
   }
-#pragma unroll
-  for (int p = 0; p < PAIRS; ++p)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int nc = ch0 + 32 * p + 8 * c + 4 * h;
-      half4_t bv = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-      if (a.bias) bv = *(const half4_t*)(a.bias + nc);
-#pragma unroll
-      for (int mt = 0; mt < MB; ++mt) {
-        const int m = t.m0 + mt * 32 + rho;
-        if (m < a.M) {
-          half4_t res = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-          if (a.residual) res = *(const half4_t*)(a.residual + (size_t)m * a.N + nc);
-          half4_t o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[p][mt][4 * c + r] + (float)bv[r] + (float)res[r]);
-          *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
-        }
-      }
-    }
-}
-
-template <int MB, int PAIRS>
-__device__ __forceinline__ void wide_zero(floatx16 (&acc)[PAIRS][MB]) {
-#pragma unroll
-  for (int p = 0; p < PAIRS; ++p)
-#pragma unroll
-    for (int mt = 0; mt < MB; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[p][mt][r] = 0.f;
+  wide_epilogue<MB, PAIRS, WK>(a, t, acc, smem, lane, wave, active);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -390,6 +429,8 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
   constexpr int XI = MB * 2, NU = 8 * PAIRS;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE_BYTES
 
+  unsigned long long ph[5];  // ABL bit 64: s_memrealtime stamps (100 MHz) at the phase boundaries, per wave, into a.dbg
+  if constexpr (ABL & 64) ph[0] = __builtin_amdgcn_s_memrealtime();
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
   const int rho = lane & 31, h = lane >> 5;
@@ -419,6 +460,7 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
   __builtin_amdgcn_s_barrier();
   WideCarry<MB, PAIRS, GM> carry;
   wide_prepare<MB, PAIRS, GM, false>(carry, wc, 0u, dq);
+  if constexpr (ABL & 64) ph[1] = __builtin_amdgcn_s_memrealtime();
 
   for (int s = 0; s < t.nstage; ++s) {
     const int ktn = min(t.kt_lo + s + 1, t.kt_hi - 1);
@@ -441,7 +483,18 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
     __builtin_amdgcn_s_barrier();        // ... in every wave, and everybody is done reading stage s
     wc = wn;
   }
+  if constexpr (ABL & 64) ph[2] = __builtin_amdgcn_s_memrealtime();
   wide_finish<MB, PAIRS>(a, t, acc, smem, ct0, lane, wave);
+  if constexpr (ABL & 64) {
+    ph[3] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    ph[4] = __builtin_amdgcn_s_memrealtime();
+    if (a.dbg && lane == 0) {
+      unsigned long long* o = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) o[i] = ph[i];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -586,7 +639,7 @@ __global__ __launch_bounds__(256 * WK) void w4a16_ring_kernel(const GemmArgs a) 
     }
     __syncthreads();  // (splitk_arrive writes its flag into the same LDS)
   }
-  wide_finish<MB, PAIRS>(a, t, acc, smem, ct0, lane, wn, wk == 0);
+  wide_finish<MB, PAIRS, WK>(a, t, acc, smem, ct0, lane, wn, wk == 0);
   if constexpr (ABL & 32) span_stamp(a.span, 1);
 }
 
