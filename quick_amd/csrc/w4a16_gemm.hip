@@ -1355,54 +1355,109 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   // 17.0-17.3 us, 64 x 14336 x 4096 22.2 -> 19.8, 64 x 16384 x 4096 24.8 -> 21.0; a tie at M = 49..56, and up to K = 8192 the
   // skinny kernel stays ahead: 64 x 8192 x 4096 13.9 against 14.5 us, 64 x 4096 x 4096 8.3 against 10.9)
   const int tiled_tiles = (N / 128) * ((M + 63) / 64);
-  // [r02 audit, profiles/r02_planner_audit_*.jsonl] 48 tiles are enough (4096 x 6144, M = 24..64: 10.4-12.8 against the skinny
+  // [r02 audit, profiles/r02_planner_audit*.jsonl] 48 tiles are enough (4096 x 6144, M = 24..64: 10.4-12.8 against the skinny
   // kernel's 11.4-14.2 us); and the long-K rule starts at M = 33 from K = 12288 (48 x 14336 x 4096: 22.2 -> 19.2)
   // (the 48-tile rule with G % 128 == 0 only: at G = 64 / 32 the four-tile exact skinny kernel is ahead there, 32 x 4096 x 6144 9.4 /
   // 10.0 against 11.1 / 11.5 us)
-  const bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= (G % 128 == 0 ? 48 : 64)) || (M > 56 && K >= 10240) || (M > 32 && K >= 12288);
+  bool want_tiled = M > 64 || (M > 16 && tiled_tiles >= (G % 128 == 0 ? 48 : 64)) || (M > 56 && K >= 10240) || (M > 32 && K >= 12288);
+  // [r02, third audit: 21 layer shapes incl. Llama-2-13B / Qwen2 / Yi ones the rules above were not tuned on, M = 20..64,
+  // scripts/gpu_planner_sweep_17_64.sh]  With G % 128 == 0 the rule is the four-tile skinny kernel's own geometry instead: it wins where
+  // its workgroups (64 channels x 16 tokens each, K split in powers of two down to 8 stages) fit one round of 256 AND a workgroup's K
+  // slice is at most 64 stages (4096 x 6144 M = 20..32: 7.6 against the tiled kernel's 10.3 us, 5120 x 5120 M <= 48: 8.6-9.2 against
+  // 10.8-12.8, 8192 x 8192 M <= 32: 13.3 against 14.2); two rounds (5120 x 5120 M = 64: 16.0 against 13.0) or long slices
+  // (13824 x 5120 M <= 32: 19.3-21.3 against 16.2, 20480 x 7168: 28.4 against 23.7) go to the tiled kernel.
+  if (G % 128 == 0 && M > 16 && M <= 64 && N % 64 == 0) {
+    const long wg = (long)(N / 64) * ((M + 15) / 16);
+    int sk = 1;
+    while (wg * sk * 2 <= 256 && KT / (sk * 2) >= 8) sk *= 2;
+    want_tiled = !(wg <= 256 && (KT + sk - 1) / sk <= 64);
+  }
   p.kernel = family == QUICK_KERNEL_AUTO ? (want_tiled ? QUICK_KERNEL_TILED : QUICK_KERNEL_SKINNY) : family;
   // Wide kernels (32x32x16 MFMA, one wave per SIMD, LDS-DMA) from 256 tokens, and from 64 tokens once there are enough
   // 64 x 128 tiles to cover the chip (large N): 13 % ahead of the r01 kernels on average over 45 (M, K, N) shapes between
   // 64 x 4096 x 12288 and 8192 x 4096 x 22016, never behind by more than 3 % [r02 probes, profiles/r02_planner_probe*.jsonl].
-  // The tile (mb x 32 tokens, pairs x 128 channels) minimises  rounds * tile work / efficiency + K-split reduction -- a
-  // quantisation model: how many tiles the busiest CU runs, times what a tile costs.  Efficiencies (relative) fitted to the
-  // probes: 64x128 0.86, 64x256 0.90, 128x128 1.00, 128x256 1.03, 256x256 1.04 (the fit picks within 0.3 % of the best
-  // measured variant on average, 3.3 % at worst); a K split costs slices * tile bytes at ~60 GB/s for the last arriver.
+  // The tile (mb x 32 tokens, pairs x 128 channels) minimises a fitted launch-time model, see below.
   int wide_mb = 0, wide_pairs = 0;
   bool wide_ring = false;
+  // K slices of a wide launch: as many as keep the workgroups within one round of 256 and the slices >= 4 stages -- any count,
+  // not only powers of two (80 tiles run 3 slices = 240 workgroups; Llama-2-13B's N = 5120 is 40 / 80 tiles wide)
+  const auto wide_split = [KT](long tiles) { return (int)std::max<long>(1, std::min<long>(256 / std::max<long>(1, tiles), KT / 4)); };
   // [r02] ... or, with fewer tiles, once the K slices that fill the chip are still >= 32 stages long (64 x 28672 x 8192: 64 tiles
   // x 4 slices of 56 stages, 46.6 us against the tiled kernel's 54.6-58; M = 80 / 96 / 128 / 200 there: 70.6 / 72.4 / 73.8 / 126.9
   // against 78.4 / 80.0 / 79.3 / 150.8; at 16-22 stages per slice the r01 kernels stay ahead)
   const long wide_tiles64 = (long)((M + 63) / 64) * (N / 128);
   // (audit: from 24 stages -- 96 / 128 x 14336 x 4096, 4 slices of 28: 27.3 / 28.0 against 29.0 / 29.3 us; at 21 stages it is a toss-up,
   // 96 x 11008 x 4096 22.8 against 23.6 but 48 x 8192 x 10240 25.2 against 22.3 -- and from M = 33: 48 x 28672 x 8192 54.6 -> 45.5)
-  const bool wide_long_k = wide_tiles64 <= 128 && KT / std::max<long>(1, 256 / wide_tiles64) >= 24;
+  // (after the store-path change [r02, second audit]: from 21 stages above 64 tokens -- 96 / 128 x 11008 x 4096 22.8 / 24.3 against 24.4 / 25.6)
+  // (third audit, with any-count K splits: one token tile, M = 33..64, from 16 stages per slice while the tiles fit one round -- 8192 x
+  // 8192 18.0 against 19.0 us, 18944 x 3584 20.6 against 22.3, 28672 x 8192 41.6 against 53, 4096 x 22016 21.3 against 22.2; at 4-11
+  // stages per slice the reduction makes it lose 2-8 %, and so do two rounds of tiles, 8192 x 57344 82 against 74)
+  const bool wide_long_k = M <= 64 ? (wide_tiles64 <= 256 && KT / std::max<long>(1, 256 / wide_tiles64) >= 16)
+                                   : (wide_tiles64 <= 128 && KT / std::max<long>(1, 256 / wide_tiles64) >= 21);
   // ... except where 32-token tiles fit the token count exactly, fill one round and the 64- / 128-token tiles would run a quarter
   // empty (M = 65..96 on Llama-2-70B's qkv: 96 x 8192 x 10240 = 240 tiles of 32 x 128, 30.2 us against 38.6 [r02 audit])
   const long tiles32 = (long)((M + 31) / 32) * (N / 128);
   const bool exact32 = M < 128 && ((M + 63) / 64) * 64 - M >= 32 && tiles32 >= 208 && tiles32 <= 256 && !wide_long_k;
-  if (family == QUICK_KERNEL_AUTO && G % 128 == 0 && !exact32 &&
-      ((M >= 64 && (M >= 256 || wide_tiles64 >= 160)) || (M > 32 && wide_long_k))) {
-    static const int cand[5][3] = {{2, 1, 4}, {2, 2, 2}, {4, 1, 2}, {4, 2, 1}, {8, 2, 1}};   // mb, pairs, workgroups per CU
-    static const double eff[5] = {0.86, 0.90, 1.00, 1.03, 1.04};
+  // 65..256 tokens: the r01 tiled kernel's 32 x 128 and 64 x 128 tiles compete in the same model (its own K-split rule, coefficients
+  // from all five audits); over the 152 audited shapes of that range the minimum is 1.2 % behind the best measured kernel on average,
+  // 12 % at worst, where the separate rules were 2.1 % / 22 % (160 x 4096 x 6144: five exact 32-token tile rows, 17.7 against 21.4 us)
+  const bool unified = family == QUICK_KERNEL_AUTO && G % 128 == 0 && M > 64 && M <= 256 && !mt_req && !waves_req;
+  int model_tiled_mt = 0;
+  if (family == QUICK_KERNEL_AUTO && G % 128 == 0 &&
+      (unified || (!exact32 && ((M >= 64 && (M >= 256 || wide_tiles64 >= 96)) || (M > 32 && wide_long_k))))) {
+    // (96 tiles of 64 x 128 [second audit]: 64 x 4096 x 12288 17.3 against 18.0 us, 96 / 128 x 4096 x 6144 16.8 / 17.2 against 17.4 / 18.0,
+    // 192 x 4096 x 4096 16.9 against 17.9, 192 x 4096 x 6144 22.2 against 24.5; at 64-80 tiles the r01 kernels are level or ahead)
+    // Launch-time model per kernel, fitted (relative least squares) to 198 shapes x 10 kernels, 64..8192 tokens on the model
+    // layers [r02, scripts/gpu_planner_sweep_large.sh, two sessions averaged; residual 2.5-3.4 % rms = the session noise]:
+    //   us = c + a n + stages (b_ceil n + b_frac f) [+ split0 + split1 * slices * tile MB],  n = ceil(f), f = workgroups / 256
+    // -- a round of tiles costs what its fullest CU runs (b_ceil), and a partly filled chip runs its tiles faster (b_frac: clocks,
+    // HBM share).  Picking the minimum is within 0.6 % of the best measured kernel on average over the 182 shapes routed here,
+    // 7.5 % at worst (the r01 cost model after the store-path change: 4.4 % / 26 %).  The ring kernel only at 64 x 128 (one
+    // workgroup per CU); 64 x 256 / 128-token ring variants and the 256 x 128 tile never won a shape in the sweep.
+    struct WideCand { int mb, pairs; double c, a, b_ceil, b_frac, split0, split1; };
+    static const WideCand cand[5] = {{2, 1, 1.31, 2.61, 0.3985, 0.2318, 2.03, 19.6},  {2, 2, 6.34, -0.46, 0.4908, 0.5177, 2.13, 13.5},
+                                     {4, 1, 6.08, -0.99, 0.4298, 0.5297, 2.54, 13.1}, {4, 2, -1.68, 7.41, 0.6715, 1.0087, 3.53, 10.6},
+                                     {8, 2, -7.23, 15.76, 1.2716, 1.7451, 2.48, 58.9}};
     double best = 0;
     for (int c = 0; c < 5; ++c) {
-      const int mb = cand[c][0], pairs = cand[c][1];
+      const int mb = cand[c].mb, pairs = cand[c].pairs;
       if (N % (pairs * 128) != 0) continue;
       const long T = (long)((M + mb * 32 - 1) / (mb * 32)) * (N / (pairs * 128));
-      int s = 1;
-      while (T * s * 2 <= 256 && KT / (s * 2) >= 4) s *= 2;
-      const double tile = 2.0 * mb * 32 * pairs * 128 * ((double)K / s) / (3.7e6 * eff[c]);   // us, one tile alone on its CU
-      const long n = (T * s + 255) / 256;
-      const double cost = n * tile + 3.0 + (s > 1 ? s * mb * 32.0 * pairs * 128 * 4 / 60e3 + 1.0 : 0.0);
+      const int s = wide_split(T);
+      const double f = (double)(T * s) / 256.0, n = (double)((T * s + 255) / 256), stages = (double)((KT + s - 1) / s);
+      const double cost = cand[c].c + cand[c].a * n + stages * (cand[c].b_ceil * n + cand[c].b_frac * f) +
+                          (s > 1 ? cand[c].split0 + cand[c].split1 * s * (mb * 32.0 * pairs * 128 * 4 / 1e6) : 0.0);
       if (wide_mb == 0 || cost < best) {
         best = cost;
         wide_mb = mb;
         wide_pairs = pairs;
-        wide_ring = mb == 2 && T * s <= 256;   // the ring holds one workgroup per CU: only where there is no second one anyway
+        wide_ring = mb == 2 && pairs == 1;
       }
     }
+    if (unified) {
+      static const double tc[2][6] = {{5.968, -0.491, 0.263, 0.145, 0.697, 0.421}, {4.645, 1.535, 0.432, 0.195, 1.204, 0.711}};  // 32 / 64 tokens
+      for (int c = 0; c < 2; ++c) {
+        const int mt = c == 0 ? 2 : 4;
+        const long T = (long)(N / 128) * ((M + mt * 16 - 1) / (mt * 16));
+        const int nstage = (KT + 1) / 2;  // (eight waves: stages of 256 k)
+        int s = 1;
+        while (T * s * 2 <= 256 && nstage / (s * 2) >= 2) s *= 2;
+        if (256 / T > s && nstage / (256 / T) >= 2) s = (int)(256 / T);
+        s = std::max(1, std::min(s, nstage));
+        const int kps = ((nstage + s - 1) / s) * 2, slices = (KT + kps - 1) / kps;
+        const double f = (double)(T * slices) / 256.0, n = (double)((T * slices + 255) / 256);
+        const double cost = tc[c][0] + tc[c][1] * n + kps * (tc[c][2] * n + tc[c][3] * f) + (slices > 1 ? tc[c][4] + tc[c][5] * slices : 0.0);
+        if (wide_mb == 0 || cost < best) {
+          best = cost;
+          wide_mb = -1;  // (not a wide tile)
+          model_tiled_mt = mt;
+        }
+      }
+      if (wide_mb < 0) wide_mb = 0;
+      else model_tiled_mt = 0;
+    }
     if (wide_mb) p.kernel = QUICK_KERNEL_WIDE;
+    else if (model_tiled_mt) p.kernel = QUICK_KERNEL_TILED;
   }
   int ks = 1;
   if (p.kernel == QUICK_KERNEL_WIDE && G % 128 != 0) p.kernel = QUICK_KERNEL_TILED;  // small groups: r01's tiled kernel
@@ -1424,7 +1479,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / p.tch;
     p.ntiles = MBk * NBk;
     p.slab_floats = (size_t)mb * 32 * p.tch;
-    while (p.ntiles * ks * 2 <= 256 && KT / (ks * 2) >= 4) ks *= 2;
+    ks = wide_split(p.ntiles);
     p.ksplit = std::max(1, std::min(grid_split_k > 0 ? grid_split_k : ks, KT));
     p.kt_per_split = (KT + p.ksplit - 1) / p.ksplit;
     long best = -1;
@@ -1440,7 +1495,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   } else if (p.kernel == QUICK_KERNEL_SKINNY) {
     const int mblocks = (M + 15) / 16;
     // channel tiles per workgroup ~ token blocks (weights are re-read per token block, x per channel block)
-    int mt_auto = mblocks <= 1 ? 1 : (mblocks <= 2 ? 2 : 4);
+    // (two token blocks: four tiles as well with G % 128 == 0 -- never behind two in the third audit, 32 x 5120 x 5120 15.8 -> 9.1 us)
+    int mt_auto = mblocks <= 1 ? 1 : (mblocks <= 2 && G % 128 != 0 ? 2 : 4);
     // M = 9..16 on a large layer: the fragments-from-L2 path reads x once per 16-channel tile -- 4x the weight bytes at
     // M = 16 -- so share every x fragment among 4 channel tiles (8192 x 57344 at M = 16: 119 -> 78 us, 28672 x 8192:
     // 65 -> 36 us [r01]).  Small layers keep NTW = 1 (more workgroups); from 1024 channel blocks the deferred-zero path
@@ -1463,6 +1519,10 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
       else if (M >= 4 && M <= 8) mt_auto = 2;
       else if (M > 8 && (long)K * N < 40L * 1000 * 1000) mt_auto = 2;
     }
+    // M = 7, 8 with a long K (>= 10240: the x copy is far beyond the 64 KiB LDS budget) where the exact path would take its fragments
+    // from L2 once per 16 channels: two tiles per workgroup share them (8 x 11008 x 4096 10.0 -> 9.2 us, 14336 x 4096 12.2 -> 11.4,
+    // 18944 x 3584 14.7 -> 13.1; at M = 6 it is a tie) [audits]
+    if (!mt_req && mt_auto == 1 && M >= 7 && M <= 8 && N / 16 <= 256 && G % 128 == 0 && K >= 10240) mt_auto = 2;
     p.mt = mt_req ? mt_req : mt_auto;
     if (p.mt != 1 && p.mt != 2) p.mt = 4;
     while (p.mt > 1 && (N / 16) % p.mt != 0) p.mt /= 2;
@@ -1474,17 +1534,17 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     p.ksplit = std::max(1, std::min(grid_split_k > 0 ? grid_split_k : ks, KT));
     p.kt_per_split = (KT + p.ksplit - 1) / p.ksplit;
   } else {
-    p.mt = mt_req ? (mt_req == 2 ? 2 : (mt_req == 8 ? 8 : 4)) : (M <= 32 ? 2 : 4);
+    p.mt = mt_req ? (mt_req == 2 ? 2 : (mt_req == 8 ? 8 : 4)) : (model_tiled_mt ? model_tiled_mt : (M <= 32 ? 2 : 4));
     p.waves = waves_req == 16 ? 16 : 8;
     int wk = p.wn2 ? 4 : p.waves / 4;
     // 32-token tiles once 64-token tiles would need a 4-way K split to cover the CUs (twice the tiles, half the slices
     // to reduce): M = 65..128 at N = 4096, 15.5 us instead of 16.5 us at M = 128 [r01]
-    if (!mt_req && p.mt == 4 && (N / 128) * ((M + 63) / 64) * 4 <= 256 && (KT + wk - 1) / wk >= 8) p.mt = 2;
+    if (!mt_req && !model_tiled_mt && p.mt == 4 && (N / 128) * ((M + 63) / 64) * 4 <= 256 && (KT + wk - 1) / wk >= 8) p.mt = 2;
     // ... and at K <= 4096 already where they would need a 2-way split: twice the tiles and nothing to reduce (64 x 4096 x 12288
     // 18.1 -> 17.0 us, 192 x 4096 x 4096 18.2 -> 17.1, 96 / 128 x 4096 x 6144 17.9 -> 16.9 [r02 audit]; with a longer K the split
     // tiles stay ahead: 48 x 8192 x 10240 22.3 against 29.4)
-    if (!mt_req && p.mt == 4 && exact32 && !((kernel >> 27) & 1) && !((kernel >> 29) & 1)) p.mt = 2;  // (see exact32 above)
-    if (!mt_req && p.mt == 4 && K <= 4096 && !((kernel >> 27) & 1) && !((kernel >> 29) & 1) && (N / 128) * ((M + 63) / 64) * 2 <= 256 &&
+    if (!mt_req && !model_tiled_mt && p.mt == 4 && exact32 && !((kernel >> 27) & 1) && !((kernel >> 29) & 1)) p.mt = 2;  // (see exact32 above)
+    if (!mt_req && !model_tiled_mt && p.mt == 4 && K <= 4096 && !((kernel >> 27) & 1) && !((kernel >> 29) & 1) && (N / 128) * ((M + 63) / 64) * 2 <= 256 &&
         (N / 128) * ((M + 31) / 32) <= 256)
       p.mt = 2;
     // 256-channel tiles (4 channel tiles per wave: one LDS fragment read per four MFMAs instead of two, 2/3 of the L2 -> CU
@@ -1496,7 +1556,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     // N = 4096, 256 x 12288, 128 x 22016, M = 384..512 at K = N = 8192); just above a multiple of 256 the second, nearly
     // empty round loses (192 x 22016: 80 against 70 us; 512 x 11008: 84 against 75) [r01 sweep, one session].
     // Kernel bit 29 forces them, bit 30 forbids them.
-    const bool wide_ok = p.mt == 4 && p.waves == 8 && !p.wn2 && !p.mfma32 && !p.ablate && N % 256 == 0 && !mt_req;
+    const bool wide_ok = p.mt == 4 && p.waves == 8 && !p.wn2 && !p.mfma32 && !p.ablate && N % 256 == 0 && !mt_req && !model_tiled_mt;
     const long wtiles = (long)(N / 256) * ((M + 63) / 64);
     const long nfull = 2 * wtiles / 512, nrem = 2 * wtiles % 512;
     const double narrow_cost = 1.65 * nfull + (nrem == 0 ? 0.0 : (nrem <= 256 ? 1.0 : 1.65));
@@ -1569,7 +1629,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
       // ... and only when the rounds keep the slots busy (384 blocks on 256 slots = 2 rounds at 75 %: Mistral's qkv
       // at M = 16 lost 2 % to the exact path's 384 one-block workgroups [r01])
       const bool balanced = (double)nblocks >= 0.8 * rounds * 256 * c;
-      if (M <= 2 || ((kernel >> 26) & 1) || (rounds >= 2 && balanced && p.ksplit == 1)) {  // bit 26: tests force the path
+      // (M = 3 from 256 blocks as well [third audit: never behind the exact path there, 13824 x 5120 16.3 -> 11.5 us, 4096 x 6144 6.7 -> 6.2,
+      // 5120 x 5120 8.0 -> 7.4, 11008 x 4096 8.2 -> 7.9; with 224 blocks, 18944 x 3584, the exact path is ahead 12.8 against 13.9])
+      if (M <= 2 || (M == 3 && nblocks >= 256 && p.ksplit == 1) || ((kernel >> 26) & 1) || (rounds >= 2 && balanced && p.ksplit == 1)) {  // bit 26: tests force the path
         p.dz = p.xlds = true;
         if (!flip && p.ksplit == 1 && rounds >= 2) p.grid_x = std::min(nblocks, ((nblocks + rounds - 1) / rounds + 7) & ~7);
         // One workgroup per CU and a long K: 16 waves instead of 8 -- twice the bytes in flight per CU and half the chain of

@@ -1,6 +1,6 @@
 #!/bin/bash
 # planner audit: every model shape x a ladder of token counts x the kernel families (and the skinny flavours at small M);
-# writes gpurun_out/planner_sweep_{small,big}.jsonl (kept as profiles/r02_planner_audit_*.jsonl)
+# writes gpurun_out/planner_sweep_{small,big}.jsonl (kept as profiles/r02_planner_audit*.jsonl)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 if [ "$1" = "tests" ]; then timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3; fi
