@@ -380,20 +380,31 @@ __device__ __forceinline__ void wide_finish(const GemmArgs& a, const WideTile& t
     }
     if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
     // every slice is read back from its slab (the own one too) and added in index order: the sum does not depend on
-    // who arrived last
+    // who arrived last.  The slabs were written through by other CUs, so every load is a trip to memory (~0.65 us): the loads
+    // of D slices are issued together (as many as 128 registers hold), the adds stay in slice order.
+    constexpr int NL = PAIRS * MB * 4, D = NL <= 8 ? 4 : (NL <= 16 ? 2 : 1);
     floatx16 sum[PAIRS][MB];
     wide_zero<MB, PAIRS>(sum);
-    for (int o = 0; active && o < a.ksplit; ++o) {
+    for (int o = 0; active && o < a.ksplit; o += D) {
+      floatx4 part[D][NL];
 #pragma unroll
-      for (int p = 0; p < PAIRS; ++p)
+      for (int d = 0; d < D; ++d) {
+        const unsigned base = (unsigned)min(o + d, a.ksplit - 1) * SLAB_BYTES + my;  // (past the end: a load nobody adds)
 #pragma unroll
-        for (int mt = 0; mt < MB; ++mt)
+        for (int i = 0; i < NL; ++i) part[d][i] = slab_load(rs, base + i * 4096);
+      }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const floatx4 part = slab_load(rs, o * SLAB_BYTES + ((p * MB + mt) * 4 + c) * 4096 + my);
+      for (int d = 0; d < D; ++d)
+        if (o + d < a.ksplit) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sum[p][mt][4 * c + r] += part[r];
-          }
+          for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+            for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[p][mt][4 * c + r] += part[d][(p * MB + mt) * 4 + c][r];
+        }
     }
     wide_epilogue<MB, PAIRS, WK>(a, t, sum, smem, lane, wave, active);
     return;

@@ -885,6 +885,42 @@ def test_random_shapes_with_fused_epilogues_and_prologue(qa, device):
     assert len(seen) == 5
 
 
+@pytest.mark.parametrize("kernel_id", [wide(2, 1), wide(2, 2), wide(4, 1), wide(4, 2), wide(8, 1), wide(8, 2), wide(2, 1) | WIDE_NORING,
+                                       wide(4, 2) | WIDE_NORING, wide(2, 1) | WIDE_8WAVES, wide(2, 2) | WIDE_8WAVES, wide(4, 1) | WIDE_8WAVES],
+                         ids=["64x128", "64x256", "128x128", "128x256", "256x128", "256x256", "64x128nr", "128x256nr", "64x128w8", "64x256w8", "128x128w8"])
+@pytest.mark.parametrize("M,K,N", [(300, 512, 512), (77, 1152, 768), (1, 256, 1024), (513, 384, 256)])
+def test_wide_family_way_out(qa, device, M, K, N, kernel_id):
+    """Every tile of the 32x32x16 family through its LDS-staged way out: ragged token counts (last tile 44 / 13 / 1 rows), bias +
+    residual (the residual is added to the ROUNDED product, as GEMM-then-add does), SiLU*mul (half the channels), and a forced K
+    split of 2 and 3 slices (the last arriver's exit)."""
+    from quick_amd import kernels as K_
+    if ((kernel_id >> 8) & 15) == 2 and N % 256 != 0:
+        pytest.skip("256-channel tiles need N % 256 == 0")
+    G = 128
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + K + N + 11)
+    want = oracle.w4a16_forward(x, iw, s, z, G).astype(np.float32)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device)
+    bias = torch.linspace(-1, 1, N, device=device).half()
+    res = torch.randn(M, N, device=device).half()
+    assert K_.plan_describe(M, K, N, G, kernel_id).startswith("wide")
+    y = qa.gemm_forward(xd, *packed, kernel_id=kernel_id)
+    assert rel_err(y.cpu().numpy(), want) <= TOL
+    yb = qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=kernel_id)
+    two = (qa.gemm_forward(xd, *packed, bias=bias, kernel_id=kernel_id).float() + res.float()).half()
+    assert torch.equal(yb, two)                                     # bit for bit the two-step result
+    assert rel_err(yb.cpu().numpy(), want + bias.float().cpu().numpy() + res.float().cpu().numpy()) <= TOL
+    for ks in (2, 3):
+        y2 = qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=kernel_id, grid_split_k=ks)
+        assert rel_err(y2.cpu().numpy(), want + bias.float().cpu().numpy() + res.float().cpu().numpy()) <= TOL
+        assert torch.equal(y2, qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=kernel_id, grid_split_k=ks))   # order of arrival does not matter
+    y_act = qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kernel_id)
+    assert y_act.shape == (M, N // 2)
+    torch.testing.assert_close(y_act, K_.silu_mul(y), rtol=2e-3, atol=2e-3)
+    y_act2 = qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kernel_id, grid_split_k=2)
+    torch.testing.assert_close(y_act2, K_.silu_mul(y), rtol=2e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("kernel_id", [TILED_WIDE, TILED_BIG], ids=["64x256", "128x256"])
 @pytest.mark.parametrize("M,K,N,G", [(300, 512, 512, 128), (129, 1152, 768, 64), (640, 256, 1024, 32), (1100, 384, 512, 128)])
 def test_wide_tiles_epilogues_and_k_split(qa, device, M, K, N, G, kernel_id):
