@@ -13,6 +13,7 @@ Cache, so small-M numbers are HBM numbers, not cache numbers.  Rank 0 prints ONE
                        rocprofv3 --kernel-trace reports) against the HBM or MFMA peak
   sweep                the same two measurements for every M of the BASELINE sweep (1, 8, 64, 512)
   decode_layers        kernel duration and HBM fraction of the Llama-2-7B layer shapes at M=1 (N=1 only)
+  prefill_layers       kernel duration and MFMA fraction of prefill-sized launches (N=1 only)
   decode               decode tok/s of a synthetic Llama-2-7B stack at bs = 1, 64 (128/128, hipGraph step; N=1 only)
   cpu_baseline         the reference's CPU path (dequantize_gemm + torch.matmul, restated in oracle/cpu_path.py)
                        timed on the host cores on a bounded sample, N=1 only
@@ -137,6 +138,8 @@ def main():
     ap.add_argument("--split-k", type=int, default=0, help="K slices across workgroups (0 = the planner's choice; tuning only)")
     ap.add_argument("--layers", default="1x4096x12288,1x4096x22016,1x11008x4096",
                     help="MxKxN shapes (Llama-2-7B fused qkv, gate_up, down at bs=1) timed kernel-only into 'decode_layers'; '' = none")
+    ap.add_argument("--prefill-layers", default="4096x4096x4096,8192x4096x22016,8192x11008x4096,4096x28672x8192",
+                    help="MxKxN prefill-sized launches (K = N = 4096; Llama-2-7B gate_up / down at 8192 tokens; Llama-2-70B down) into 'prefill_layers'; '' = none")
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--decode-seconds", type=float, default=40.0, help="budget of the decode tok/s leg (Llama-2-7B bs=1,64; 0 = skip)")
     args = ap.parse_args()
@@ -152,7 +155,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = replicas.init("gloo")             # replicas only, no RCCL anywhere: the barrier and the max over ranks run on CPU tensors
 
-    from quick_amd import _lib, packing
+    from quick_amd import _lib, kernels, packing
     from quick_amd.build import build
     build()
     lib = _lib.load()
@@ -336,6 +339,34 @@ def main():
                                                       "frac_inkernel": nb / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS if s_us else None}})
             log(f"layer M={Ml} K={Kl} N={Nl}: kernel {k_us:7.2f} us  {ach:7.1f} GB/s = {100 * ach / HBM_PEAK_GBS:.1f}% of HBM peak"
                 + (f"; in-kernel span {s_us:.2f} us = {100 * nb / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS:.1f}%" if s_us else ""))
+            del lsets, larr
+
+    # ---- prefill-sized launches (compute-bound end of the path), kernel duration only, MFMA roofline
+    if world == 1 and args.prefill_layers:
+        out["prefill_layers"] = []
+        for spec in args.prefill_layers.split(","):
+            Ml, Kl, Nl = (int(v) for v in spec.lower().split("x"))
+            sb = Kl * Nl // 2 + (Kl // G) * 2 * Nl * 2 + (Kl // G) * (Nl // 4) * 4
+            ns = max(2, min(8, -(-(320 << 20) // sb)))
+            lsets = [packing.random_mi355x(Kl, Nl, G, dev, gen) for _ in range(ns)]
+            larr = lambda i: (ctypes.c_void_p * ns)(*[st[i].data_ptr() for st in lsets])
+            xl = (torch.randn((Ml, Kl), device=dev, generator=gen) * 0.5).half()
+            yl = torch.empty((Ml, Nl), dtype=torch.float16, device=dev)
+            wsb = lib.quick_w4a16_workspace_bytes_ex(Ml, Kl, Nl, G, args.kernel, 0)
+            wsl = torch.zeros(max(wsb, 1), dtype=torch.uint8, device=dev)
+            it = 24
+            kus = (ctypes.c_float * it)()
+            rc = lib.quick_w4a16_gemm_profile(xl.data_ptr(), larr(0), larr(1), larr(2), ns, yl.data_ptr(), wsl.data_ptr(), wsb,
+                                              Ml, Kl, Nl, G, args.kernel, 0, it, kus, stream.cuda_stream)
+            if rc != 0:
+                raise RuntimeError(_lib.last_error())
+            k_us = float(np.median(np.asarray(kus[:])[4:]))
+            fl = algorithmic_flops(Ml, Kl, Nl)
+            ach = fl / (k_us * 1e-6) / 1e12
+            out["prefill_layers"].append({"M": Ml, "K": Kl, "N": Nl, "kernel_us": k_us, "plan": kernels.plan_describe(Ml, Kl, Nl, G, args.kernel),
+                                          "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                       "frac": ach / MFMA_PEAK_TFLOPS, "flops": fl}})
+            log(f"prefill M={Ml} K={Kl} N={Nl}: kernel {k_us:8.2f} us  {ach:7.1f} TFLOP/s = {100 * ach / MFMA_PEAK_TFLOPS:.1f}% of the f16 MFMA peak")
             del lsets, larr
 
     # ---- the reference's CPU path on the host cores, bounded sample, rank 0 / N=1 only
