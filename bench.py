@@ -354,16 +354,20 @@ def main():
             yl = torch.empty((Ml, Nl), dtype=torch.float16, device=dev)
             wsb = lib.quick_w4a16_workspace_bytes_ex(Ml, Kl, Nl, G, args.kernel, 0)
             wsl = torch.zeros(max(wsb, 1), dtype=torch.uint8, device=dev)
-            it = 24
-            kus = (ctypes.c_float * it)()
-            rc = lib.quick_w4a16_gemm_profile(xl.data_ptr(), larr(0), larr(1), larr(2), ns, yl.data_ptr(), wsl.data_ptr(), wsb,
-                                              Ml, Kl, Nl, G, args.kernel, 0, it, kus, stream.cuda_stream)
-            if rc != 0:
-                raise RuntimeError(_lib.last_error())
-            k_us = float(np.median(np.asarray(kus[:])[4:]))
+            it = 32   # three rounds, the best median counts (same as tools/wide_probe.py): the clocks ramp for tens of
+            kus = (ctypes.c_float * it)()   # milliseconds after the light launches before this leg
+            meds = []
+            for _ in range(3):
+                rc = lib.quick_w4a16_gemm_profile(xl.data_ptr(), larr(0), larr(1), larr(2), ns, yl.data_ptr(), wsl.data_ptr(), wsb,
+                                                  Ml, Kl, Nl, G, args.kernel, 0, it, kus, stream.cuda_stream)
+                if rc != 0:
+                    raise RuntimeError(_lib.last_error())
+                meds.append(float(np.median(np.asarray(kus[:])[4:])))
+            k_us = min(meds)
             fl = algorithmic_flops(Ml, Kl, Nl)
             ach = fl / (k_us * 1e-6) / 1e12
             out["prefill_layers"].append({"M": Ml, "K": Kl, "N": Nl, "kernel_us": k_us, "plan": kernels.plan_describe(Ml, Kl, Nl, G, args.kernel),
+                                          "kernel_us_medians": meds,
                                           "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                        "frac": ach / MFMA_PEAK_TFLOPS, "flops": fl}})
             log(f"prefill M={Ml} K={Kl} N={Nl}: kernel {k_us:8.2f} us  {ach:7.1f} TFLOP/s = {100 * ach / MFMA_PEAK_TFLOPS:.1f}% of the f16 MFMA peak")
