@@ -1425,13 +1425,17 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
       const long T = (long)((M + mb * 32 - 1) / (mb * 32)) * (N / (pairs * 128));
       const int s = wide_split(T);
       const double f = (double)(T * s) / 256.0, n = (double)((T * s + 255) / 256), stages = (double)((KT + s - 1) / s);
-      const double cost = cand[c].c + cand[c].a * n + stages * (cand[c].b_ceil * n + cand[c].b_frac * f) +
-                          (s > 1 ? cand[c].split0 + cand[c].split1 * s * (mb * 32.0 * pairs * 128 * 4 / 1e6) : 0.0);
+      // (64 x 128 tiles in more than one round: the double-buffered kernel, 2-4 workgroups per CU, instead of the ring's one --
+      // 256 x 4096 x 12288 33.8 against 42.3 us; its own fit over the 219 such rows of the audits, 2.1 % rms)
+      const bool rounds64 = mb == 2 && pairs == 1 && T * s > 256;
+      const double cost = rounds64 ? 5.25 - 0.05 * n + stages * (0.2382 * n + 0.3242 * f)
+                                   : cand[c].c + cand[c].a * n + stages * (cand[c].b_ceil * n + cand[c].b_frac * f) +
+                                         (s > 1 ? cand[c].split0 + cand[c].split1 * s * (mb * 32.0 * pairs * 128 * 4 / 1e6) : 0.0);
       if (wide_mb == 0 || cost < best) {
         best = cost;
         wide_mb = mb;
         wide_pairs = pairs;
-        wide_ring = mb == 2 && pairs == 1;
+        wide_ring = mb == 2 && pairs == 1 && !rounds64;
       }
     }
     if (unified) {
