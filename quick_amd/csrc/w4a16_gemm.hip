@@ -1415,7 +1415,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     // 7.5 % at worst (the r01 cost model after the store-path change: 4.4 % / 26 %).  The ring kernel only at 64 x 128 (one
     // workgroup per CU); 64 x 256 / 128-token ring variants and the 256 x 128 tile never won a shape in the sweep.
     struct WideCand { int mb, pairs; double c, a, b_ceil, b_frac, split0, split1; };
-    static const WideCand cand[5] = {{2, 1, 1.31, 2.61, 0.3985, 0.2318, 2.03, 19.6},  {2, 2, 6.34, -0.46, 0.4908, 0.5177, 2.13, 13.5},
+    static const WideCand cand[5] = {{2, 1, 1.31, 2.61, 0.3865, 0.2248, 2.03, 19.6},   // (fitted on four waves: 0.3985 / 0.2318; eight waves are 3 % faster per stage)
+                                      {2, 2, 6.34, -0.46, 0.4908, 0.5177, 2.13, 13.5},
                                      {4, 1, 6.08, -0.99, 0.4298, 0.5297, 2.54, 13.1}, {4, 2, -1.68, 7.41, 0.6715, 1.0087, 3.53, 10.6},
                                      {8, 2, -7.23, 15.76, 1.2716, 1.7451, 2.48, 58.9}};
     double best = 0;
@@ -1475,8 +1476,13 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     p.wide_pairs = pairs;
     // bit 12: no ring (the double-buffered kernel at every tile size); bits 22-24: ring slots (0 = as many as fit, up to 6);
     // bit 15: eight waves per workgroup (two per SIMD, k16 steps split by parity) -- ring kernel, tiles up to 128 x 128 / 64 x 256
-    const bool eight = ((kernel >> 15) & 1) && mb * pairs <= 4 && !no_xlds;
-    const int nb_req = (kernel >> 22) & 7, nb_max = mb == 8 ? 0 : wide_ring_nbuf(mb, pairs, eight ? 2 : 1);
+    // The planner's own ring launches (64 x 128 tiles) run the eight-wave variant with four slots: since the whole workgroup shares
+    // the way out (§5.3 of DESIGN.md) it is 2-5 % ahead of four waves / six slots on every shape probed, warm against warm in one
+    // session -- 512 x 4096 x 4096 24.04 against 24.68 us, 128 x 4096 x 12288 21.5 / 22.6, 64 x 4096 x 22016 20.8 / 21.7, 512 x 11008 x 4096
+    // 57.8 / 59.2, 448 x 4096 x 4096 22.7 / 23.4; four slots are level with or 1 % ahead of six [r02].
+    const bool auto_ring = wide_mb && wide_ring;
+    const bool eight = (((kernel >> 15) & 1) || auto_ring) && mb * pairs <= 4 && !no_xlds;
+    const int nb_req = auto_ring ? 4 : (kernel >> 22) & 7, nb_max = mb == 8 ? 0 : wide_ring_nbuf(mb, pairs, eight ? 2 : 1);
     p.wide_nbuf = (no_xlds || nb_max < 3 || (wide_mb && !wide_ring)) ? 0 : (nb_req >= 3 ? std::min(nb_req, nb_max) : nb_max);
     p.waves = (eight && p.wide_nbuf >= 3) ? 8 : 4;
     p.tch = pairs * 128;
@@ -1854,7 +1860,7 @@ static void launch_ring(const Plan& p, const GemmArgs& a, const Launch& L) {
       return;
     }
   if (a.span) {
-    if constexpr (MB == 2 && PAIRS == 1 && NBUF == 6 && WK == 1) {
+    if constexpr (MB == 2 && PAIRS == 1 && ((NBUF == 6 && WK == 1) || (NBUF == 4 && WK == 2))) {
       if (group_mode(a.G) == 0) {
         auto kfn = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 32, WK>;   // ABL bit 32 = span stamps, nothing else
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

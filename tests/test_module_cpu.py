@@ -152,9 +152,11 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(32, 4096, 8192).startswith("skinny ntw=4")   # 256 workgroups of 64 channels x 16 tokens: one round, 32 stages each
     assert plan(32, 4096, 12288).startswith("tiled")         # 384 of them would be two: the tiled kernel, no K split needed
     # K split until the 256 CUs are covered; the workspace is what workspace_bytes_ex says
-    p = plan(128, 4096, 4096)
+    p = plan(128, 4096, 4096, kernel_id=kernels.KERNEL_TILED)
     assert "tokens=32 channels=128" in p and "ksplit=2" in p
-    assert p.endswith(f"workspace={_lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, 0, 0)}")
+    assert p.endswith(f"workspace={_lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, kernels.KERNEL_TILED, 0)}")
+    p = plan(128, 4096, 4096)
+    assert p.endswith(f"workspace={_lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, 0, 0)}") and "ksplit=1" not in p
     assert "grid=80x3 ksplit=3" in plan(64, 8192, 10240)     # not only powers of two: 240 of 256 CUs (tiled and wide kernels alike)
     assert "grid=80x3 ksplit=3" in plan(64, 8192, 10240, kernel_id=kernels.KERNEL_TILED)
     # r01's tiled kernel (kernel_id TILED; the planner's own choice for G < 128): 256-channel tiles by how they quantise onto 256 CUs
@@ -169,7 +171,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "channels=256" in plan(8192, 4096, 22016, kernel_id=T)
     assert plan(512, 4096, 4096, G=64).startswith("tiled")                # small groups: the wide kernels need G % 128 == 0
     # r02: the wide kernels (32x32x16 MFMA, LDS-DMA) from 256 tokens, and from 64 once 64 x 128 tiles cover the chip
-    assert plan(512, 4096, 4096).startswith("wide tokens=64 channels=128 waves=4 ring=6 grid=256x1")   # one tile per CU: the LDS-DMA ring
+    assert plan(512, 4096, 4096).startswith("wide tokens=64 channels=128 waves=8 ring=4 grid=256x1")   # one tile per CU: the LDS-DMA ring, eight waves
     assert plan(256, 4096, 4096).startswith("wide") and plan(65, 4096, 4096).startswith("tiled tokens=32")   # 65..256 tokens: one launch-time model over both
     assert "tiled tokens=32 channels=128 waves=8 grid=240x1 ksplit=1" in plan(160, 4096, 6144)                # five exact rows of 32-token tiles
     assert plan(64, 4096, 22016).startswith("wide tokens=64") and plan(64, 4096, 12288).startswith("wide tokens=64")   # from 96 tiles of 64 x 128
