@@ -1415,7 +1415,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     // 7.5 % at worst (the r01 cost model after the store-path change: 4.4 % / 26 %).  The ring kernel only at 64 x 128 (one
     // workgroup per CU); 64 x 256 / 128-token ring variants and the 256 x 128 tile never won a shape in the sweep.
     struct WideCand { int mb, pairs; double c, a, b_ceil, b_frac, split0, split1; };
-    static const WideCand cand[5] = {{2, 1, 1.31, 2.61, 0.3865, 0.2248, 2.03, 19.6},   // (fitted on four waves: 0.3985 / 0.2318; eight waves are 3 % faster per stage)
+    static const WideCand cand[5] = {{2, 1, 1.31, 2.61, 0.3806, 0.2214, 2.03, 19.6},   // (fitted on four waves, 0.3985 / 0.2318; eight waves: x 0.955, the median over 337 rows)
                                       {2, 2, 6.34, -0.46, 0.4908, 0.5177, 2.13, 13.5},
                                      {4, 1, 6.08, -0.99, 0.4298, 0.5297, 2.54, 13.1}, {4, 2, -1.68, 7.41, 0.6715, 1.0087, 3.53, 10.6},
                                      {8, 2, -7.23, 15.76, 1.2716, 1.7451, 2.48, 58.9}};

@@ -6,4 +6,4 @@ KN="4096x4096 4096x8192 4096x12288 4096x22016 11008x4096 4096x6144 4096x28672 14
 sh=""
 for kn in $KN; do for m in 20 24 32 40 48 56 64; do sh="$sh,${m}x$kn"; done; done
 N4=$((1+(4<<4))); N2=$((1+(2<<4)))
-python tools/wide_probe.py --shapes "${sh:1}" --variants "warm=0,auto=0,ntw2=$N2,ntw4=$N4,tiled=2,tiled32=$((2+(2<<4))),w2x1=$((3+32+256))" --iters 16 --out gpurun_out/planner_sweep_17_64.jsonl 2>&1 | grep -v amdgpu.ids | tail -1
+python tools/wide_probe.py --shapes "${sh:1}" --variants "warm=0,auto=0,ntw2=$N2,ntw4=$N4,tiled=2,tiled32=$((2+(2<<4))),w2x1=$((3+32+256)),w2x1e=$((3+32+256+(1<<15)+(4<<22)))" --iters 16 --out gpurun_out/planner_sweep_17_64.jsonl 2>&1 | grep -v amdgpu.ids | tail -1

@@ -9,4 +9,4 @@ for kn in $KN; do for m in $MS; do sh="$sh,${m}x$kn"; done; done
 NR=4096
 W21=$((3+32+256)); W22=$((3+32+512)); W41=$((3+64+256)); W42=$((3+64+512)); W82=$((3+128+512))
 # "warm" = the planner's choice once more (the first variant of a shape reads high: clocks ramp after the allocation pause)
-python tools/wide_probe.py --shapes "${sh:1}" --variants "warm=0,auto=0,skinny=1,tiled=2,tiled32=$((2+(2<<4))),w2x1=$W21,w2x1nr=$((W21+NR)),w2x2nr=$((W22+NR)),w4x1nr=$((W41+NR)),w4x2nr=$((W42+NR)),w8x2=$W82" --iters ${ITERS:-16} --out gpurun_out/planner_sweep_mid.jsonl 2>&1 | grep -v amdgpu.ids | tail -1
+python tools/wide_probe.py --shapes "${sh:1}" --variants "warm=0,auto=0,skinny=1,tiled=2,tiled32=$((2+(2<<4))),w2x1=$W21,w2x1e=$((W21+(1<<15)+(4<<22))),w2x1nr=$((W21+NR)),w2x2nr=$((W22+NR)),w4x1nr=$((W41+NR)),w4x2nr=$((W42+NR)),w8x2=$W82" --iters ${ITERS:-16} --out gpurun_out/planner_sweep_mid.jsonl 2>&1 | grep -v amdgpu.ids | tail -1
