@@ -55,6 +55,9 @@ const char* quick_amd_last_error(void);
  *   scales   fp16  [K/G, 2N]    as uint32 [K/G * N]: word ((n/16) * (K/G) + g) * 16 + n%16 = fp16 scale | zero point << 16
  *   qzeros   int32 [K/G, N/4]   plain copy of the zero points (nibble n%8 of dword n/8 of row g); not read by the GEMM
  *
+ * Pointers: every tensor base 16-byte aligned (rows then are, N and K being multiples of 128); torch allocations are
+ * 256-byte aligned.  The kernels move x, y, bias and the residual in 16-byte pieces.
+ *
  * Dequantised weight = fp16((w - z) * s) exactly as the reference computes it
  * (csrc/dequantize_quick.cuh:15-63 + sub/mul.rn.f16x2 in csrc/gemm_cuda_quick.cu:52-60);
  * accumulation in fp32, one rounding to fp16 at the end.
