@@ -1431,7 +1431,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
       const bool rounds64 = mb == 2 && pairs == 1 && T * s > 256;
       const double cost = rounds64 ? 5.25 - 0.05 * n + stages * (0.2382 * n + 0.3242 * f)
                                    : cand[c].c + cand[c].a * n + stages * (cand[c].b_ceil * n + cand[c].b_frac * f) +
-                                         (s > 1 ? cand[c].split0 + cand[c].split1 * s * (mb * 32.0 * pairs * 128 * 4 / 1e6) : 0.0);
+                                         (s > 1 ? cand[c].split0 + cand[c].split1 * s * (mb * 32.0 * pairs * 128 * 4 / 1e6) : 0.0) -
+                                         (s == 2 && mb * pairs <= 8 ? 1.2 : 0.0);   // (two slices: the own partial stays in registers, measured after the fit)
       if (wide_mb == 0 || cost < best) {
         best = cost;
         wide_mb = mb;

@@ -385,6 +385,24 @@ __device__ __forceinline__ void wide_finish(const GemmArgs& a, const WideTile& t
     constexpr int NL = PAIRS * MB * 4, D = NL <= 8 ? 4 : (NL <= 16 ? 2 : 1);
     floatx16 sum[PAIRS][MB];
     wide_zero<MB, PAIRS>(sum);
+    if (NL <= 32 && a.ksplit == 2) {  // two slices: a + b == b + a exactly -- the own partial stays in registers, one slab is read
+      if (active) {
+        const unsigned base = (unsigned)(1 - t.ks) * SLAB_BYTES + my;
+        floatx4 part[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) part[i] = slab_load(rs, base + i * 4096);
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+          for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sum[p][mt][4 * c + r] = acc[p][mt][4 * c + r] + part[(p * MB + mt) * 4 + c][r];
+      }
+      wide_epilogue<MB, PAIRS, WK>(a, t, sum, smem, lane, wave, active);
+      return;
+    }
     for (int o = 0; active && o < a.ksplit; o += D) {
       floatx4 part[D][NL];
 #pragma unroll
