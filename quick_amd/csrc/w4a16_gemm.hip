@@ -1839,6 +1839,13 @@ static void launch_ring(const Plan& p, const GemmArgs& a, const Launch& L) {
     }                                                                                                              \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
+  if constexpr ((MB == 2 && PAIRS == 1 && NBUF == 4 && WK == 2) || (MB == 4 && PAIRS == 1 && NBUF == 3 && WK == 2))
+    if (p.ablate == 16 && a.G == 128) {  // phase stamps into the workspace (tools/wide_phases.py), nothing else changes
+      auto kfn = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 64, WK>;
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
+      return;
+    }
   if constexpr (MB == 2 && PAIRS == 1 && NBUF == 6 && WK == 1)
     if (p.ablate && a.G == 128) {  // timing experiments (results are wrong on purpose)
       auto kfn1 = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 1>;
@@ -1949,7 +1956,9 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
              (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr, (const half_t*)f.ln_w, f.ln_eps};
-  if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64) a.dbg = (unsigned long long*)workspace;
+  // (phase stamps: the LAST 2 MiB of the workspace, behind whatever a K split needs)
+  if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64 + workspace_need(p))
+    a.dbg = (unsigned long long*)((char*)workspace + workspace_bytes - (size_t)4096 * 8 * 64);
   a.span = L.span;
   g_span_unsupported = false;
   if (p.ksplit > 1) {

@@ -544,6 +544,8 @@ __global__ __launch_bounds__(256) void w4a16_wide_kernel(const GemmArgs a) {
 template <int MB, int PAIRS, int GM, int NBUF, int ABL = 0, int WK = 1>
 __global__ __launch_bounds__(256 * WK) void w4a16_ring_kernel(const GemmArgs a) {
   if constexpr (ABL & 32) span_stamp(a.span, 0);  // (the one "ablation" bit that changes nothing but writes the in-kernel span stamps)
+  unsigned long long ph[5];  // ABL bit 64: s_memrealtime stamps (100 MHz) at the phase boundaries, per wave, into a.dbg (tools/wide_phases.py)
+  if constexpr (ABL & 64) ph[0] = __builtin_amdgcn_s_memrealtime();
   constexpr int NG = groups_per_tile<GM>();
   constexpr int NW = 4 * WK;
   constexpr int X_BYTES = MB * 8192, W_BYTES = PAIRS * 8192, S_BYTES = NW * PAIRS * NG * 256;
@@ -621,6 +623,7 @@ __global__ __launch_bounds__(256 * WK) void w4a16_ring_kernel(const GemmArgs a) 
   WideCarry<MB, PAIRS, GM> carry;
   wide_prepare<MB, PAIRS, GM, true, WK>(carry, wc, xrd, dq);
 
+  if constexpr (ABL & 64) ph[1] = __builtin_amdgcn_s_memrealtime();
   unsigned cur = 0u, nxt = (unsigned)SLOT, fill = (unsigned)(NBUF - 1) * SLOT;  // slot offsets of stage s, s + 1, s + NBUF - 1
   for (int s = 0; s < t.nstage; ++s) {
     const int ktf = min(t.kt_lo + s + NBUF - 1, t.kt_hi - 1);
@@ -639,6 +642,7 @@ __global__ __launch_bounds__(256 * WK) void w4a16_ring_kernel(const GemmArgs a) 
     cur = nxt;
     nxt = nxt + SLOT >= (unsigned)(NBUF * SLOT) ? 0u : nxt + SLOT;
   }
+  if constexpr (ABL & 64) ph[2] = __builtin_amdgcn_s_memrealtime();
   if constexpr (WK == 2) {  // add the second K half to the first through LDS (the ring is free: drain the replayed DMAs first)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -668,8 +672,18 @@ __global__ __launch_bounds__(256 * WK) void w4a16_ring_kernel(const GemmArgs a) 
     }
     __syncthreads();  // (splitk_arrive writes its flag into the same LDS)
   }
+  if constexpr (ABL & 64) ph[3] = __builtin_amdgcn_s_memrealtime();   // (K halves added)
   wide_finish<MB, PAIRS, WK>(a, t, acc, smem, ct0, lane, wn, wk == 0);
   if constexpr (ABL & 32) span_stamp(a.span, 1);
+  if constexpr (ABL & 64) {  // (only the workgroups that finish a tile get here when K is split)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ph[4] = __builtin_amdgcn_s_memrealtime();
+    if (a.dbg && lane == 0) {
+      unsigned long long* o = a.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) o[i] = ph[i];
+    }
+  }
 }
 
 }  // namespace quick_amd
