@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, uint32_t seed) {
   if (s == 12345.678f) out[1] = s;
 }
 
-template <int NM>
-__global__ __launch_bounds__(256) void k5(float* out, int iters, uint32_t seed) {
+template <int NM, int W = 1, bool NODQ = false>
+__global__ __launch_bounds__(256 * W) void k5(float* out, int iters, uint32_t seed) {
   half8_t a[2] = {{1, 2, 3, 4, 5, 6, 7, 8}, {2, 3, 4, 5, 6, 7, 8, 9}}, b = {1, 1, 1, 1, 1, 1, 1, 1};
   floatx16 c[NM] = {};
   uint32_t mlo = 0x000f000fu, mhi = 0x00f000f0u;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k5(float* out, int iters, uint32_t seed) 
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, (15 + NM - 1) / NM, 0);
       }
-      a[u ^ 1] = half8_t{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+      if constexpr (!NODQ) a[u ^ 1] = half8_t{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -97,19 +97,27 @@ __global__ __launch_bounds__(256) void k5(float* out, int iters, uint32_t seed) 
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(t1 - t0) / (iters * NM);
   if (s == 12345.678f) out[1] = s;
 }
-template <int NM>
+template <int NM, int W = 1, bool NODQ = false>
 static void run5(float* out) {
-  hipLaunchKernelGGL((k5<NM>), dim3(256), dim3(256), 0, 0, out, 2000, 12345u);
+  hipLaunchKernelGGL((k5<NM, W, NODQ>), dim3(256), dim3(256 * W), 0, 0, out, 2000, 12345u);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((k5<NM, W, NODQ>), dim3(256), dim3(256 * W), 0, 0, out, 20000, 12345u);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  const double pf = 256.0 * 4 * W * 20000.0 * NM * 32768.0 / (ms * 1e-3) / 1e15;
   float h[2]; hipMemcpy(h, out, 8, hipMemcpyDeviceToHost);
-  printf("%d accumulators  dequant chain -> next A operand, double-buffered (13 ops per %d MFMAs): %6.1f cycles per MFMA\n", NM, NM, h[0]);
+  if (NODQ) printf("%d accumulators  MFMAs only, %d wave(s) per SIMD: %6.1f cycles per MFMA per wave = %5.1f per SIMD   (wall clock: %.2f PFLOP/s chip-wide)\n", NM, W, h[0], h[0] / W, pf);
+  else if (W > 1) printf("%d accumulators  dequant chain -> next A operand, double-buffered, %d waves per SIMD: %6.1f cycles per MFMA per wave = %5.1f per SIMD\n", NM, W, h[0], h[0] / W);
+  else printf("%d accumulators  dequant chain -> next A operand, double-buffered (13 ops per %d MFMAs): %6.1f cycles per MFMA\n", NM, NM, h[0]);
 }
 
 // KIND 6: KIND 5 plus the B operand of every MFMA read from LDS three MFMA-pairs ahead (ds_read_b128, XOR-ed address), as in
 // the kernels' K loop; LDADD extra SALU + VALU ops per unit stand in for the ring bookkeeping
-template <int NM, int EXTRA>
-__global__ __launch_bounds__(256) void k6(float* out, int iters, uint32_t seed) {
+template <int NM, int EXTRA, int W = 1>
+__global__ __launch_bounds__(256 * W) void k6(float* out, int iters, uint32_t seed) {
   __shared__ __attribute__((aligned(16))) char lds[32768];
-  for (int i = threadIdx.x; i < 32768 / 4; i += 256) ((uint32_t*)lds)[i] = 0x3c003c00u;
+  for (int i = threadIdx.x; i < 32768 / 4; i += 256 * W) ((uint32_t*)lds)[i] = 0x3c003c00u;
   __syncthreads();
   half8_t a[2] = {{1, 2, 3, 4, 5, 6, 7, 8}, {2, 3, 4, 5, 6, 7, 8, 9}};
   floatx16 c[NM] = {};
@@ -156,11 +164,12 @@ __global__ __launch_bounds__(256) void k6(float* out, int iters, uint32_t seed) 
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(t1 - t0) / (iters * NM);
   if (s == 12345.678f) out[1] = s;
 }
-template <int NM, int EXTRA>
+template <int NM, int EXTRA, int W = 1>
 static void run6(float* out) {
-  hipLaunchKernelGGL((k6<NM, EXTRA>), dim3(256), dim3(256), 0, 0, out, 2000, 12345u);
+  hipLaunchKernelGGL((k6<NM, EXTRA, W>), dim3(256), dim3(256 * W), 0, 0, out, 2000, 12345u);
   float h[2]; hipMemcpy(h, out, 8, hipMemcpyDeviceToHost);
-  printf("%d accumulators  dequant -> A (double-buffered) + B from LDS 3 units ahead + %d extra VALU per unit: %6.1f cycles per MFMA\n", NM, EXTRA, h[0]);
+  printf("%d accumulators  dequant -> A (double-buffered) + B from LDS 3 units ahead + %d extra VALU per unit, %d wave(s) per SIMD: %6.1f cycles per MFMA per wave = %5.1f per SIMD\n",
+         NM, EXTRA, W, h[0], h[0] / W);
 }
 
 template <int NV, int NM, int KIND>
@@ -180,6 +189,7 @@ int main() {
   run<0, 2, 3>(out); run<0, 4, 3>(out); run<0, 8, 3>(out);
   run<0, 2, 4>(out); run<0, 4, 4>(out); run<0, 8, 4>(out);
   run5<2>(out); run5<4>(out); run5<8>(out);
+  run5<8, 1, true>(out); run5<8, 2, true>(out);   // (wall clock: per-wave s_memtime spans do not add up to the launch with several waves per SIMD)
   run6<2, 0>(out); run6<2, 4>(out); run6<2, 8>(out); run6<4, 0>(out); run6<8, 0>(out);
   return 0;
 }
