@@ -44,6 +44,8 @@ extern "C" {
 #define QUICK_KERNEL_SKINNY 1 /* M-tiles straight from L2 to VGPRs, k split over the waves of a workgroup */
 #define QUICK_KERNEL_TILED 2  /* activations staged through LDS, MFMA-bound regime */
 #define QUICK_KERNEL_WIDE 3   /* large M: 32x32x16 MFMA, one wave per SIMD, operands by LDS-DMA (G % 128 == 0; else TILED runs) */
+#define QUICK_KERNEL_XK 4     /* 64- / 128-token tiles, eight waves, the K slices of a tile on different CUs exchange partial tiles
+                                 (G % 128 == 0; else TILED runs) */
 
 int quick_amd_abi_version(void);
 const char* quick_amd_last_error(void);
@@ -72,11 +74,13 @@ const char* quick_amd_last_error(void);
  *
  * workspace: device scratch of at least quick_w4a16_workspace_bytes(...) bytes (may be NULL when
  * that function returns 0).  It must stay valid until the work enqueued on `hip_stream` completes,
- * must be ZERO-FILLED before its first use, and is handed back zero-filled where it matters (its first
- * 64 KiB are the arrival counters of the in-kernel split-K reduction, which reset themselves; the fp32
- * partial tiles behind them are overwritten before they are read), so one zeroed buffer can be reused by
- * every later call on the same stream, whatever its shape.  Do not share it between streams that run
- * concurrently.
+ * must be ZERO-FILLED before its first use, and is handed back zero-filled where it matters -- layout:
+ * [64 KiB arrival counters of the last-arriver split-K reduction, which reset themselves][16 MiB exchange
+ * zone: the mailboxes through which the K slices of an exchange-K tile swap partial sums; every consumer
+ * zeroes what it has read][fp32 partial tiles of the last-arriver kernels, overwritten before they are read]
+ * -- so one zeroed buffer can be reused by every later call on the same stream, whatever its shape.  Do
+ * not share it between streams that run concurrently.  (A launch that is aborted -- device reset, trap --
+ * may leave the first two regions dirty: zero the buffer again before reusing it.)
  */
 int quick_w4a16_gemm_f16(const void* x, const void* qweight, const void* scales, const void* qzeros,
                          void* y, void* workspace, size_t workspace_bytes,
@@ -84,9 +88,29 @@ int quick_w4a16_gemm_f16(const void* x, const void* qweight, const void* scales,
 
 size_t quick_w4a16_workspace_bytes(int M, int K, int N, int group_size, int split_k_iters);
 
-/* Same as quick_w4a16_gemm_f16 with an explicit kernel choice (QUICK_KERNEL_*), an optional fp16
- * bias[N] added in the epilogue (NULL = none; replaces the separate torch add of
- * quick/awq/modules/linear/quick.py:165), and a forced K split across workgroups (0 = heuristic). */
+/* Same as quick_w4a16_gemm_f16 with an explicit kernel choice, an optional fp16 bias[N] added in the
+ * epilogue (NULL = none; replaces the separate torch add of quick/awq/modules/linear/quick.py:165), and a
+ * forced K split across workgroups (0 = heuristic).
+ *
+ * `kernel`: 0 = the library's planner (what every product path passes).  Otherwise, for tests and tuning, a
+ * bit field -- every field 0 = "planner's choice within the family":
+ *   bits 0-3    family, QUICK_KERNEL_*
+ *   bits 4-7    SKINNY: channel tiles of 16 per workgroup (1, 2, 4); TILED: token tiles of 16 per workgroup (2, 4, 8);
+ *               WIDE / XK: token tiles of 32 per workgroup (WIDE 2, 4, 8; XK 2, 4)
+ *   bits 8-11   SKINNY / TILED: waves per workgroup / 4; WIDE: 32-channel pairs per wave (1, 2); XK: K slices per tile (1, 2, 4, 8)
+ *   bit 12      SKINNY: no LDS copy of x; WIDE: the double-buffered kernel at every tile size (no ring)
+ *   bit 13      TILED: 32x32x16 MFMA flavour         bit 14  TILED / WIDE / XK: plain (not XCD-aware) tile order
+ *   bit 15      TILED: 2 x 4 wave grid; WIDE: eight waves per workgroup (ring kernel)
+ *   bits 16-20  timing experiments (wrong results on purpose, phase stamps): only in a QUICK_AMD_TOOLS build of the library
+ *               (`python -m quick_amd.build --tools`); the product library answers QUICK_ERR_INVALID_ARGUMENT
+ *   bit 21      SKINNY: flip the persistence default
+ *   bits 22-24  SKINNY: persistent slots per CU; WIDE: LDS ring slots; XK: x ring slots
+ *   bit 25      SKINNY: exact per-weight dequantisation (no deferred zero point)
+ *   bits 26-28  SKINNY: 26 force the table deferred-zero path, 28 no fragment deferred-zero path; TILED: 27 force 128 x 256
+ *               four-wave tiles; XK: weight queue depth in stages (3..6)
+ *   bits 29-30  TILED: force / forbid 256-channel tiles
+ * A combination the library has no build for returns QUICK_ERR_UNSUPPORTED; results never depend on the field
+ * beyond fp32 summation order (and bit 25's rounding). */
 int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scales, const void* qzeros,
                             const void* bias, void* y, void* workspace, size_t workspace_bytes,
                             int M, int K, int N, int group_size, int kernel, int grid_split_k,

@@ -1,23 +1,33 @@
 """Builds libquick_amd.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
 
-    python -m quick_amd.build [--force]
+    python -m quick_amd.build [--force] [--tools]
 
 The shared object lands in quick_amd/lib/ (git-ignored, but it travels to the GPU box with the
-working-tree snapshot).  Cross-compiles without a GPU.
+working-tree snapshot).  Cross-compiles without a GPU.  Every translation unit is compiled to its own
+object (in parallel, rebuilt only when it or a header changed) and the objects are linked.
+
+--tools builds quick_amd/lib/libquick_amd_tools.so instead: the same library plus the timing-experiment
+kernels (ablations with wrong results, phase stamps) that tools/*.py ask for through kernel-id bits 16-20
+(-DQUICK_AMD_TOOLS).  The product library contains none of them.
 """
 import hashlib
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libquick_amd.so")
-SOURCES = ["w4a16_gemm.hip", "repack.hip", "decode_ops.hip"]
-HEADERS = ["w4a16_common.hpp", "w4a16_wide.hpp", os.path.join("..", "..", "include", "quick_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
+TOOLS_LIB = os.path.join(LIBDIR, "libquick_amd_tools.so")
+SOURCES = ["w4a16_gemm.hip", "w4a16_xk.hip", "repack.hip", "decode_ops.hip"]
+HEADERS = ["w4a16_common.hpp", "w4a16_args.hpp", "w4a16_wide.hpp", "w4a16_xk.hpp", "w4a16_xk_host.hpp",
+           os.path.join("..", "..", "include", "quick_amd.h")]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"]
+FLAGS = CFLAGS + ["-shared"]   # (what the library is built with, for the record)
 
 
 def _hipcc():
@@ -27,31 +37,63 @@ def _hipcc():
     raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
 
 
-def _digest():
+def _sha(paths, extra=""):
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
-        with open(os.path.join(CSRC, f), "rb") as fh:
+    for f in paths:
+        with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(extra.encode())
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
-    os.makedirs(LIBDIR, exist_ok=True)
-    stamp = LIB + ".sha256"
-    dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
-        return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+def _digest(tools=False):
+    return _sha([os.path.join(CSRC, f) for f in SOURCES + HEADERS], " ".join(FLAGS) + (" tools" if tools else ""))
+
+
+def _compile(src, obj, flags, verbose):
+    cmd = [_hipcc()] + flags + ["-c", "-o", obj, os.path.join(CSRC, src)]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, r.stdout, r.stderr))
+
+
+def build(force=False, verbose=False, tools=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    lib = TOOLS_LIB if tools else LIB
+    stamp = lib + ".sha256"
+    dig = _digest(tools)
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return lib
+    objdir = os.path.join(LIBDIR, "obj_tools" if tools else "obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = CFLAGS + (["-DQUICK_AMD_TOOLS"] if tools else [])
+    hdr = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        want = _sha([os.path.join(CSRC, src)] + hdr, " ".join(flags))
+        ostamp = obj + ".sha256"
+        if force or not os.path.exists(obj) or not os.path.exists(ostamp) or open(ostamp).read().strip() != want:
+            jobs.append((src, obj, ostamp, want))
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        futs = [(j, ex.submit(_compile, j[0], j[1], flags, verbose)) for j in jobs]
+        for j, f in futs:
+            f.result()
+            with open(j[2], "w") as fh:
+                fh.write(j[3])
+    cmd = [_hipcc()] + LDFLAGS + ["-o", lib] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
     with open(stamp, "w") as f:
         f.write(dig)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, tools="--tools" in sys.argv))

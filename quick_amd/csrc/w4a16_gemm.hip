@@ -24,83 +24,9 @@
 #include <cstring>
 #include <vector>
 
-namespace quick_amd {
-
-struct GemmArgs {
-  const half_t* X;
-  const u32x4* QW;
-  const half_t* S;
-  const uint32_t* QZ;
-  const half_t* bias;      // [N] or null
-  const half_t* residual;  // [M, N] added in the epilogue, or null
-  int silu_mul;            // epilogue: y[m, 8t+i] = silu(acc[m, 16t+i]) * acc[m, 16t+8+i]  (gate/up interleaved by 8), Y is [M, N/2]
-  half_t* Y;
-  float* slabs;        // ksplit > 1: fp32 partial tiles, [tile][slice][slab]
-  unsigned* counters;  // ksplit > 1: one arrival counter per output tile (zero on entry, zero again on exit)
-  int M, K, N, G;
-  int tpg;     // G / 128 (group mode 1)
-  int ksplit;  // K slices across workgroups
-  int kt_per_split;
-  int xcd_gm;  // tiled: XCD-aware tile order -- the 8 XCDs form an xcd_gm x (8/xcd_gm) grid over (token, channel) blocks; 0 = plain order
-  unsigned long long* dbg;  // ablation bit 16: per-wave phase cycle totals [workgroup][wave][8]
-  const half_t* ln_w;  // deferred-zero skinny kernel: RMSNorm weight [K] applied to x on its way into LDS, or null
-  float ln_eps;
-  unsigned long long* span;  // measurement aid: per-wave start / end stamps in s_memrealtime ticks (100 MHz), see span_stamp; or null
-};
-
-// In-kernel wall-clock span of a launch: first wave's start -> last wave's end on the constant 100 MHz counter.  The
-// dispatch-duration clock (event pair / rocprofv3) cannot read below ~4.2 us -- an EMPTY kernel reads that -- so for the
-// microsecond-scale small-M launches this is the clock that can see the kernel (quick_w4a16_gemm_span, bench.py
-// roofline.frac_inkernel).  Every wave stores its own two stamps into its own slot (plain 8-byte stores: 2048 atomics on
-// one word would serialise for tens of microseconds and be the thing measured); the host takes min / max.  Costs one
-// scalar compare per wave when off.
-constexpr unsigned kSpanWaves = 1u << 16;  // slots per launch: [kSpanWaves starts][kSpanWaves ends]
-__device__ __forceinline__ void span_stamp(unsigned long long* span, int end) {
-  if (span != nullptr) {  // wave-uniform branch on purpose (all 64 lanes store the same word): a lane-0 branch at kernel entry
-    // made hipcc treat the buffer descriptors built after it as divergent (VGPRs, "invalid operand" in the LDS-DMA asm).
-    // Only the SPAN = true instantiations contain this at all: even switched off, the branch and the longer kernarg cost
-    // the M = 1 launch 7 % in an A/B session [r02].
-    const unsigned w = (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) +
-                        (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) & (kSpanWaves - 1);
-    span[(end ? kSpanWaves : 0u) + w] = __builtin_amdgcn_s_memrealtime();
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K split across workgroups, reduced inside the launch ("last arriver finishes the tile").
-// Every slice writes its fp32 partial tile to its slab with WRITE-THROUGH (sc1) 16-byte stores, drains them
-// (per-wave vmcnt(0)), and after a workgroup barrier ONE lane draws a ticket from the tile's agent-scope
-// counter.  The workgroup that draws the last ticket resets the counter (the workspace is handed back zeroed)
-// and adds the other slices' slabs -- read with sc1 loads, which bypass the reader's possibly stale L1 -- to the
-// partial it still holds in registers.  No fences (a release would write back the whole XCD L2: 2-7 us under
-// load), no spinning (so no co-residency requirement), and nothing depends on which XCD or CU a slice ran on
-// (cdna_hip_programming.md G16, form R1).  Replaces the reference's fp16 `[split_k, M, N]` scratch + torch
-// `.sum(0)` (csrc/gemm_cuda_quick.cu:1468, 1515).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(float* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ void slab_store(__amdgpu_buffer_rsrc_t r, unsigned byte_off, floatx4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, /*sc1*/ 16);
-}
-__device__ __forceinline__ floatx4 slab_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, /*sc1*/ 16));
-}
-__device__ __forceinline__ bool splitk_arrive(unsigned* counter, int nslices, unsigned* lds_word) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have landed
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = t == (unsigned)nslices - 1u;
-    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *lds_word = last ? 1u : 0u;
-  }
-  __syncthreads();
-  return *lds_word != 0u;
-}
-
-}  // namespace quick_amd
+#include "w4a16_args.hpp"
 #include "w4a16_wide.hpp"
+#include "w4a16_xk_host.hpp"
 namespace quick_amd {
 
 // ------------------------------------------------------------------------------------------------
@@ -1302,6 +1228,7 @@ struct Plan {
   bool wn2;    // tiled: 2 x 4 wave grid (kernel bit 15)
   int tch;     // tiled: channels per workgroup tile, 128 or 256
   bool mfma32; // tiled: v_mfma_f32_32x32x16_f16 flavour (kernel bit 13; measured slower than 16x16x32 in r01)
+  int xk_nbuf, xk_wd;  // exchange-K: x ring slots, weight queue depth (wide_mb = token tiles of 32, ksplit = slices that exchange)
 };
 
 // Where the main kernel goes: the stream, plus an optional event pair bound to that one dispatch
@@ -1332,6 +1259,23 @@ static size_t skinny_lds_bytes(int M, int G, int ntw, int waves, int kt_per_spli
   if (xlds) b += (size_t)std::min(M, 16) * (kt_per_split * 256 + 16);
   if (dz) b += (size_t)kt_per_split * (G >= 128 ? 1 : (G == 64 ? 2 : 4)) * 128;
   return b;
+}
+
+// compute units of the current device (256 on MI355X); 256 when there is no device to ask (plan_describe on a CPU-only host)
+static int cu_count() {
+  static thread_local int cached_dev = -2, cached = 256;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  if (dev != cached_dev) {
+    int n = 0;
+    cached = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    (void)hipGetLastError();
+    cached_dev = dev;
+  }
+  return cached;
 }
 
 // `kernel`: low 4 bits = family (QUICK_KERNEL_*), bits 4-7 = token tiles (tiled) / channel tiles per workgroup (skinny),
@@ -1466,8 +1410,46 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     else if (model_tiled_mt) p.kernel = QUICK_KERNEL_TILED;
   }
   int ks = 1;
-  if (p.kernel == QUICK_KERNEL_WIDE && G % 128 != 0) p.kernel = QUICK_KERNEL_TILED;  // small groups: r01's tiled kernel
-  if (p.kernel == QUICK_KERNEL_WIDE) {
+  if ((p.kernel == QUICK_KERNEL_WIDE || p.kernel == QUICK_KERNEL_XK) && G % 128 != 0) p.kernel = QUICK_KERNEL_TILED;  // small groups: r01's tiled kernel
+  // x travels through a buffer descriptor with 32-bit offsets in the wide / exchange-K kernels: from 4 GiB of activations on, r01's
+  // tiled kernel (64-bit pointers) runs instead
+  if ((p.kernel == QUICK_KERNEL_WIDE || p.kernel == QUICK_KERNEL_XK) && (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32)) p.kernel = QUICK_KERNEL_TILED;
+  if (p.kernel == QUICK_KERNEL_XK) {
+    // exchange-K kernels (w4a16_xk.hpp): tile = mb * 32 tokens x 128 channels, eight waves; the S slices of a tile run on S compute
+    // units at the same time and swap parts of their partial tiles, so S > 1 needs the whole grid co-resident: tiles * S <= CUs.
+    // bits 4-7: mb (2, 4; 0 = by M), bits 8-11: S (1, 2, 4, 8; 0 = as many as fit), bits 22-24: x ring slots, bits 26-28: weight queue depth
+    const int mb = (mt_req == 2 || mt_req == 4) ? mt_req : (M > 64 ? 4 : 2);
+    const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / 128;
+    const int cus = cu_count();
+    p.wide_mb = mb;
+    p.wide_pairs = 1;
+    p.tch = 128;
+    p.waves = 8;
+    p.ntiles = MBk * NBk;
+    const int s_req = grid_split_k > 0 ? grid_split_k : (kernel >> 8) & 15;
+    int s = 1;
+    if (s_req == 1 || s_req == 2 || s_req == 4 || s_req == 8) s = s_req;
+    else
+      while (s < 8 && (long)p.ntiles * s * 2 <= cus && KT / (s * 2) >= 4) s *= 2;
+    // (the slices must fit the chip, and ceil-dividing K must give exactly S non-empty slices)
+    while (s > 1 && ((long)p.ntiles * s > cus || (KT + (KT + s - 1) / s - 1) / ((KT + s - 1) / s) != s)) s /= 2;
+    p.ksplit = s;
+    p.kt_per_split = (KT + s - 1) / s;
+    const int nb_req = (kernel >> 22) & 7, wd_req = (kernel >> 26) & 7;
+    p.xk_nbuf = nb_req >= 3 ? nb_req : 5;
+    p.xk_wd = wd_req >= 3 ? wd_req : 4;
+    const int groups = 8 / s;  // XCDs per K slice: they form a gm x gn grid over the (token, channel) tiles
+    long best = -1;
+    if (!((kernel >> 14) & 1) && ((long)p.ntiles * s) % 8 == 0)
+      for (int gm = 1; gm <= groups; gm *= 2) {
+        if (MBk % gm != 0 || NBk % (groups / gm) != 0) continue;
+        const long cost = (long)(MBk / gm) * 64 * mb + (long)(NBk * gm / groups) * 64;  // bytes per k and XCD: x rows (2 B) + weight columns (1/2 B)
+        if (best < 0 || cost < best) {
+          best = cost;
+          p.xcd_gm = gm;
+        }
+      }
+  } else if (p.kernel == QUICK_KERNEL_WIDE) {
     // bits 4-7: MB (token tiles of 32 per workgroup: 2, 4, 8), bits 8-11: PAIRS (32-channel pairs per wave: 1, 2); 0 = choose
     int mb = wide_mb ? wide_mb : mt_req, pairs = wide_mb ? wide_pairs : (kernel >> 8) & 15;
     if (mb != 2 && mb != 4 && mb != 8) mb = M > 128 ? 8 : (M > 64 ? 4 : 2);
@@ -1675,13 +1657,19 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   return p;
 }
 
-// workspace: [64 KiB of arrival counters, one per output tile][ntiles * ksplit fp32 slabs]
+// workspace: [64 KiB of arrival counters, one per output tile][exchange zone][ntiles * ksplit fp32 slabs]
 // The counter region has a FIXED size: the slabs are not handed back zeroed, so a region that grew with the tile count
 // would lay the counters of one launch over the stale partial sums of an earlier, smaller one.
 static constexpr int kMaxSplitTiles = 16384;
 static size_t counters_bytes(const Plan&) { return (size_t)kMaxSplitTiles * 4; }
+// ... and behind the counters a FIXED 16 MiB "exchange zone": the mailboxes of the exchange-K kernels (w4a16_xk.hpp), all-zero
+// between launches (every consumer zeroes what it has read); the slabs of the last-arriver kernels start behind it and never
+// touch it.  Layout: [64 KiB counters][16 MiB exchange zone][ntiles * ksplit fp32 slabs].
+static size_t slabs_offset(const Plan& p) { return counters_bytes(p) + kXkZoneBytesHost; }
 static size_t workspace_need(const Plan& p) {
-  return p.ksplit > 1 ? counters_bytes(p) + (size_t)p.ntiles * p.ksplit * p.slab_floats * sizeof(float) : 0;
+  if (p.ksplit <= 1) return 0;
+  if (p.kernel == QUICK_KERNEL_XK) return slabs_offset(p);
+  return slabs_offset(p) + (size_t)p.ntiles * p.ksplit * p.slab_floats * sizeof(float);
 }
 
 static int group_mode(int G) { return G == 128 ? 0 : (G % 128 == 0 ? 1 : (G == 64 ? 2 : (G == 32 ? 3 : 4))); }
@@ -1777,6 +1765,7 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
     }                                                                                                              \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
+#ifdef QUICK_AMD_TOOLS
   if constexpr (BMT == 4 && WN == 4 && TCH == 128) if (p.ablate && a.G == 128) {  // timing experiments (tools/): results are wrong on purpose
     switch (p.ablate) {
       case 1: QA_TILED_K(0, 1); return;
@@ -1794,6 +1783,7 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
       default: break;
     }
   }
+#endif
   if constexpr (WN == 4 && TCH == 128) if (p.mfma32) {
 #define QA_TILED32_K(GMV)                                                                                          \
   do {                                                                                                             \
@@ -1839,6 +1829,7 @@ static void launch_ring(const Plan& p, const GemmArgs& a, const Launch& L) {
     }                                                                                                              \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
+#ifdef QUICK_AMD_TOOLS
   if constexpr ((MB == 2 && PAIRS == 1 && NBUF == 4 && WK == 2) || (MB == 4 && PAIRS == 1 && NBUF == 3 && WK == 2))
     if (p.ablate == 16 && a.G == 128) {  // phase stamps into the workspace (tools/wide_phases.py), nothing else changes
       auto kfn = w4a16_ring_kernel<MB, PAIRS, 0, NBUF, 64, WK>;
@@ -1867,6 +1858,7 @@ static void launch_ring(const Plan& p, const GemmArgs& a, const Launch& L) {
       hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
       return;
     }
+#endif
   if (a.span) {
     if constexpr (MB == 2 && PAIRS == 1 && ((NBUF == 6 && WK == 1) || (NBUF == 4 && WK == 2))) {
       if (group_mode(a.G) == 0) {
@@ -1920,6 +1912,7 @@ static void launch_wide(const Plan& p, const GemmArgs& a, const Launch& L) {
     }                                                                                                              \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
+#ifdef QUICK_AMD_TOOLS
   if constexpr ((MB == 2 && PAIRS == 1) || (MB == 8 && PAIRS == 2))
     if (p.ablate && a.G == 128) {  // timing experiments (results are wrong on purpose)
       auto kfn1 = w4a16_wide_kernel<MB, PAIRS, 0, 1>;
@@ -1930,6 +1923,7 @@ static void launch_wide(const Plan& p, const GemmArgs& a, const Launch& L) {
       hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
       return;
     }
+#endif
   if (group_mode(a.G) == 0) QA_WIDE_K(0);
   else QA_WIDE_K(1);
 #undef QA_WIDE_K
@@ -1947,8 +1941,12 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
                     void* workspace, size_t workspace_bytes, int M, int K, int N, int G, int kernel, int grid_split_k,
                     const Launch& L) {
   if (int rc = check_shapes(M, K, N, G)) return rc;
+  if ((kernel & 15) > QUICK_KERNEL_XK || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+#ifndef QUICK_AMD_TOOLS
+  if ((kernel >> 16) & 31)  // the timing-experiment builds (wrong results on purpose, phase stamps) are not in the product library
+    return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: bits 16-20 select timing experiments that only a QUICK_AMD_TOOLS build contains", kernel);
+#endif
   if (!x || !qweight || !scales || !qzeros || !y) return fail(QUICK_ERR_INVALID_ARGUMENT, "null tensor pointer");
-  if ((kernel & 15) > QUICK_KERNEL_WIDE || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
   const Plan p = make_plan(M, K, N, G, kernel, grid_split_k);
   if (f.silu_mul && (f.bias || f.residual)) return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual");
   if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
@@ -1967,9 +1965,17 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     if (!workspace || workspace_bytes < need)
       return fail(QUICK_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     a.counters = (unsigned*)workspace;  // zero on entry (caller's contract), zero again when the launch completes
-    a.slabs = (float*)((char*)workspace + counters_bytes(p));
+    a.slabs = (float*)((char*)workspace + (p.kernel == QUICK_KERNEL_XK ? counters_bytes(p) : slabs_offset(p)));  // (exchange-K: the zone)
   }
-  if (p.kernel == QUICK_KERNEL_WIDE) {
+  if (p.kernel == QUICK_KERNEL_XK) {
+    if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
+    if (a.span || (f.silu_mul && (p.wide_mb / 2 * 16) % (16 * p.ksplit) != 0))
+      return fail(QUICK_ERR_UNSUPPORTED, "exchange-K kernels: no span stamps; SiLU * mul only where a wave finishes whole 32-token blocks");
+    const int abl = p.ablate == 16 ? 64 : p.ablate;  // (tools builds: 16 = phase stamps, 4 = no exchange, 1 / 2 = no compute / no loads)
+    if (!xk_launch(XkConfig{p.wide_mb, p.ksplit, p.xk_nbuf, p.xk_wd, abl}, a, p.ntiles * p.ksplit, L.st, L.start, L.stop))
+      return fail(QUICK_ERR_UNSUPPORTED, "no exchange-K build for tokens=%d slices=%d ring=%d queue=%d%s", p.wide_mb * 32, p.ksplit, p.xk_nbuf,
+                  p.xk_wd, abl ? " (timing-experiment bits need a QUICK_AMD_TOOLS build)" : "");
+  } else if (p.kernel == QUICK_KERNEL_WIDE) {
     if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
     const int sel = p.wide_mb * 10 + p.wide_pairs;
     switch (sel) {
@@ -2062,6 +2068,9 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
     snprintf(text, text_bytes, "skinny ntw=%d waves=%d x=%s dequant=%s grid=%dx%dx%d ksplit=%d workspace=%zu", p.mt, p.waves,
              p.xlds ? "lds" : "l2", p.dz ? (p.xlds ? "deferred-zero-table" : "deferred-zero-fragment") : "exact", p.grid_x,
              (M + 15) / 16, p.ksplit, p.ksplit, workspace_need(p));
+  else if (p.kernel == QUICK_KERNEL_XK)
+    snprintf(text, text_bytes, "xk tokens=%d channels=128 waves=8 ring=%d queue=%d grid=%d slices=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
+             p.xk_nbuf, p.xk_wd, p.ntiles * p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_WIDE)
     snprintf(text, text_bytes, "wide tokens=%d channels=%d waves=%d ring=%d grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
              p.tch, p.waves, p.wide_nbuf, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));

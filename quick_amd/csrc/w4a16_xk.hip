@@ -1,0 +1,80 @@
+// Exchange-K kernels: instantiations and launcher (see w4a16_xk.hpp).  Its own translation unit so that the library builds in parallel.
+#include "w4a16_common.hpp"
+
+#include <hip/hip_ext.h>
+
+#include "w4a16_args.hpp"
+#include "w4a16_wide.hpp"
+#include "w4a16_xk.hpp"
+#include "w4a16_xk_host.hpp"
+
+namespace quick_amd {
+
+static_assert(kXkZoneBytesHost == kXkZoneBytes, "exchange zone size");
+
+XkConfig xk_default_config(int mb, int s) { return XkConfig{mb, s, 5, 4, 0}; }
+
+template <int MB, int NBUF, int WD, int S, int ABL = 0>
+static bool xk_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+  constexpr unsigned lds = NBUF * MB * 8192;
+  const dim3 grid(workgroups), block(512);
+  const int gm = a.G == 128 ? 0 : (a.G % 128 == 0 ? 1 : -1);
+  if (gm < 0) return false;
+#define QA_XK_K(GMV)                                                                                               \
+  do {                                                                                                             \
+    auto kfn = w4a16_xk_kernel<MB, GMV, NBUF, WD, S, ABL>;                                                         \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipExtLaunchKernelGGL(kfn, grid, block, lds, st, start, stop, 0, a);                                           \
+  } while (0)
+  if constexpr (ABL != 0) {
+    if (gm != 0) return false;
+    QA_XK_K(0);
+  } else {
+    if (gm == 0) QA_XK_K(0);
+    else QA_XK_K(1);
+  }
+#undef QA_XK_K
+  return true;
+}
+
+template <int MB, int NBUF, int WD, int ABL = 0>
+static bool xk_go_s(int s, const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+  switch (s) {
+    case 1: return xk_go<MB, NBUF, WD, 1, ABL>(a, workgroups, st, start, stop);
+    case 2: return xk_go<MB, NBUF, WD, 2, ABL>(a, workgroups, st, start, stop);
+    case 4: return xk_go<MB, NBUF, WD, 4, ABL>(a, workgroups, st, start, stop);
+    case 8: return xk_go<MB, NBUF, WD, 8, ABL>(a, workgroups, st, start, stop);
+    default: return false;
+  }
+}
+
+bool xk_launch(const XkConfig& c, const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+  const int key = c.mb * 100 + c.nbuf * 10 + c.wd;
+#ifdef QUICK_AMD_TOOLS
+  if (c.abl) {  // timing experiments (tools builds): phase stamps, and the launch without the cross-CU exchange (wrong results)
+    if (key == 454 && c.s == 2 && c.abl == 64) return xk_go<4, 5, 4, 2, 64>(a, workgroups, st, start, stop);
+    if (key == 454 && c.s == 2 && c.abl == 4) return xk_go<4, 5, 4, 2, 4>(a, workgroups, st, start, stop);
+    if (key == 454 && c.s == 2 && c.abl == 2) return xk_go<4, 5, 4, 2, 2>(a, workgroups, st, start, stop);
+    if (key == 454 && c.s == 2 && c.abl == 1) return xk_go<4, 5, 4, 2, 1>(a, workgroups, st, start, stop);
+    if (key == 254 && c.s == 8 && c.abl == 64) return xk_go<2, 5, 4, 8, 64>(a, workgroups, st, start, stop);
+    return false;
+  }
+  // ring / queue geometries that only the tuning sweeps ask for
+  if (key == 444) return xk_go_s<4, 4, 4>(c.s, a, workgroups, st, start, stop);
+  if (key == 445) return xk_go_s<4, 4, 5>(c.s, a, workgroups, st, start, stop);
+  if (key == 455) return xk_go_s<4, 5, 5>(c.s, a, workgroups, st, start, stop);
+  if (key == 456) return xk_go_s<4, 5, 6>(c.s, a, workgroups, st, start, stop);
+  if (key == 244) return xk_go_s<2, 4, 4>(c.s, a, workgroups, st, start, stop);
+#else
+  if (c.abl) return false;
+#endif
+  if (key == 454) return xk_go_s<4, 5, 4>(c.s, a, workgroups, st, start, stop);
+  if (key == 254) return xk_go_s<2, 5, 4>(c.s, a, workgroups, st, start, stop);
+  return false;
+}
+
+}  // namespace quick_amd

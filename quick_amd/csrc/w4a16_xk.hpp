@@ -1,0 +1,472 @@
+// "Exchange-K" kernels (r03): 128- / 64-token tiles whose K slices live on DIFFERENT compute units and meet without a
+// last arriver -- the co-resident slices of a tile swap parts of their fp32 partial tiles through write-through mailboxes and
+// each finishes its own part.  Replaces the reference's `[split_k, M, N]` scratch + torch `.sum(0)`
+// (csrc/gemm_cuda_quick.cu:1468, 1515) where a tile count below the CU count forces a K split (M = 64 .. 512 on 4096^2).
+//
+// Shape: tile = MB*32 tokens x 128 channels, EIGHT waves = 4 along N x 2 along the k16 steps of a stage (two per SIMD: one
+// wave alone issues at most ~5 instructions per 32-cycle MFMA, and a 128-token wave needs 4.3 -- 13 VALU of dequantisation + 4
+// B-fragment reads per 4 MFMAs -- before any load or wait; two waves issue VALU, LDS, SALU and vector-memory instructions
+// side by side).  A wave owns all MB*32 tokens x 32 channels for the k16 steps of its parity: 13 / MB VALU per MFMA.
+//
+// Pipeline (what r02's ring kernel could not do at 128 tokens -- three 41 KiB slots = vmcnt(0) every stage):
+//   x        LDS-DMA into a ring of NBUF slots of MB*8 KiB (x only), NBUF - 3 whole stages in flight behind a counted vmcnt;
+//   weights  HBM -> registers directly, WD stages ahead, into a queue of ACCUMULATION registers (a[0 : 5 WD)): the loads are
+//            inline asm that names the AGPRs, so the compiler neither sees an asynchronous result it could copy too early nor
+//            spends VGPRs on the queue; a landed set is moved to VGPRs (5 v_accvgpr_read) one stage before use;
+//   all vector-memory instructions are asm, every wait is an explicit counted s_waitcnt (hipcc's own waitcnt pass only sees
+//   the LDS reads).
+//
+// The way out, S = K slices of a tile on S compute units (S = 1: no exchange):
+//   1. the two K parities of a channel quarter swap halves through LDS: wave (wn, wk) ends up with blocks wk*MB/2 .. of 32 tokens;
+//   2. each wave's holding (MB/2 * 16 registers) is cut into S parts; part p goes to slice p's mailbox with 16-byte write-through
+//      (sc1) stores -- NEGATED, and never -0.0, so that a stored word is never 0x00000000 -- and the receiving wave polls the
+//      mailbox words themselves (sc1 loads) until none is zero: no flag, no atomic, no drain on the producer's side.  The
+//      consumer zeroes the mailbox again (the workspace's "exchange zone" is all-zero between launches).  Sums are taken in
+//      slice order, so a result does not depend on timing.  The poll is bounded and traps: the protocol needs the S slices of
+//      a tile co-resident, which the host guarantees by launching at most one workgroup per CU (make_plan).
+//   3. S <= 2 with whole 32-token blocks per wave: f16 image of the finished rows in LDS, whole rows to y (as wide_store_tile);
+//      otherwise 8-byte stores straight from the registers (the tiles of those launches are small).
+#pragma once
+
+#include <utility>
+
+namespace quick_amd {
+
+// ------------------------------------------------------------------------------------------------
+// the weight queue in accumulation registers: set J = a[4 J : 4 J + 3] (16 bytes of packed weights) + a[24 + J] ((scale, zero) word)
+// ------------------------------------------------------------------------------------------------
+template <int J>
+struct XkSet;
+#define QA_XK_SET(J, A0, A1, A2, A3, AS)                                                                                      \
+  template <>                                                                                                                 \
+  struct XkSet<J> {                                                                                                           \
+    static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rw, unsigned vw, unsigned sw, __amdgpu_buffer_rsrc_t rs, \
+                                                 unsigned vs, unsigned ss) {                                                  \
+      asm volatile("buffer_load_dwordx4 a[" #A0 ":" #A3 "], %0, %1, %2 offen\n\tbuffer_load_dword a" #AS ", %3, %4, %5 offen" \
+                   :: "v"(vw), "s"(rw), "s"(sw), "v"(vs), "s"(rs), "s"(ss)                                                    \
+                   : "memory", "a" #A0, "a" #A1, "a" #A2, "a" #A3, "a" #AS);                                                  \
+    }                                                                                                                         \
+    static __device__ __forceinline__ void read(u32x4& q, uint32_t& sz) {                                                     \
+      uint32_t q0, q1, q2, q3, s;                                                                                             \
+      asm volatile("v_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1 "\n\tv_accvgpr_read_b32 %2, a" #A2      \
+                   "\n\tv_accvgpr_read_b32 %3, a" #A3 "\n\tv_accvgpr_read_b32 %4, a" #AS                                      \
+                   : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(s));                                                        \
+      q = u32x4{q0, q1, q2, q3};                                                                                              \
+      sz = s;                                                                                                                 \
+    }                                                                                                                         \
+  };
+QA_XK_SET(0, 0, 1, 2, 3, 24)
+QA_XK_SET(1, 4, 5, 6, 7, 25)
+QA_XK_SET(2, 8, 9, 10, 11, 26)
+QA_XK_SET(3, 12, 13, 14, 15, 27)
+QA_XK_SET(4, 16, 17, 18, 19, 28)
+QA_XK_SET(5, 20, 21, 22, 23, 29)
+#undef QA_XK_SET
+
+template <int V>
+using xk_ic = std::integral_constant<int, V>;
+
+// ------------------------------------------------------------------------------------------------
+// mailbox traffic (exchange zone of the workspace): all asm, see the header comment
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void xk_mail_store(__amdgpu_buffer_rsrc_t r, unsigned off, floatx4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, /*sc1*/ 16);
+}
+__device__ __forceinline__ void xk_mail_store(__amdgpu_buffer_rsrc_t r, unsigned off, float v0, float v1) {
+  __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(uint32_t, v0), __builtin_bit_cast(uint32_t, v1)}, r, off, 0, /*sc1*/ 16);
+}
+// N granules of 16 bytes, `stride` bytes apart, loaded AND waited for inside one asm statement (the results are valid where
+// the compiler believes they are)
+template <int N>
+__device__ __forceinline__ void xk_mail_load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned stride, u32x4 (&v)[N]) {
+  static_assert(N >= 1 && N <= 4, "granules per mailbox load");
+  const unsigned o1 = off + stride, o2 = off + 2 * stride, o3 = off + 3 * stride;
+  if constexpr (N == 1)
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(off), "s"(r) : "memory");
+  else if constexpr (N == 2)
+    asm volatile("buffer_load_dwordx4 %0, %2, %4, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %3, %4, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(off), "v"(o1), "s"(r) : "memory");
+  else if constexpr (N == 3)
+    asm volatile("buffer_load_dwordx4 %0, %3, %6, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %4, %6, 0 offen sc1\n\t"
+                 "buffer_load_dwordx4 %2, %5, %6, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(off), "v"(o1), "v"(o2), "s"(r) : "memory");
+  else
+    asm volatile("buffer_load_dwordx4 %0, %4, %8, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %5, %8, 0 offen sc1\n\t"
+                 "buffer_load_dwordx4 %2, %6, %8, 0 offen sc1\n\tbuffer_load_dwordx4 %3, %7, %8, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(off), "v"(o1), "v"(o2), "v"(o3), "s"(r) : "memory");
+}
+__device__ __forceinline__ u32x2 xk_mail_load8(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  u32x2 v;
+  asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(off), "s"(r) : "memory");
+  return v;
+}
+
+// tile / slice coordinates.  XCD-aware order (a.xcd_gm > 0): workgroup b runs on XCD b % 8; XCD x serves K slice x % S only, and the
+// 8 / S XCDs of a slice form an xcd_gm x gn grid over the (token, channel) tiles, each taking a compact rectangle -- its L2 fetches
+// the x rows and weight columns of that rectangle for ONE K slice.  The S slices of a tile are S consecutive workgroups either way.
+struct XkTile {
+  int mb, nb, ks, tile, kt_lo, kt_hi, nstage, m0;
+};
+template <int MB, int S>
+__device__ __forceinline__ XkTile xk_tile(const GemmArgs& a) {
+  XkTile t;
+  const int NB = a.N >> 7, MBk = (a.M + MB * 32 - 1) / (MB * 32);
+  const int b = blockIdx.x;
+  if (a.xcd_gm > 0) {
+    const int xcd = b & 7, idx = b >> 3;
+    t.ks = xcd % S;
+    const int g = xcd / S, gn = (8 / S) / a.xcd_gm;
+    const int mcnt = MBk / a.xcd_gm, ncnt = NB / gn;
+    t.mb = (g / gn) * mcnt + idx / ncnt;
+    t.nb = (g % gn) * ncnt + idx % ncnt;
+  } else {
+    t.ks = b % S;
+    t.mb = (b / S) / NB;
+    t.nb = (b / S) % NB;
+  }
+  t.tile = t.mb * NB + t.nb;
+  const int KT = a.K >> 7;
+  t.kt_lo = t.ks * a.kt_per_split;
+  t.kt_hi = min(KT, t.kt_lo + a.kt_per_split);
+  t.nstage = t.kt_hi - t.kt_lo;
+  t.m0 = t.mb * MB * 32;
+  return t;
+}
+
+constexpr unsigned kXkZoneBytes = 16u << 20;   // exchange zone of the workspace (all-zero between launches), see workspace_need()
+constexpr unsigned kXkPollLimit = 1u << 22;    // polls of ~1 us before a wave gives up and traps (a slice that never came)
+
+// ABL (tools builds only): 64 = s_memrealtime stamps at the phase boundaries of every wave into a.dbg; 4 = no cross-CU exchange (the
+// own part is finished without the other slices: wrong results, the launch minus the exchange); 1 / 2 as in wide_compute.
+template <int MB, int GM, int NBUF, int WD, int S, int ABL = 0>
+__global__ __launch_bounds__(512) void w4a16_xk_kernel(const GemmArgs a) {
+  constexpr int NW = 8, NG = 1;
+  constexpr int SLOT = MB * 8192;
+  constexpr int XI = MB;       // x LDS-DMA instructions per wave and stage (MB * 32 rows / (8 waves * 4 rows))
+  constexpr int L = XI + 2;    // vector-memory instructions per wave and stage (+ weights, + (scale, zero) word)
+  constexpr int NU = 4;        // units (k16 steps of this wave's parity) per stage
+  constexpr int PEND = (NBUF - 3) * L;
+  static_assert(GM <= 1 && (MB == 2 || MB == 4), "G % 128 == 0, 64- or 128-token tiles");
+  static_assert(NBUF >= 3 && NBUF * SLOT <= 160 * 1024 && WD >= NBUF - 1 && WD >= 3 && WD <= 6 && PEND <= 63, "ring / queue geometry");
+  static_assert(S == 1 || S == 2 || S == 4 || S == 8, "K slices per tile");
+  static_assert(MB * 16384 <= NBUF * SLOT, "the K-parity exchange must fit in the ring");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF * SLOT
+
+  unsigned long long ph[6];
+  if constexpr (ABL & 64) ph[0] = __builtin_amdgcn_s_memrealtime();
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int wn = wave & 3, wk = wave >> 2;
+  const int rho = lane & 31, h = lane >> 5;
+  const XkTile t = xk_tile<MB, S>(a);
+  const int ct0 = (t.nb * 4 + wn) * 2;
+  const WideBufs<XI> b = wide_bufs<MB, 1, 2>(a, t.m0, ct0, lane, wave);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned xdst = lds_base + (unsigned)wave * 1024u;  // + slot + i * 8 KiB
+  const unsigned xrd = (lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4)) ^ ((unsigned)wk << 5);
+
+  auto issue_x = [&](int i, int kt, unsigned slot) { lds_dma16(b.x, b.x_voff[i], (unsigned)kt * 256u, xdst + slot + i * (NW * 1024)); };
+  auto issue_w = [&](auto jc, int kt) {
+    const unsigned g = (unsigned)group_index<GM>(kt, 0, a.tpg, a.G);
+    XkSet<decltype(jc)::value>::issue(b.w, b.w_voff, (unsigned)kt * 1024u, b.s, b.s_voff, g * 64u);
+  };
+  auto read_w = [&](auto jc, WideW<1, GM>& w) {
+    XkSet<decltype(jc)::value>::read(w.lo[0], w.sz[0][0]);
+    w.hi[0] = w.lo[0];
+  };
+
+  floatx16 acc[1][MB];
+  wide_zero<MB, 1>(acc);
+  const DqConsts dq = make_dq_consts();
+
+  // prologue, in the order the steady state would have issued it: [W(0 .. WD - NBUF)], then W(WD - NBUF + 1 + q), X(q) for q = 0 .. NBUF - 2
+  {
+    auto pro_w = [&](auto jc) { issue_w(jc, min(t.kt_lo + decltype(jc)::value, t.kt_hi - 1)); };
+    auto pro_x = [&](int q) {
+      const int kt = min(t.kt_lo + q, t.kt_hi - 1);
+#pragma unroll
+      for (int i = 0; i < XI; ++i) issue_x(i, kt, (unsigned)q * SLOT);
+    };
+    constexpr int E = WD - NBUF + 1;  // sets issued ahead of the first x stage
+    if constexpr (E > 0) pro_w(xk_ic<0>{});
+    if constexpr (E > 1) pro_w(xk_ic<1>{});
+    if constexpr (E > 2) pro_w(xk_ic<2>{});
+    if constexpr (E > 3) pro_w(xk_ic<3>{});
+    pro_w(xk_ic<E>{});
+    pro_x(0);
+    if constexpr (NBUF > 2) { pro_w(xk_ic<E + 1>{}); pro_x(1); }
+    if constexpr (NBUF > 3) { pro_w(xk_ic<E + 2>{}); pro_x(2); }
+    if constexpr (NBUF > 4) { pro_w(xk_ic<E + 3>{}); pro_x(3); }
+    static_assert(NBUF <= 5, "prologue written out for up to five slots");
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");  // x stages 0 and 1, weight sets 0 and 1 have landed
+  __builtin_amdgcn_s_barrier();
+  WideW<1, GM> wc, wnx;
+  read_w(xk_ic<0>{}, wc);
+  WideCarry<MB, 1, GM> carry;
+  wide_prepare<MB, 1, GM, true, 2>(carry, wc, xrd, dq);
+  if (wk) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses every VALU arbitration otherwise (MI355X_MICROARCH.md, two waves per SIMD)
+  if constexpr (ABL & 64) ph[1] = __builtin_amdgcn_s_memrealtime();
+
+  unsigned cur = 0u, nxt = (unsigned)SLOT, fill = (unsigned)(NBUF - 1) * SLOT;  // slots of stage s, s + 1, s + NBUF - 1
+  auto stage = [&](auto jc, int s) __attribute__((always_inline)) {
+    constexpr int J = decltype(jc)::value;
+    const int ktx = min(t.kt_lo + s + NBUF - 1, t.kt_hi - 1), ktw = min(t.kt_lo + s + WD, t.kt_hi - 1);
+    read_w(xk_ic<(J + 1) % WD>{}, wnx);  // W(s + 1): landed since the wait that ended stage s - 1
+    wide_compute<MB, 1, GM, (ABL & 3), true, 2>(wc, wnx, xrd + cur, xrd + nxt, dq, acc, carry, [&](int u) {
+      if constexpr (!(ABL & 2)) {
+        if (u == 0) issue_w(xk_ic<J>{}, ktw);  // set J held W(s), which has been in VGPRs since stage s - 1
+        constexpr int PER = XI / 2;            // x pieces with units 1 and 2 (nothing with the last unit of the stage)
+        if (u == 1 || u == 2) {
+#pragma unroll
+          for (int i = 0; i < PER; ++i) issue_x((u - 1) * PER + i, ktx, fill);
+        }
+      }
+    });
+    if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");  // x stage s + 2 and weight set s + 2 have landed ...
+    __builtin_amdgcn_s_barrier();                                                         // ... in every wave; everybody is done with x stage s
+    wc = wnx;
+    fill = cur;
+    cur = nxt;
+    nxt = nxt + SLOT >= (unsigned)(NBUF * SLOT) ? 0u : nxt + SLOT;
+  };
+  for (int base = 0; base < t.nstage; base += WD) {
+    stage(xk_ic<0>{}, base);
+    if (base + 1 < t.nstage) stage(xk_ic<1>{}, base + 1);
+    if (base + 2 < t.nstage) stage(xk_ic<2>{}, base + 2);
+    if constexpr (WD > 3) if (base + 3 < t.nstage) stage(xk_ic<3 % WD>{}, base + 3);
+    if constexpr (WD > 4) if (base + 4 < t.nstage) stage(xk_ic<4 % WD>{}, base + 4);
+    if constexpr (WD > 5) if (base + 5 < t.nstage) stage(xk_ic<5 % WD>{}, base + 5);
+  }
+  if (wk) __builtin_amdgcn_s_setprio(0);
+  if constexpr (ABL & 64) ph[2] = __builtin_amdgcn_s_memrealtime();
+
+  // ---- 1. the two K parities of a channel quarter swap halves through LDS ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the replayed loads of the last stages)
+  __builtin_amdgcn_s_barrier();                     // the ring is free
+  constexpr int HB = MB / 2;                        // 32-token blocks a wave keeps: blocks wk * HB .. + HB - 1
+  floatx16 part[HB];
+  {
+    floatx4* ex = (floatx4*)smem;  // inbox [wave][HB * 4 quads][lane]
+    floatx4* out = ex + (size_t)((wn + 4 * (1 - wk)) * (HB * 4)) * 64 + lane;
+    const floatx4* in = ex + (size_t)(wave * (HB * 4)) * 64 + lane;
+    auto swap = [&](auto wkc) __attribute__((always_inline)) {
+      constexpr int WKV = decltype(wkc)::value;
+#pragma unroll
+      for (int j = 0; j < HB; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const floatx16& v = acc[0][(1 - WKV) * HB + j];
+          out[(j * 4 + c) * 64] = floatx4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
+        }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < HB; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const floatx4 v = in[(j * 4 + c) * 64];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[j][4 * c + r] = acc[0][WKV * HB + j][4 * c + r] + v[r];
+        }
+    };
+    if (wk == 0) swap(xk_ic<0>{});
+    else swap(xk_ic<1>{});
+  }
+  if constexpr (ABL & 64) ph[3] = __builtin_amdgcn_s_memrealtime();
+
+  // ---- 2. the S slices of the tile swap parts through the mailboxes ----
+  constexpr int H = HB * 16, P = H / S;       // registers a wave holds / finishes
+  constexpr int GR = P >= 4 ? 4 : 2;          // registers per mailbox granule
+  constexpr int NGR = P / GR;                 // granules per part
+  static_assert(P >= 2 && P % GR == 0, "part size");
+  float fin[P];
+  auto flat = [&](int f) { return part[f / 16][f % 16]; };
+  if constexpr (S == 1) {
+#pragma unroll
+    for (int f = 0; f < P; ++f) fin[f] = flat(f);
+  } else {
+    // mailbox [tile][dst][src < dst ? src : src - 1][wave][granule][lane] x GR * 4 bytes
+    constexpr unsigned GBYTES = GR * 4 * 64, WBYTES = NGR * GBYTES, BOX = 8 * WBYTES;
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.slabs, 0, kXkZoneBytes, 0x00020000);
+    const unsigned tbase = (unsigned)t.tile * (unsigned)(S * (S - 1)) * BOX + (unsigned)wave * WBYTES + (unsigned)lane * (GR * 4);
+    auto exchange = [&](auto ksc) __attribute__((always_inline)) {
+      constexpr int KS = decltype(ksc)::value;
+      // send: part p to slice p, negated and never -0.0 (so never the bit pattern 0): w = v + 0.0 is never -0.0, -0.0 - w is -w exactly
+#pragma unroll
+      for (int p = 0; p < S; ++p) {
+        if (p == KS) continue;
+        const unsigned box = tbase + (unsigned)(p * (S - 1) + (KS < p ? KS : KS - 1)) * BOX;
+#pragma unroll
+        for (int g = 0; g < NGR; ++g) {
+          float v[GR];
+#pragma unroll
+          for (int r = 0; r < GR; ++r) v[r] = -0.0f - (flat(p * P + g * GR + r) + 0.0f);
+          if constexpr (GR == 4) xk_mail_store(rz, box + g * GBYTES, floatx4{v[0], v[1], v[2], v[3]});
+          else xk_mail_store(rz, box + g * GBYTES, v[0], v[1]);
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < P; ++f) fin[f] = flat(KS * P + f);
+      if constexpr (!(ABL & 4)) {
+        // receive, in slice order (own part at position KS): poll each source's box until no word of it is zero
+        float sum[P];
+        bool first = true;
+#pragma unroll
+        for (int src = 0; src < S; ++src) {
+          float got[P];
+          if (src == KS) {
+#pragma unroll
+            for (int f = 0; f < P; ++f) got[f] = fin[f];
+          } else {
+            const unsigned box = tbase + (unsigned)(KS * (S - 1) + (src < KS ? src : src - 1)) * BOX;
+            unsigned polls = 0;
+            for (;;) {
+              bool ok = true;
+              if constexpr (GR == 4) {
+                u32x4 q[NGR];
+                xk_mail_load<NGR>(rz, box, GBYTES, q);
+#pragma unroll
+                for (int g = 0; g < NGR; ++g)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    ok = ok && q[g][r] != 0u;
+                    got[g * 4 + r] = -__builtin_bit_cast(float, q[g][r]);
+                  }
+              } else {
+                const u32x2 q = xk_mail_load8(rz, box);
+                ok = q[0] != 0u && q[1] != 0u;
+                got[0] = -__builtin_bit_cast(float, q[0]);
+                got[1] = -__builtin_bit_cast(float, q[1]);
+              }
+              if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+              if (++polls > kXkPollLimit) __builtin_trap();
+              __builtin_amdgcn_s_sleep(8);
+            }
+            // hand the box back zeroed
+#pragma unroll
+            for (int g = 0; g < NGR; ++g) {
+              if constexpr (GR == 4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rz, box + g * GBYTES, 0, 16);
+              else __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rz, box + g * GBYTES, 0, 16);
+            }
+          }
+#pragma unroll
+          for (int f = 0; f < P; ++f) sum[f] = first ? got[f] : sum[f] + got[f];
+          first = false;
+        }
+#pragma unroll
+        for (int f = 0; f < P; ++f) fin[f] = sum[f];
+      }
+    };
+    if constexpr (S == 2) {
+      if (t.ks == 0) exchange(xk_ic<0>{});
+      else exchange(xk_ic<1>{});
+    } else if constexpr (S == 4) {
+      if (t.ks == 0) exchange(xk_ic<0>{});
+      else if (t.ks == 1) exchange(xk_ic<1>{});
+      else if (t.ks == 2) exchange(xk_ic<2>{});
+      else exchange(xk_ic<3>{});
+    } else {
+      if (t.ks == 0) exchange(xk_ic<0>{});
+      else if (t.ks == 1) exchange(xk_ic<1 % S>{});
+      else if (t.ks == 2) exchange(xk_ic<2 % S>{});
+      else if (t.ks == 3) exchange(xk_ic<3 % S>{});
+      else if (t.ks == 4) exchange(xk_ic<4 % S>{});
+      else if (t.ks == 5) exchange(xk_ic<5 % S>{});
+      else if (t.ks == 6) exchange(xk_ic<6 % S>{});
+      else exchange(xk_ic<7 % S>{});
+    }
+  }
+  if constexpr (ABL & 64) ph[4] = __builtin_amdgcn_s_memrealtime();
+
+  // ---- 3. the way out.  fin[f], f = 0 .. P - 1, is flattened register ks * P + f = (block j, accumulator register r):
+  //         token m0 + ((wk * HB + j) * 32 + rho), channels 128 nb + 32 wn + 8 (r / 4) + 4 h + r % 4 ----
+  if constexpr (P % 16 == 0) {
+    // whole blocks: f16 image of the finished rows in LDS (row lr, 16-byte chunk q at (lr * CPR + (q ^ lr % 8)) * 16), whole rows out
+    constexpr int NBL = P / 16;               // blocks a wave finishes; local row block index = wk * NBL + jj
+    constexpr int ROWS = 2 * NBL * 32;        // rows this workgroup finishes
+    const int jb0 = (t.ks * P) / 16;          // first finished block among the wave's HB
+    __syncthreads();                          // (the K-parity inboxes have been read)
+    auto image = [&](auto siluc) __attribute__((always_inline)) {
+      constexpr bool SILU = decltype(siluc)::value != 0;
+      constexpr int CPR = SILU ? 8 : 16;
+      const unsigned r7 = (unsigned)rho & 7u;
+#pragma unroll
+      for (int jj = 0; jj < NBL; ++jj) {
+        char* wrow = smem + ((wk * NBL + jj) * 32 + rho) * (CPR * 16) + h * 8;
+#pragma unroll
+        for (int c = 0; c < 4; c += SILU ? 2 : 1) {
+          const unsigned q = (unsigned)wn * (SILU ? 2 : 4) + (SILU ? c / 2 : c);
+          half4_t bv = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+          if constexpr (!SILU)
+            if (a.bias) bv = *(const half4_t*)(a.bias + t.nb * 128 + wn * 32 + 8 * c + 4 * h);
+          half4_t o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (SILU) o[r] = silu_mul_f16((half_t)fin[jj * 16 + 4 * c + r], (half_t)fin[jj * 16 + 4 * c + 4 + r]);
+            else o[r] = (half_t)(fin[jj * 16 + 4 * c + r] + (float)bv[r]);
+          }
+          *(half4_t*)(wrow + ((q ^ r7) << 4)) = o;
+        }
+      }
+      __syncthreads();
+      const int ldy = SILU ? a.N >> 1 : a.N;
+      const int q = (int)threadIdx.x % CPR;
+      half_t* ycol = a.Y + (SILU ? t.nb * 64 : t.nb * 128) + q * 8;
+      const half_t* rcol = (!SILU && a.residual) ? a.residual + t.nb * 128 + q * 8 : nullptr;
+      constexpr int RPI = 512 / CPR;          // rows per pass of the workgroup
+#pragma unroll
+      for (int it = 0; it < ROWS / RPI; ++it) {
+        const int lr = it * RPI + (int)threadIdx.x / CPR;  // local row: block lr / 32 (= wkk * NBL + jj), token lr % 32
+        half8_t v = *(const half8_t*)(smem + (lr * CPR + (q ^ (lr & 7))) * 16);
+        const int blk = lr >> 5, wkk = blk / NBL, jj = blk % NBL;
+        const int m = t.m0 + ((wkk * HB + jb0 + jj) * 32 + (lr & 31));
+        if (m < a.M) {
+          if (rcol) {
+            const half8_t res = *(const half8_t*)(rcol + (size_t)m * a.N);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = (half_t)((float)v[r] + (float)res[r]);
+          }
+          *(half8_t*)(ycol + (size_t)m * ldy) = v;
+        }
+      }
+    };
+    if (a.silu_mul) image(xk_ic<1>{});
+    else image(xk_ic<0>{});
+  } else {
+    // part of a block: straight from the registers, GR channels (8 or 4 bytes) per store.  (No SiLU * mul here: make_plan does not
+    // route such launches to these shapes.)
+#pragma unroll
+    for (int g = 0; g < NGR; ++g) {
+      const int f0 = t.ks * P + g * GR;       // flattened register of fin[g * GR]
+      const int j = f0 / 16, r0 = f0 % 16;
+      const int m = t.m0 + ((wk * HB + j) * 32 + rho);
+      const int n = t.nb * 128 + wn * 32 + 8 * (r0 / 4) + 4 * h + (r0 % 4);
+      if (m < a.M) {
+        float v[GR];
+#pragma unroll
+        for (int r = 0; r < GR; ++r) v[r] = fin[g * GR + r] + (a.bias ? (float)a.bias[n + r] : 0.f);
+        half_t o[GR];
+#pragma unroll
+        for (int r = 0; r < GR; ++r) o[r] = (half_t)v[r];
+        if (a.residual) {
+#pragma unroll
+          for (int r = 0; r < GR; ++r) o[r] = (half_t)((float)o[r] + (float)a.residual[(size_t)m * a.N + n + r]);
+        }
+        half_t* yp = a.Y + (size_t)m * a.N + n;
+        if constexpr (GR == 4) *(half4_t*)yp = half4_t{o[0], o[1], o[2], o[3]};
+        else *(half2_t*)yp = half2_t{o[0], o[1]};
+      }
+    }
+  }
+  if constexpr (ABL & 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ph[5] = __builtin_amdgcn_s_memrealtime();
+    if (a.dbg && lane == 0) {
+      unsigned long long* o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) o[i] = ph[i];
+    }
+  }
+}
+
+}  // namespace quick_amd

@@ -132,8 +132,31 @@ def test_c_abi_library_exports_every_declared_symbol():
     rc = _lib.load().quick_w4a16_gemm_f16(None, None, None, None, None, None, 0, 1, 192, 128, 64, 8, None)
     assert rc == 4
     assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 4096, 128, 8) == 0
-    # N = 1024 at M = 1: 64 channel tiles x 4 K slices, one 1 KiB fp32 slab each, behind 256 B of arrival counters
-    assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 1024, 128, 8) == 65536 + 64 * 4 * 256 * 4
+    # N = 1024 at M = 1: 64 channel tiles x 4 K slices, one 1 KiB fp32 slab each, behind 64 KiB of arrival counters and the
+    # 16 MiB exchange zone (include/quick_amd.h, "workspace")
+    assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 1024, 128, 8) == 65536 + (16 << 20) + 64 * 4 * 256 * 4
+    # exchange-K launch with two slices per tile: counters + zone, no slabs
+    assert _lib.load().quick_w4a16_workspace_bytes_ex(512, 4096, 4096, 128, 4, 0) == 65536 + (16 << 20)
+
+
+def test_product_library_has_no_timing_experiments():
+    """Kernel-id bits 16-20 select ablation builds (wrong results on purpose) and phase stamps: a QUICK_AMD_TOOLS build only.
+    The product library rejects them before any GPU work and exports no such kernels."""
+    lib = _lib.load()
+    for kid in (2 | (1 << 16), 3 | (16 << 16), 4 | (4 << 16), 1 << 16):
+        rc = lib.quick_w4a16_gemm_f16_ex(None, None, None, None, None, None, None, 0, 512, 4096, 4096, 128, kid, 0, None)
+        assert rc == 1 and "QUICK_AMD_TOOLS" in _lib.last_error(), (kid, rc, _lib.last_error())
+    import subprocess
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if os.path.exists(nm):
+        syms = subprocess.run([nm, "-C", LIB], capture_output=True, text=True).stdout
+        # ABL is the last-but-one template argument of the ring kernel and the last of the wide / tiled / xk kernels: every shipped build has 0
+        # (ring: 32 = span stamps, a measurement aid that changes no result)
+        bad = [l for l in syms.splitlines() if re.search(r"w4a16_wide_kernel<\d+, \d+, \d+, [1-9]\d*>", l) or
+               re.search(r"w4a16_xk_kernel<\d+, \d+, \d+, \d+, \d+, [1-9]\d*>", l) or
+               re.search(r"w4a16_ring_kernel<\d+, \d+, \d+, \d+, (?!0,|32,)\d+, \d+>", l) or
+               re.search(r"w4a16_tiled_kernel<\d+, \d+, \d+, \d+, [1-9]\d*, \d+>", l)]
+        assert not bad, bad[:5]
 
 
 def test_plan_describe_pins_the_shape_heuristics():
