@@ -22,6 +22,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #include "w4a16_args.hpp"
@@ -1971,7 +1972,14 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
     if (a.span || (f.silu_mul && (p.wide_mb / 2 * 16) % (16 * p.ksplit) != 0))
       return fail(QUICK_ERR_UNSUPPORTED, "exchange-K kernels: no span stamps; SiLU * mul only where a wave finishes whole 32-token blocks");
-    const int abl = p.ablate == 16 ? 64 : p.ablate;  // (tools builds: 16 = phase stamps, 4 = no exchange, 1 / 2 = no compute / no loads)
+    // (tools builds: kernel bits 16-20 = 16 phase stamps only; 17 loads only; 18 no loads; 19 no loads, no B-fragment reads; 20 no cross-CU
+    // exchange; 21 no loads, no dequantisation; 22 MFMAs + barrier; 23 no loads, no barrier; 24 MFMAs only -- all with the stamps)
+    static const int xk_abl[9] = {64, 65, 66, 82, 68, 74, 90, 98, 122};
+    int abl = p.ablate == 0 ? 0 : ((p.ablate >= 16 && p.ablate <= 24) ? xk_abl[p.ablate - 16] : -1);
+#ifdef QUICK_AMD_TOOLS
+    if (p.ablate)  // (experiments whose bits do not fit the kernel id: the ABL value itself, tools/xk_phases.py --env-abl)
+      if (const char* e = getenv("QUICK_XK_ABL")) abl = atoi(e);
+#endif
     if (!xk_launch(XkConfig{p.wide_mb, p.ksplit, p.xk_nbuf, p.xk_wd, abl}, a, p.ntiles * p.ksplit, L.st, L.start, L.stop))
       return fail(QUICK_ERR_UNSUPPORTED, "no exchange-K build for tokens=%d slices=%d ring=%d queue=%d%s", p.wide_mb * 32, p.ksplit, p.xk_nbuf,
                   p.xk_wd, abl ? " (timing-experiment bits need a QUICK_AMD_TOOLS build)" : "");

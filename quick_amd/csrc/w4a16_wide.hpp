@@ -124,7 +124,8 @@ __device__ __forceinline__ half8_t dequant8(uint32_t q, const GroupQ& g, const D
 // `hook(u)` runs at the head of unit u: the callers spread their LDS-DMA issue (and the ring kernel its early weight
 // read) over the units with it -- a wave that issues a stage's 16 KiB of LDS-DMA in one go keeps the CU's vector memory
 // path busy for ~1000 cycles during which no wave issues an MFMA.
-// ABL (timing experiments only, results are wrong): 1 = no compute (hooks only), 2 = the callers issue no loads in the K loop.
+// ABL (timing experiments only, results are wrong): 1 = no compute (hooks only), 2 = the callers issue no loads in the K loop,
+// 8 = no dequantisation (the packed dword goes to the matrix core as it is), 16 = no B-fragment reads.
 // B fragments are requested DEPTH k16 steps ahead of their MFMAs: a step is MB * PAIRS MFMAs = 32 * MB * PAIRS cycles, an
 // LDS round trip under load 130-200, so short steps need a longer lead (first build: lead 1 everywhere -- at MB = 2 every
 // MFMA waited ~100 cycles for a fragment requested eight instructions earlier).
@@ -222,7 +223,11 @@ __device__ __forceinline__ void wide_compute(const WideW<PAIRS, GM>& w, const Wi
       if (ahead < NSTEP) wide_read_frags<MB, WK, ABL>(xb, ahead, bf[ahead % NBF]);
       else wide_read_frags<MB, WK, ABL>(xb_next, ahead - NSTEP, carry.bf[ahead - NSTEP]);  // the next stage's first steps (PRE_B: landed)
     }
-    if (!last) {
+    if constexpr (ABL & 8) {  // timing experiment: no dequantisation
+      const uint32_t raw = w.lo[0][(u + 1) & 3];
+      af[(u + 1) & 1] = __builtin_bit_cast(half8_t, u32x4{raw, raw, raw, raw});
+      if (last) carry.af = af[(u + 1) & 1];
+    } else if (!last) {
       af[(u + 1) & 1] = wide_frag<PAIRS, GM, WK>(w, grp, u + 1, dq);
     } else {  // the next stage's group constants and first A fragment
 #pragma unroll

@@ -17,7 +17,7 @@ XkConfig xk_default_config(int mb, int s) { return XkConfig{mb, s, 5, 4, 0}; }
 template <int MB, int NBUF, int WD, int S, int ABL = 0>
 static bool xk_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
   constexpr unsigned lds = NBUF * MB * 8192;
-  const dim3 grid(workgroups), block(512);
+  const dim3 grid(workgroups), block((ABL & 4096) ? 768 : 512);
   const int gm = a.G == 128 ? 0 : (a.G % 128 == 0 ? 1 : -1);
   if (gm < 0) return false;
 #define QA_XK_K(GMV)                                                                                               \
@@ -56,10 +56,28 @@ bool xk_launch(const XkConfig& c, const GemmArgs& a, int workgroups, hipStream_t
   const int key = c.mb * 100 + c.nbuf * 10 + c.wd;
 #ifdef QUICK_AMD_TOOLS
   if (c.abl) {  // timing experiments (tools builds): phase stamps, and the launch without the cross-CU exchange (wrong results)
-    if (key == 454 && c.s == 2 && c.abl == 64) return xk_go<4, 5, 4, 2, 64>(a, workgroups, st, start, stop);
-    if (key == 454 && c.s == 2 && c.abl == 4) return xk_go<4, 5, 4, 2, 4>(a, workgroups, st, start, stop);
-    if (key == 454 && c.s == 2 && c.abl == 2) return xk_go<4, 5, 4, 2, 2>(a, workgroups, st, start, stop);
-    if (key == 454 && c.s == 2 && c.abl == 1) return xk_go<4, 5, 4, 2, 1>(a, workgroups, st, start, stop);
+    if (key == 454 && c.s == 2) switch (c.abl) {   // (all with phase stamps: tools/xk_phases.py reads the K loop's own time)
+      case 64: return xk_go<4, 5, 4, 2, 64>(a, workgroups, st, start, stop);
+      case 65: return xk_go<4, 5, 4, 2, 65>(a, workgroups, st, start, stop);    // loads only
+      case 66: return xk_go<4, 5, 4, 2, 66>(a, workgroups, st, start, stop);    // no loads
+      case 82: return xk_go<4, 5, 4, 2, 82>(a, workgroups, st, start, stop);    // no loads, no B-fragment reads
+      case 74: return xk_go<4, 5, 4, 2, 74>(a, workgroups, st, start, stop);    // no loads, no dequantisation
+      case 90: return xk_go<4, 5, 4, 2, 90>(a, workgroups, st, start, stop);    // MFMAs + barrier
+      case 98: return xk_go<4, 5, 4, 2, 98>(a, workgroups, st, start, stop);    // no loads, no barrier
+      case 122: return xk_go<4, 5, 4, 2, 122>(a, workgroups, st, start, stop);  // MFMAs only
+      case 68: return xk_go<4, 5, 4, 2, 68>(a, workgroups, st, start, stop);    // no cross-CU exchange
+      case 192: return xk_go<4, 5, 4, 2, 192>(a, workgroups, st, start, stop);  // no counted wait at the end of a stage
+      case 320: return xk_go<4, 5, 4, 2, 320>(a, workgroups, st, start, stop);  // no x pieces in the K loop
+      case 576: return xk_go<4, 5, 4, 2, 576>(a, workgroups, st, start, stop);  // no weight loads in the K loop
+      case 1088: return xk_go<4, 5, 4, 2, 1088>(a, workgroups, st, start, stop);  // one x piece with every unit
+      case 4160: return xk_go<4, 5, 4, 2, 4160>(a, workgroups, st, start, stop);  // four loader waves issue the x pieces
+      case 80: return xk_go<4, 5, 4, 2, 80>(a, workgroups, st, start, stop);      // loads, no B-fragment reads
+      case 72: return xk_go<4, 5, 4, 2, 72>(a, workgroups, st, start, stop);      // loads, no dequantisation
+      case 88: return xk_go<4, 5, 4, 2, 88>(a, workgroups, st, start, stop);      // loads, MFMAs, barrier
+      case 336: return xk_go<4, 5, 4, 2, 336>(a, workgroups, st, start, stop);    // weight loads only, no B-fragment reads
+      default: return false;
+    }
+    if (key == 454 && c.s == 4 && c.abl == 64) return xk_go<4, 5, 4, 4, 64>(a, workgroups, st, start, stop);
     if (key == 254 && c.s == 8 && c.abl == 64) return xk_go<2, 5, 4, 8, 64>(a, workgroups, st, start, stop);
     return false;
   }

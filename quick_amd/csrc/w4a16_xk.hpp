@@ -75,30 +75,127 @@ __device__ __forceinline__ void xk_mail_store(__amdgpu_buffer_rsrc_t r, unsigned
 __device__ __forceinline__ void xk_mail_store(__amdgpu_buffer_rsrc_t r, unsigned off, float v0, float v1) {
   __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(uint32_t, v0), __builtin_bit_cast(uint32_t, v1)}, r, off, 0, /*sc1*/ 16);
 }
-// N granules of 16 bytes, `stride` bytes apart, loaded AND waited for inside one asm statement (the results are valid where
-// the compiler believes they are)
+// N mailbox granules (16 or 8 bytes per lane) at voff + so[k] (so: wave-uniform byte offsets), loaded AND waited for inside ONE asm
+// statement: the results are valid where the compiler believes they are.
 template <int N>
-__device__ __forceinline__ void xk_mail_load(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned stride, u32x4 (&v)[N]) {
-  static_assert(N >= 1 && N <= 4, "granules per mailbox load");
-  const unsigned o1 = off + stride, o2 = off + 2 * stride, o3 = off + 3 * stride;
+__device__ __forceinline__ void xk_mail_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, const unsigned (&so)[N], u32x4 (&v)[N]) {
+  static_assert(N >= 1 && N <= 7, "granules per poll");
   if constexpr (N == 1)
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(off), "s"(r) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0])
+                 : "v"(voff), "s"(r), "s"(so[0])
+                 : "memory");
   else if constexpr (N == 2)
-    asm volatile("buffer_load_dwordx4 %0, %2, %4, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %3, %4, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(off), "v"(o1), "s"(r) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen sc1\n\t"
+                 "buffer_load_dwordx4 %1, %2, %3, %5 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1])
+                 : "memory");
   else if constexpr (N == 3)
-    asm volatile("buffer_load_dwordx4 %0, %3, %6, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %4, %6, 0 offen sc1\n\t"
-                 "buffer_load_dwordx4 %2, %5, %6, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(off), "v"(o1), "v"(o2), "s"(r) : "memory");
-  else
-    asm volatile("buffer_load_dwordx4 %0, %4, %8, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %5, %8, 0 offen sc1\n\t"
-                 "buffer_load_dwordx4 %2, %6, %8, 0 offen sc1\n\tbuffer_load_dwordx4 %3, %7, %8, 0 offen sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(off), "v"(o1), "v"(o2), "v"(o3), "s"(r) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %3, %4, %5 offen sc1\n\t"
+                 "buffer_load_dwordx4 %1, %3, %4, %6 offen sc1\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4, %7 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1]), "s"(so[2])
+                 : "memory");
+  else if constexpr (N == 4)
+    asm volatile("buffer_load_dwordx4 %0, %4, %5, %6 offen sc1\n\t"
+                 "buffer_load_dwordx4 %1, %4, %5, %7 offen sc1\n\t"
+                 "buffer_load_dwordx4 %2, %4, %5, %8 offen sc1\n\t"
+                 "buffer_load_dwordx4 %3, %4, %5, %9 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3])
+                 : "memory");
+  else if constexpr (N == 5)
+    asm volatile("buffer_load_dwordx4 %0, %5, %6, %7 offen sc1\n\t"
+                 "buffer_load_dwordx4 %1, %5, %6, %8 offen sc1\n\t"
+                 "buffer_load_dwordx4 %2, %5, %6, %9 offen sc1\n\t"
+                 "buffer_load_dwordx4 %3, %5, %6, %10 offen sc1\n\t"
+                 "buffer_load_dwordx4 %4, %5, %6, %11 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3]), "s"(so[4])
+                 : "memory");
+  else if constexpr (N == 6)
+    asm volatile("buffer_load_dwordx4 %0, %6, %7, %8 offen sc1\n\t"
+                 "buffer_load_dwordx4 %1, %6, %7, %9 offen sc1\n\t"
+                 "buffer_load_dwordx4 %2, %6, %7, %10 offen sc1\n\t"
+                 "buffer_load_dwordx4 %3, %6, %7, %11 offen sc1\n\t"
+                 "buffer_load_dwordx4 %4, %6, %7, %12 offen sc1\n\t"
+                 "buffer_load_dwordx4 %5, %6, %7, %13 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3]), "s"(so[4]), "s"(so[5])
+                 : "memory");
+  else if constexpr (N == 7)
+    asm volatile("buffer_load_dwordx4 %0, %7, %8, %9 offen sc1\n\t"
+                 "buffer_load_dwordx4 %1, %7, %8, %10 offen sc1\n\t"
+                 "buffer_load_dwordx4 %2, %7, %8, %11 offen sc1\n\t"
+                 "buffer_load_dwordx4 %3, %7, %8, %12 offen sc1\n\t"
+                 "buffer_load_dwordx4 %4, %7, %8, %13 offen sc1\n\t"
+                 "buffer_load_dwordx4 %5, %7, %8, %14 offen sc1\n\t"
+                 "buffer_load_dwordx4 %6, %7, %8, %15 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3]), "s"(so[4]), "s"(so[5]), "s"(so[6])
+                 : "memory");
 }
-__device__ __forceinline__ u32x2 xk_mail_load8(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  u32x2 v;
-  asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(off), "s"(r) : "memory");
-  return v;
+template <int N>
+__device__ __forceinline__ void xk_mail_load8(__amdgpu_buffer_rsrc_t r, unsigned voff, const unsigned (&so)[N], u32x2 (&v)[N]) {
+  static_assert(N >= 1 && N <= 7, "granules per poll");
+  if constexpr (N == 1)
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0])
+                 : "v"(voff), "s"(r), "s"(so[0])
+                 : "memory");
+  else if constexpr (N == 2)
+    asm volatile("buffer_load_dwordx2 %0, %2, %3, %4 offen sc1\n\t"
+                 "buffer_load_dwordx2 %1, %2, %3, %5 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1])
+                 : "memory");
+  else if constexpr (N == 3)
+    asm volatile("buffer_load_dwordx2 %0, %3, %4, %5 offen sc1\n\t"
+                 "buffer_load_dwordx2 %1, %3, %4, %6 offen sc1\n\t"
+                 "buffer_load_dwordx2 %2, %3, %4, %7 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1]), "s"(so[2])
+                 : "memory");
+  else if constexpr (N == 4)
+    asm volatile("buffer_load_dwordx2 %0, %4, %5, %6 offen sc1\n\t"
+                 "buffer_load_dwordx2 %1, %4, %5, %7 offen sc1\n\t"
+                 "buffer_load_dwordx2 %2, %4, %5, %8 offen sc1\n\t"
+                 "buffer_load_dwordx2 %3, %4, %5, %9 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3])
+                 : "memory");
+  else if constexpr (N == 5)
+    asm volatile("buffer_load_dwordx2 %0, %5, %6, %7 offen sc1\n\t"
+                 "buffer_load_dwordx2 %1, %5, %6, %8 offen sc1\n\t"
+                 "buffer_load_dwordx2 %2, %5, %6, %9 offen sc1\n\t"
+                 "buffer_load_dwordx2 %3, %5, %6, %10 offen sc1\n\t"
+                 "buffer_load_dwordx2 %4, %5, %6, %11 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3]), "s"(so[4])
+                 : "memory");
+  else if constexpr (N == 6)
+    asm volatile("buffer_load_dwordx2 %0, %6, %7, %8 offen sc1\n\t"
+                 "buffer_load_dwordx2 %1, %6, %7, %9 offen sc1\n\t"
+                 "buffer_load_dwordx2 %2, %6, %7, %10 offen sc1\n\t"
+                 "buffer_load_dwordx2 %3, %6, %7, %11 offen sc1\n\t"
+                 "buffer_load_dwordx2 %4, %6, %7, %12 offen sc1\n\t"
+                 "buffer_load_dwordx2 %5, %6, %7, %13 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3]), "s"(so[4]), "s"(so[5])
+                 : "memory");
+  else if constexpr (N == 7)
+    asm volatile("buffer_load_dwordx2 %0, %7, %8, %9 offen sc1\n\t"
+                 "buffer_load_dwordx2 %1, %7, %8, %10 offen sc1\n\t"
+                 "buffer_load_dwordx2 %2, %7, %8, %11 offen sc1\n\t"
+                 "buffer_load_dwordx2 %3, %7, %8, %12 offen sc1\n\t"
+                 "buffer_load_dwordx2 %4, %7, %8, %13 offen sc1\n\t"
+                 "buffer_load_dwordx2 %5, %7, %8, %14 offen sc1\n\t"
+                 "buffer_load_dwordx2 %6, %7, %8, %15 offen sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6])
+                 : "v"(voff), "s"(r), "s"(so[0]), "s"(so[1]), "s"(so[2]), "s"(so[3]), "s"(so[4]), "s"(so[5]), "s"(so[6])
+                 : "memory");
 }
 
 // tile / slice coordinates.  XCD-aware order (a.xcd_gm > 0): workgroup b runs on XCD b % 8; XCD x serves K slice x % S only, and the
@@ -137,10 +234,13 @@ constexpr unsigned kXkZoneBytes = 16u << 20;   // exchange zone of the workspace
 constexpr unsigned kXkPollLimit = 1u << 22;    // polls of ~1 us before a wave gives up and traps (a slice that never came)
 
 // ABL (tools builds only): 64 = s_memrealtime stamps at the phase boundaries of every wave into a.dbg; 4 = no cross-CU exchange (the
-// own part is finished without the other slices: wrong results, the launch minus the exchange); 1 / 2 as in wide_compute.
+// own part is finished without the other slices: wrong results, the launch minus the exchange); 1 / 2 / 8 / 16 as in wide_compute (no
+// compute / no loads in the K loop / no dequantisation / no B-fragment reads); 32 = no barrier in the K loop; 128 = no counted wait at the
+// end of a stage; 256 / 512 = no x pieces / no weight loads in the K loop; 1024 = one x piece with every unit instead of two with two.
 template <int MB, int GM, int NBUF, int WD, int S, int ABL = 0>
-__global__ __launch_bounds__(512) void w4a16_xk_kernel(const GemmArgs a) {
+__global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(const GemmArgs a) {
   constexpr int NW = 8, NG = 1;
+  constexpr bool LD = (ABL & 4096) != 0;  // experiment: four extra LOADER waves issue every x piece, the eight compute waves only their weights
   constexpr int SLOT = MB * 8192;
   constexpr int XI = MB;       // x LDS-DMA instructions per wave and stage (MB * 32 rows / (8 waves * 4 rows))
   constexpr int L = XI + 2;    // vector-memory instructions per wave and stage (+ weights, + (scale, zero) word)
@@ -152,7 +252,7 @@ __global__ __launch_bounds__(512) void w4a16_xk_kernel(const GemmArgs a) {
   static_assert(MB * 16384 <= NBUF * SLOT, "the K-parity exchange must fit in the ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF * SLOT
 
-  unsigned long long ph[6];
+  unsigned long long ph[6], cyc = 0;  // (cyc: shader clocks spent in the K loop, s_memtime)
   if constexpr (ABL & 64) ph[0] = __builtin_amdgcn_s_memrealtime();
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
@@ -165,7 +265,44 @@ __global__ __launch_bounds__(512) void w4a16_xk_kernel(const GemmArgs a) {
   const unsigned xdst = lds_base + (unsigned)wave * 1024u;  // + slot + i * 8 KiB
   const unsigned xrd = (lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4)) ^ ((unsigned)wk << 5);
 
-  auto issue_x = [&](int i, int kt, unsigned slot) { lds_dma16(b.x, b.x_voff[i], (unsigned)kt * 256u, xdst + slot + i * (NW * 1024)); };
+  if constexpr (LD) {
+    static_assert(!LD || (NBUF == 5 && MB == 4), "loader experiment: 128-token tiles, five slots");
+    if (wave >= 8) {  // loader wave lw: piece i = rows 16 i + 4 lw + lane / 16 of the token tile, i = 0 .. 7
+      const unsigned lw = (unsigned)wave - 8u;
+      const unsigned row = 4u * lw + ((unsigned)lane >> 4);
+      unsigned voff[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        voff[i] = (unsigned)min(t.m0 + 16 * i + (int)row, a.M - 1) * (unsigned)a.K * 2u + 16u * (((unsigned)lane & 15u) ^ (row & 15u));
+      const unsigned dst = lds_base + lw * 1024u;
+      auto fillx = [&](int q, unsigned slot) {
+        const int kt = min(t.kt_lo + q, t.kt_hi - 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds_dma16(b.x, voff[i], (unsigned)kt * 256u, dst + slot + i * 4096);
+      };
+      fillx(0, 0u); fillx(1, SLOT); fillx(2, 2 * SLOT); fillx(3, 3 * SLOT);
+      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // x stage 0
+      __builtin_amdgcn_s_barrier();                      // A
+      fillx(4, 4 * SLOT);
+      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // x stage 1
+      __builtin_amdgcn_s_barrier();                      // M (stage 0, before the first read of stage 1)
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // x stage 2
+      __builtin_amdgcn_s_barrier();                      // end of stage 0
+      unsigned slot = 0u;                                // slot of stage s + 4 = slot of stage s - 1
+      for (int s2 = 1; s2 < t.nstage; ++s2) {
+        fillx(s2 + 4, slot);
+        slot = slot + SLOT >= (unsigned)(NBUF * SLOT) ? 0u : slot + SLOT;
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // x stage s + 2
+        __builtin_amdgcn_s_barrier();                      // end of stage s
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // the ring is free
+      return;
+    }
+  }
+  auto issue_x = [&](int i, int kt, unsigned slot) {
+    if constexpr (!LD) lds_dma16(b.x, b.x_voff[i], (unsigned)kt * 256u, xdst + slot + i * (NW * 1024));
+  };
   auto issue_w = [&](auto jc, int kt) {
     const unsigned g = (unsigned)group_index<GM>(kt, 0, a.tpg, a.G);
     XkSet<decltype(jc)::value>::issue(b.w, b.w_voff, (unsigned)kt * 1024u, b.s, b.s_voff, g * 64u);
@@ -179,52 +316,110 @@ __global__ __launch_bounds__(512) void w4a16_xk_kernel(const GemmArgs a) {
   wide_zero<MB, 1>(acc);
   const DqConsts dq = make_dq_consts();
 
-  // prologue, in the order the steady state would have issued it: [W(0 .. WD - NBUF)], then W(WD - NBUF + 1 + q), X(q) for q = 0 .. NBUF - 2
-  {
-    auto pro_w = [&](auto jc) { issue_w(jc, min(t.kt_lo + decltype(jc)::value, t.kt_hi - 1)); };
-    auto pro_x = [&](int q) {
-      const int kt = min(t.kt_lo + q, t.kt_hi - 1);
+  // FAST start (the shipped geometry, five slots / four sets): the prologue asks only for what stage 0 needs -- weight sets 0, 1 and x
+  // stage 0 (and 1 where stage 0 reads it from its second unit on: 64-token tiles) -- and stage 0 itself issues the rest of the
+  // ring next to its MFMAs.  Every CU's vector-memory path moves 64 B per clock: a prologue that asks for all four stages (164 KB
+  // at 128 tokens) spends ~1.5 us ISSUING before the first wait [r03 phase stamps: 2.6-2.8 us to the first MFMA, with or without
+  // waiting for stage 1].  Other geometries (tuning sweeps) keep the plain prologue, in the order the steady state would have
+  // issued it: [W(0 .. WD - NBUF)], then W(WD - NBUF + 1 + q), X(q) for q = 0 .. NBUF - 2.
+  constexpr bool FAST = NBUF == 5 && WD == 4 && !(ABL & 2) && !LD;
+  constexpr int DEPTH = wide_bdepth<MB, 1>();
+  constexpr int UM = NU - DEPTH;            // the unit of a stage that first reads the NEXT stage's tokens
+  constexpr int PX = UM >= 2 ? 1 : 2;       // x stages the FAST prologue asks for
+  constexpr int PER = XI / 2;               // steady state: x pieces with units 1 and 2 (nothing with the last unit of the stage)
+  auto x_stage = [&](int q) {               // all pieces of x stage q (q < NBUF: its slot is q)
+    const int kt = min(t.kt_lo + q, t.kt_hi - 1);
 #pragma unroll
-      for (int i = 0; i < XI; ++i) issue_x(i, kt, (unsigned)q * SLOT);
-    };
+    for (int i = 0; i < XI; ++i) issue_x(i, kt, (unsigned)q * SLOT);
+  };
+  auto pro_w = [&](auto jc) { issue_w(jc, min(t.kt_lo + decltype(jc)::value, t.kt_hi - 1)); };
+  if constexpr (FAST) {
+    pro_w(xk_ic<0>{});
+    pro_w(xk_ic<1>{});
+    x_stage(0);
+    if constexpr (PX == 2) x_stage(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PX - 1) * XI) : "memory");  // weight sets 0, 1 and x stage 0 have landed
+  } else {
     constexpr int E = WD - NBUF + 1;  // sets issued ahead of the first x stage
     if constexpr (E > 0) pro_w(xk_ic<0>{});
     if constexpr (E > 1) pro_w(xk_ic<1>{});
     if constexpr (E > 2) pro_w(xk_ic<2>{});
     if constexpr (E > 3) pro_w(xk_ic<3>{});
     pro_w(xk_ic<E>{});
-    pro_x(0);
-    if constexpr (NBUF > 2) { pro_w(xk_ic<E + 1>{}); pro_x(1); }
-    if constexpr (NBUF > 3) { pro_w(xk_ic<E + 2>{}); pro_x(2); }
-    if constexpr (NBUF > 4) { pro_w(xk_ic<E + 3>{}); pro_x(3); }
+    x_stage(0);
+    if constexpr (NBUF > 2) { pro_w(xk_ic<E + 1>{}); x_stage(1); }
+    if constexpr (NBUF > 3) { pro_w(xk_ic<E + 2>{}); x_stage(2); }
+    if constexpr (NBUF > 4) { pro_w(xk_ic<E + 3>{}); x_stage(3); }
     static_assert(NBUF <= 5, "prologue written out for up to five slots");
+    // start as soon as x stage 0 and weight sets 0, 1 are there; stage 0 waits for x stage 1 itself, just before its first read of it
+    constexpr int INIT = LD ? 2 * (WD - 2) : (NBUF - 2) * L - (E == 0 ? 2 : 0);  // what the prologue issued behind X(0) (and W(1))
+    static_assert(INIT <= 63, "vmcnt field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INIT) : "memory");
   }
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");  // x stages 0 and 1, weight sets 0 and 1 have landed
   __builtin_amdgcn_s_barrier();
   WideW<1, GM> wc, wnx;
   read_w(xk_ic<0>{}, wc);
   WideCarry<MB, 1, GM> carry;
   wide_prepare<MB, 1, GM, true, 2>(carry, wc, xrd, dq);
   if (wk) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses every VALU arbitration otherwise (MI355X_MICROARCH.md, two waves per SIMD)
-  if constexpr (ABL & 64) ph[1] = __builtin_amdgcn_s_memrealtime();
+  if constexpr (ABL & 64) { ph[1] = __builtin_amdgcn_s_memrealtime(); cyc = __builtin_amdgcn_s_memtime(); }
 
+  // vmcnt bookkeeping.  Steady state: stage s issues [W(s + WD), X(s + NBUF - 1)] = L instructions per wave; "x stage s + 2 and weight
+  // set s + 2 have landed" at the end of stage s is vmcnt((NBUF - 3) L).  FAST: stage 0 issues W(2) W(3) W(4) X(PX) .. X(4), in that
+  // order, so X(2) is followed by 2 XI instructions at the end of stage 0 and X(3) by 2 XI + 2 at the end of stage 1; before its unit
+  // UM stage 0 waits for X(1) (followed by X(2) at 128 tokens; by W(2..4) and X(2) at 64, where X(1) was part of the prologue).
+  constexpr int END0 = FAST ? 2 * XI : PEND, END1 = FAST ? 2 * XI + 2 : PEND;
+  constexpr int MID = FAST ? (PX == 1 ? XI : 6 + XI) : (NBUF - 3) * L + 2 + (UM - 1) * PER;
+  static_assert(MID <= 63, "vmcnt field");
   unsigned cur = 0u, nxt = (unsigned)SLOT, fill = (unsigned)(NBUF - 1) * SLOT;  // slots of stage s, s + 1, s + NBUF - 1
   auto stage = [&](auto jc, int s) __attribute__((always_inline)) {
     constexpr int J = decltype(jc)::value;
     const int ktx = min(t.kt_lo + s + NBUF - 1, t.kt_hi - 1), ktw = min(t.kt_lo + s + WD, t.kt_hi - 1);
     read_w(xk_ic<(J + 1) % WD>{}, wnx);  // W(s + 1): landed since the wait that ended stage s - 1
-    wide_compute<MB, 1, GM, (ABL & 3), true, 2>(wc, wnx, xrd + cur, xrd + nxt, dq, acc, carry, [&](int u) {
+    wide_compute<MB, 1, GM, (ABL & 27), true, 2>(wc, wnx, xrd + cur, xrd + nxt, dq, acc, carry, [&](int u) {
       if constexpr (!(ABL & 2)) {
-        if (u == 0) issue_w(xk_ic<J>{}, ktw);  // set J held W(s), which has been in VGPRs since stage s - 1
-        constexpr int PER = XI / 2;            // x pieces with units 1 and 2 (nothing with the last unit of the stage)
-        if (u == 1 || u == 2) {
+        bool first = false;
+        if constexpr (J == 0) first = s == 0;
+        if (first) {  // stage 0: wait for x stage 1 before the first read of it; FAST: fill the rest of the ring
+          if (u == UM) {
+            if constexpr (!LD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MID) : "memory");
+            __builtin_amdgcn_s_barrier();  // ... in every wave
+          }
+          if constexpr (FAST) {
+            if (u == 0) {
+              pro_w(xk_ic<2>{});
+              pro_w(xk_ic<3>{});
+              issue_w(xk_ic<0>{}, ktw);
+              x_stage(PX);
+            }
+            if (PX == 1 && u == 1) x_stage(2);
+            if (u == (PX == 1 ? 2 : 1)) x_stage(3);
+            if (u == (PX == 1 ? 3 : 2)) x_stage(4);   // (= this stage's own share: ktx, fill)
+            return;
+          }
+        }
+        if constexpr (!(ABL & 512))
+          if (u == 0) issue_w(xk_ic<J>{}, ktw);  // set J held W(s), which has been in VGPRs since stage s - 1
+        if constexpr (!(ABL & 256)) {
+          if constexpr ((ABL & 1024) && XI == 4) {
+            issue_x(u, ktx, fill);               // (experiment: one piece with every unit)
+          } else if (u == 1 || u == 2) {
 #pragma unroll
-          for (int i = 0; i < PER; ++i) issue_x((u - 1) * PER + i, ktx, fill);
+            for (int i = 0; i < PER; ++i) issue_x((u - 1) * PER + i, ktx, fill);
+          }
         }
       }
     });
-    if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");  // x stage s + 2 and weight set s + 2 have landed ...
-    __builtin_amdgcn_s_barrier();                                                         // ... in every wave; everybody is done with x stage s
+    if constexpr (!(ABL & 2) && !(ABL & 128)) {  // x stage s + 2 and weight set s + 2 have landed ...
+      bool s0 = false, s1 = false;
+      if constexpr (J == 0) s0 = s == 0;
+      if constexpr (J == 1) s1 = s == 1;
+      if constexpr (LD) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (only the weights: set s + 2 was issued two stages ago)
+      else if (s0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(END0) : "memory");
+      else if (s1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(END1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");
+    }
+    if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();  // ... in every wave; everybody is done with x stage s
     wc = wnx;
     fill = cur;
     cur = nxt;
@@ -239,7 +434,7 @@ __global__ __launch_bounds__(512) void w4a16_xk_kernel(const GemmArgs a) {
     if constexpr (WD > 5) if (base + 5 < t.nstage) stage(xk_ic<5 % WD>{}, base + 5);
   }
   if (wk) __builtin_amdgcn_s_setprio(0);
-  if constexpr (ABL & 64) ph[2] = __builtin_amdgcn_s_memrealtime();
+  if constexpr (ABL & 64) { ph[2] = __builtin_amdgcn_s_memrealtime(); cyc = __builtin_amdgcn_s_memtime() - cyc; }
 
   // ---- 1. the two K parities of a channel quarter swap halves through LDS ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the replayed loads of the last stages)
@@ -308,50 +503,63 @@ __global__ __launch_bounds__(512) void w4a16_xk_kernel(const GemmArgs a) {
 #pragma unroll
       for (int f = 0; f < P; ++f) fin[f] = flat(KS * P + f);
       if constexpr (!(ABL & 4)) {
-        // receive, in slice order (own part at position KS): poll each source's box until no word of it is zero
-        float sum[P];
-        bool first = true;
+        // receive: ONE poll fetches the boxes of all S - 1 sources (a round trip to memory each time: polled one after the other, seven
+        // sources cost seven of them [r03 phase stamps, S = 8: 3.6 us]) and is repeated until no word of any of them is zero
+        constexpr int TL = (S - 1) * NGR;
+        typedef float floatx2 __attribute__((ext_vector_type(2)));
+        unsigned so[TL];
 #pragma unroll
-        for (int src = 0; src < S; ++src) {
-          float got[P];
-          if (src == KS) {
+        for (int k = 0; k < TL; ++k) {
+          const int si = k / NGR, src = si < KS ? si : si + 1;   // (si: the source's index among the S - 1 boxes of this slice)
+          so[k] = (unsigned)(KS * (S - 1) + si) * BOX + (unsigned)(k % NGR) * GBYTES;
+          (void)src;
+        }
+        float got[S - 1][P];
+        unsigned polls = 0;
+        for (;;) {
+          bool ok = true;
+          if constexpr (GR == 4) {
+            u32x4 q[TL];
+            xk_mail_load16<TL>(rz, tbase, so, q);
 #pragma unroll
-            for (int f = 0; f < P; ++f) got[f] = fin[f];
-          } else {
-            const unsigned box = tbase + (unsigned)(KS * (S - 1) + (src < KS ? src : src - 1)) * BOX;
-            unsigned polls = 0;
-            for (;;) {
-              bool ok = true;
-              if constexpr (GR == 4) {
-                u32x4 q[NGR];
-                xk_mail_load<NGR>(rz, box, GBYTES, q);
+            for (int k = 0; k < TL; ++k) {
+              const floatx4 fq = __builtin_bit_cast(floatx4, q[k]);  // (whole vector: hipcc's bit_cast of a vector ELEMENT reads element 0)
 #pragma unroll
-                for (int g = 0; g < NGR; ++g)
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) {
-                    ok = ok && q[g][r] != 0u;
-                    got[g * 4 + r] = -__builtin_bit_cast(float, q[g][r]);
-                  }
-              } else {
-                const u32x2 q = xk_mail_load8(rz, box);
-                ok = q[0] != 0u && q[1] != 0u;
-                got[0] = -__builtin_bit_cast(float, q[0]);
-                got[1] = -__builtin_bit_cast(float, q[1]);
+              for (int r = 0; r < 4; ++r) {
+                ok = ok && q[k][r] != 0u;
+                got[k / NGR][(k % NGR) * 4 + r] = -fq[r];
               }
-              if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-              if (++polls > kXkPollLimit) __builtin_trap();
-              __builtin_amdgcn_s_sleep(8);
             }
-            // hand the box back zeroed
+          } else {
+            u32x2 q[TL];
+            xk_mail_load8<TL>(rz, tbase, so, q);
 #pragma unroll
-            for (int g = 0; g < NGR; ++g) {
-              if constexpr (GR == 4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rz, box + g * GBYTES, 0, 16);
-              else __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rz, box + g * GBYTES, 0, 16);
+            for (int k = 0; k < TL; ++k) {
+              const floatx2 fq = __builtin_bit_cast(floatx2, q[k]);
+              ok = ok && q[k][0] != 0u && q[k][1] != 0u;
+              got[k][0] = -fq[0];
+              got[k][1] = -fq[1];
             }
           }
+          if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+          if (++polls > kXkPollLimit) __builtin_trap();
+          __builtin_amdgcn_s_sleep(4);
+        }
+        // hand the boxes back zeroed
 #pragma unroll
-          for (int f = 0; f < P; ++f) sum[f] = first ? got[f] : sum[f] + got[f];
-          first = false;
+        for (int k = 0; k < TL; ++k) {
+          if constexpr (GR == 4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rz, tbase, so[k], 16);
+          else __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rz, tbase, so[k], 16);
+        }
+        // sum in slice order, the own part at position KS
+        float sum[P];
+#pragma unroll
+        for (int src = 0; src < S; ++src) {
+#pragma unroll
+          for (int f = 0; f < P; ++f) {
+            const float v = src == KS ? fin[f] : got[src < KS ? src : src - 1][f];
+            sum[f] = src == 0 ? v : sum[f] + v;
+          }
         }
 #pragma unroll
         for (int f = 0; f < P; ++f) fin[f] = sum[f];
@@ -465,6 +673,7 @@ __global__ __launch_bounds__(512) void w4a16_xk_kernel(const GemmArgs a) {
       unsigned long long* o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
 #pragma unroll
       for (int i = 0; i < 6; ++i) o[i] = ph[i];
+      o[6] = cyc;
     }
   }
 }

@@ -109,6 +109,18 @@ class WQLinear_QUICK(nn.Module):
         self._layout = _Layout(was, self._key() if was else None)   # .to()/.cuda() move bits, they do not reorder them
         return self
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # Checkpoints always hold the reference's order, and nn.Module copies them into the existing storages in place.  Do not
+        # leave it to the version counters to notice: a deep copy or an unpickled module re-keys itself on first use (a copy of
+        # prepared buffers is prepared), and inference tensors have no version counter at all -- so a load that followed either
+        # would be taken for MI355X order.  A partial load (some of the three tensors) must not mix the two orders either: a
+        # prepared module goes back to the reference's order first.
+        if any(prefix + n in state_dict for n in ("qweight", "scales", "qzeros")):
+            if self.is_prepared:
+                self._set_packed(*self.reference_order(), prepared=False)
+            self._layout = _Layout(False)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         super()._save_to_state_dict(destination, prefix, keep_vars)
         if self.is_prepared:

@@ -364,6 +364,35 @@ def test_deepcopy_and_pickle_keep_the_layout():
     assert not unprepared.is_prepared
 
 
+def test_load_state_dict_right_after_a_copy_marks_reference_order():
+    """deepcopy / unpickle carry `prepared` without a storage key (they re-key on first use); a load_state_dict that follows
+    BEFORE any such use copies reference-order bits into the storages in place, and under inference mode there is no version
+    counter to notice it.  The load itself must reset the layout."""
+    import copy
+    import io
+    g, m = _reference_checkpoint_module()
+    ckpt = {k: v.clone() for k, v in m.state_dict().items()}            # reference order
+    m.prepare()
+    for clone in (copy.deepcopy(m), torch.load(io.BytesIO(_save_bytes(m)), weights_only=False)):
+        clone.load_state_dict(ckpt)                                     # no is_prepared / forward in between
+        assert not clone.is_prepared
+        assert torch.equal(clone.qweight, ckpt["qweight"])
+        clone.prepare()
+        assert clone.is_prepared and torch.equal(clone.qweight, m.qweight)
+    with torch.inference_mode():                                        # inference tensors: version 0 for ever
+        m3 = WQLinear_QUICK(4, int(g["G"]), int(g["K"]), int(g["N"]), False, "cpu")
+        m3.load_state_dict({k: v.clone() for k, v in ckpt.items()})
+        m3.prepare()
+        assert m3.is_prepared
+        m3.load_state_dict({k: v.clone() for k, v in ckpt.items()})     # in place, no version bump
+        assert not m3.is_prepared and torch.equal(m3.qweight, ckpt["qweight"])
+    # a partial load must not mix the two orders: the tensors that are not in the checkpoint go back to the reference's order
+    m4 = copy.deepcopy(m)
+    assert m4.is_prepared
+    m4.load_state_dict({"scales": ckpt["scales"].clone()}, strict=False)
+    assert not m4.is_prepared and torch.equal(m4.qweight, ckpt["qweight"]) and torch.equal(m4.qzeros, ckpt["qzeros"])
+
+
 def _save_bytes(module):
     import io
     buf = io.BytesIO()
