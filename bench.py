@@ -14,7 +14,8 @@ Cache, so small-M numbers are HBM numbers, not cache numbers.  Rank 0 prints ONE
   sweep                the same two measurements for every M of the BASELINE sweep (1, 8, 64, 512)
   decode_layers        kernel duration and HBM fraction of the Llama-2-7B layer shapes at M=1 (N=1 only)
   prefill_layers       kernel duration and MFMA fraction of prefill-sized launches (N=1 only)
-  decode               decode tok/s of a synthetic Llama-2-7B stack at bs = 1, 64 (128/128, hipGraph step; N=1 only)
+  decode               decode / prefill tok/s of synthetic Llama-2-7B (bs = 1, 64), Mistral-7B (bs = 64) and Llama-2-70B (bs = 16)
+                       stacks (128/128, hipGraph step; N=1 only)
   cpu_baseline         the reference's CPU path (dequantize_gemm + torch.matmul, restated in oracle/cpu_path.py)
                        timed on the host cores on a bounded sample, N=1 only
 
@@ -77,7 +78,7 @@ def pmc_traffic(M, K, N, G, kernel, plan):
     if not files:
         return None, None
     text = open(files[-1]).read()
-    family = plan.split()[0]                                   # "skinny" | "tiled" | "wide"
+    family = plan.split()[0]                                   # "skinny" | "tiled" | "wide" | "xk"
     heads = [l for l in text.splitlines() if l.startswith("== ")]
     if not heads or not any(f"w4a16_{family}" in h or (family == "wide" and "w4a16_ring" in h) for h in heads):
         return None, {"file": "profiles/" + os.path.basename(files[-1]), "rejected": f"profiled kernel is not the planner's ({family})"}
@@ -93,6 +94,31 @@ def pmc_traffic(M, K, N, G, kernel, plan):
     return (2.0 * vals["FETCH_SIZE"] + vals.get("WRITE_SIZE", 0.0)) * 1024.0, src
 
 
+def pmc_issue_mix(M, K, N, G, kernel, src):
+    """north_star: "evidenced by rocprof MFMA-busy %".  From the same committed counter pass as `traffic` (accepted only if it is
+    about the kernel the planner picks today): the share of the launch during which the matrix pipes were busy --
+    SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the 1024 SIMDs) / (1024 * GRBM_GUI_ACTIVE / 8 XCDs) -- and the VALU-class
+    instructions issued per MFMA (SQ_INSTS_VALU counts the MFMAs themselves)."""
+    if not src or "file" not in src or "rejected" in src:
+        return {}
+    here = os.path.dirname(os.path.abspath(__file__))
+    vals = {}
+    for line in open(os.path.join(here, src["file"])):
+        f = line.split()
+        if len(f) >= 2 and f[0] in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_WAVE_CYCLES",
+                                    "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") and f[0] not in vals:
+            vals[f[0]] = float(f[1])
+    out = {}
+    if vals.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
+        out["mfma_busy_frac"] = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0)
+    if vals.get("SQ_INSTS_MFMA") and "SQ_INSTS_VALU" in vals:
+        out["valu_per_mfma"] = vals["SQ_INSTS_VALU"] / vals["SQ_INSTS_MFMA"]
+    if vals.get("SQ_WAVE_CYCLES"):
+        out["wave_cycles_waiting_frac"] = vals.get("SQ_WAIT_ANY", 0.0) / vals["SQ_WAVE_CYCLES"]
+        out["wave_cycles_issue_stalled_frac"] = vals.get("SQ_WAIT_INST_ANY", 0.0) / vals["SQ_WAVE_CYCLES"]
+    return out
+
+
 def decode_leg(dev, seconds, log):
     """Second half of the BASELINE metric: decode tok/s of a synthetic Llama-2-7B AWQ-QUICK stack at bs = 1 and 64,
     prefill/decode = 128/128, the reference's methodology (examples/benchmark.py:38-67,127-129: tok/s = bs / median step),
@@ -103,15 +129,17 @@ def decode_leg(dev, seconds, log):
     import torch
     from quick_amd.decoder import CONFIGS, SyntheticDecoder, run_generation
     out = []
-    cfg = CONFIGS["llama2-7b"]
     t0 = time.perf_counter()
-    for bs in (1, 64):
+    # BASELINE.json configs[2..4]: Llama-2-7B bs = 1 (and 64, the metric's second batch size), Mistral-7B bs = 64, Llama-2-70B bs = 16
+    for name, bs in (("llama2-7b", 1), ("llama2-7b", 64), ("mistral-7b", 64), ("llama2-70b", 16)):
         if time.perf_counter() - t0 > seconds:
-            break
+            out.append({"model": name, "batch": bs, "skipped": "decode-seconds budget spent"})
+            continue
+        cfg = CONFIGS[name]
         model = SyntheticDecoder(cfg, bs, 256, dev)
         torch.cuda.synchronize()
         run_generation(model, 128, 8, use_graph=False, fused=True)                  # warm-up (allocator, lazy init)
-        gen = 128 if time.perf_counter() - t0 < 0.5 * seconds else 32
+        gen = 128 if time.perf_counter() - t0 < 0.6 * seconds else 32
         prefill, steps = run_generation(model, 128, gen, use_graph=True, fused=True)
         med = float(np.median(steps))
         out.append({"model": cfg.name, "batch": bs, "prefill_len": 128, "decode_len": gen, "tok_s": bs / med, "ms_per_step": med * 1e3,
@@ -141,7 +169,8 @@ def main():
     ap.add_argument("--prefill-layers", default="4096x4096x4096,8192x4096x22016,8192x11008x4096,4096x28672x8192",
                     help="MxKxN prefill-sized launches (K = N = 4096; Llama-2-7B gate_up / down at 8192 tokens; Llama-2-70B down) into 'prefill_layers'; '' = none")
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--decode-seconds", type=float, default=40.0, help="budget of the decode tok/s leg (Llama-2-7B bs=1,64; 0 = skip)")
+    ap.add_argument("--decode-seconds", type=float, default=240.0,
+                    help="budget of the decode tok/s leg (Llama-2-7B bs=1,64; Mistral-7B bs=64; Llama-2-70B bs=16; 0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -179,6 +208,13 @@ def main():
     qw_arr, sc_arr, qz_arr = arr(0), arr(1), arr(2)
     stream = torch.cuda.current_stream()
 
+    flush_buf = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+
+    def flush_cache():
+        flush_buf.fill_(1)
+        flush_buf.view(torch.int64).sum()
+        torch.cuda.synchronize()
+
     def measure(M, steps, warmup):
         x = x_full[:M].contiguous()
         y = torch.empty((M, N), dtype=torch.float16, device=dev)
@@ -208,6 +244,9 @@ def main():
             log(f"graph capture failed ({e}); timing eager launches")
             graph, mode = None, "eager"
         torch.cuda.synchronize()
+        # The untimed replay touched exactly the weight sets the timed one will: with few steps (the driver's --steps 20 = 181 MB)
+        # they would all still sit in the 256 MiB Infinity Cache.  Push them out: write and read 512 MiB of something else.
+        flush_cache()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -269,8 +308,10 @@ def main():
         roof["traffic"], roof["traffic_source"] = pmc_traffic(M, K, N, G, args.kernel, roof["plan"])
         roof.update({"kernel_us": k_us, "kernel_us_event_pairs": k_us_events, "kernel_us_cache_resident": k_us_hot,
                      "algorithmic_bytes": nbytes, "flops": flops})
+        roof.update(pmc_issue_mix(M, K, N, G, args.kernel, roof["traffic_source"]))
         return {"M": M, "ms_per_step": ms_step, "tops": flops / (ms_step * 1e-3) / 1e12, "tops_kernel_only": flops / (k_us * 1e-6) / 1e12,
-                "launch": mode, "roofline": roof}, y
+                "launch": mode, "weight_sets_in_timed_region": min(steps, n_sets), "cache_flushed_before_timed_region": True,
+                "roofline": roof}, y
 
     fl = (ctypes.c_float * 60)()
     lib.quick_amd_dispatch_floor(60, fl, stream.cuda_stream)
@@ -300,6 +341,7 @@ def main():
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"W4A16 GEMM M={args.M} K={K} N={N} group_size={G} (BASELINE.json configs[1])", "M": args.M, "K": K, "N": N,
                    "group_size": G, "weight_sets_cycled": n_sets, "weight_set_bytes": set_bytes, "launch": head["launch"],
+                   "weight_sets_in_timed_region": head["weight_sets_in_timed_region"], "cache_flushed_before_timed_region": True,
                    "parallelism": "replicas only" if world > 1 else "single GPU"},
         "roofline": head["roofline"],
         "sweep": [results[m] for m in Ms],

@@ -97,7 +97,7 @@ size_t quick_w4a16_workspace_bytes(int M, int K, int N, int group_size, int spli
  *   bits 0-3    family, QUICK_KERNEL_*
  *   bits 4-7    SKINNY: channel tiles of 16 per workgroup (1, 2, 4); TILED: token tiles of 16 per workgroup (2, 4, 8);
  *               WIDE / XK: token tiles of 32 per workgroup (WIDE 2, 4, 8; XK 2, 4)
- *   bits 8-11   SKINNY / TILED: waves per workgroup / 4; WIDE: 32-channel pairs per wave (1, 2); XK: K slices per tile (1, 2, 4, 8)
+ *   bits 8-11   SKINNY / TILED: waves per workgroup / 4; WIDE: 32-channel pairs per wave (1, 2); XK: K slices per tile (1, 2, 4, 8; 15 = half the planner's count)
  *   bit 12      SKINNY: no LDS copy of x; WIDE: the double-buffered kernel at every tile size (no ring)
  *   bit 13      TILED: 32x32x16 MFMA flavour         bit 14  TILED / WIDE / XK: plain (not XCD-aware) tile order
  *   bit 15      TILED: 2 x 4 wave grid; WIDE: eight waves per workgroup (ring kernel)

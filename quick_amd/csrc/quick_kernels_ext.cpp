@@ -97,6 +97,12 @@ torch::Tensor gemm_forward_cuda_quick(torch::Tensor in_feats, torch::Tensor kern
           kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), e.packed[0].data_ptr(), e.packed[1].data_ptr(),
           e.packed[2].data_ptr(), K, N, G, stream);
       if (rc != QUICK_OK) raise(rc);
+      // The copy is cached for every later caller, whatever stream it is on: finish the repack once, here, so that a first use
+      // from another stream cannot read a half-written copy (not inside a stream capture, where synchronising is not allowed --
+      // there the repack is part of the captured work and ordered with it).
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) (void)hipStreamSynchronize(stream);
+      (void)hipGetLastError();
       for (auto d = g_cache.begin(); d != g_cache.end();)  // drop entries whose tensors died
         d = (d->second.ref[0].expired() || d->second.ref[1].expired() || d->second.ref[2].expired()) ? g_cache.erase(d) : std::next(d);
       it = g_cache.insert_or_assign(key, std::move(e)).first;

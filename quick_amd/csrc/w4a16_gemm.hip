@@ -1322,7 +1322,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   // 64 x 128 tiles to cover the chip (large N): 13 % ahead of the r01 kernels on average over 45 (M, K, N) shapes between
   // 64 x 4096 x 12288 and 8192 x 4096 x 22016, never behind by more than 3 % [r02 probes, profiles/r02_planner_probe*.jsonl].
   // The tile (mb x 32 tokens, pairs x 128 channels) minimises a fitted launch-time model, see below.
-  int wide_mb = 0, wide_pairs = 0;
+  int wide_mb = 0, wide_pairs = 0, xk_auto_mb = 0;
   bool wide_ring = false;
   // K slices of a wide launch: as many as keep the workgroups within one round of 256 and the slices >= 4 stages -- any count,
   // not only powers of two (80 tiles run 3 slices = 240 workgroups; Llama-2-13B's N = 5120 is 40 / 80 tiles wide)
@@ -1407,8 +1407,48 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
       if (wide_mb < 0) wide_mb = 0;
       else model_tiled_mt = 0;
     }
-    if (wide_mb) p.kernel = QUICK_KERNEL_WIDE;
+    // [r03] the exchange-K kernels (w4a16_xk.hpp) compete in the same model where their workgroups -- tiles x K slices, slices = the
+    // largest power of two that still fits one round -- are co-resident.  Fitted (relative least squares, 246 / 336 rows of
+    // scripts/gpu_xk_sweep.sh: 15 layer shapes x 24..1024 tokens, 4.4 / 3.7 % rms) and brought to this model's scale with the same
+    // session's measurements of the planner's own wide picks (194 rows, predicted / measured = 0.945):
+    //   us = c + stages (b0 + b1 f) + [s > 1] (s0 + s1 s) + d f,   f = workgroups / 256
+    // 64-token tiles: the r02 ring tile with the weights in an AGPR queue and five x slots, 3-6 % ahead of it wherever both run
+    // (512 x 4096 x 4096 22.6 against 23.8 us); 128-token tiles with 2 / 4 slices: 384 x 11008 x 4096 1.16x, 640 x 4096 x 4096 1.12x.
+    if (best > 0) {
+      static const double xc[2][6] = {{1.728, 0.3869, 0.1572, 2.320, 0.1693, 2.064}, {3.422, 0.4881, 0.3847, 1.214, 0.4284, 2.382}};
+      const int cus = cu_count();
+      for (int c = 0; c < 2; ++c) {
+        const int mb = c == 0 ? 2 : 4;
+        const long T = (long)((M + mb * 32 - 1) / (mb * 32)) * (N / 128);
+        int sx = 1;
+        while (sx < 8 && T * sx * 2 <= cus && KT / (sx * 2) >= 4) sx *= 2;
+        while (sx > 1 && (T * sx > cus || (KT + (KT + sx - 1) / sx - 1) / ((KT + sx - 1) / sx) != sx)) sx /= 2;
+        if (T * sx > 256) continue;  // (several rounds: the 128 x 256 / 256 x 256 tiles of the wide family are ahead, 0.8x in the sweep)
+        const double f = (double)(T * sx) / 256.0, stages = (double)((KT + sx - 1) / sx);
+        const double cost = xc[c][0] + stages * (xc[c][1] + xc[c][2] * f) + (sx > 1 ? xc[c][3] + xc[c][4] * sx : 0.0) + xc[c][5] * f;
+        if (cost < best) {
+          best = cost;
+          xk_auto_mb = mb;
+          wide_mb = 0;
+          model_tiled_mt = 0;
+        }
+      }
+    }
+    if (xk_auto_mb) p.kernel = QUICK_KERNEL_XK;
+    else if (wide_mb) p.kernel = QUICK_KERNEL_WIDE;
     else if (model_tiled_mt) p.kernel = QUICK_KERNEL_TILED;
+  }
+  // [r03] 33..64 tokens where the rules above leave the 32-token tiled kernel with a K split: one 64-token exchange-K tile per CU
+  // instead, when its slices are few (<= 4) and long (>= 8 stages) and cover most of the chip -- Mistral's fused GQA qkv, 4096 x
+  // 6144, at 48 / 64 tokens 12.8 / 13.0 -> 10.6 / 10.8 us, 64 x 5120 x 5120 13.5 -> 11.6 [scripts/gpu_xk_sweep.sh]
+  if (family == QUICK_KERNEL_AUTO && p.kernel == QUICK_KERNEL_TILED && G % 128 == 0 && M > 32 && M <= 64 && !mt_req && !waves_req) {
+    const long T = N / 128;
+    int sx = 1;
+    while (sx < 8 && T * sx * 2 <= 256 && KT / (sx * 2) >= 4) sx *= 2;
+    if (sx <= 4 && T * sx >= 160 && T * sx <= cu_count() && KT % sx == 0 && KT / sx >= 8) {
+      p.kernel = QUICK_KERNEL_XK;
+      xk_auto_mb = 2;
+    }
   }
   int ks = 1;
   if ((p.kernel == QUICK_KERNEL_WIDE || p.kernel == QUICK_KERNEL_XK) && G % 128 != 0) p.kernel = QUICK_KERNEL_TILED;  // small groups: r01's tiled kernel
@@ -1419,7 +1459,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     // exchange-K kernels (w4a16_xk.hpp): tile = mb * 32 tokens x 128 channels, eight waves; the S slices of a tile run on S compute
     // units at the same time and swap parts of their partial tiles, so S > 1 needs the whole grid co-resident: tiles * S <= CUs.
     // bits 4-7: mb (2, 4; 0 = by M), bits 8-11: S (1, 2, 4, 8; 0 = as many as fit), bits 22-24: x ring slots, bits 26-28: weight queue depth
-    const int mb = (mt_req == 2 || mt_req == 4) ? mt_req : (M > 64 ? 4 : 2);
+    const int mb = xk_auto_mb ? xk_auto_mb : ((mt_req == 2 || mt_req == 4) ? mt_req : (M > 64 ? 4 : 2));
     const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / 128;
     const int cus = cu_count();
     p.wide_mb = mb;
@@ -1430,8 +1470,10 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     const int s_req = grid_split_k > 0 ? grid_split_k : (kernel >> 8) & 15;
     int s = 1;
     if (s_req == 1 || s_req == 2 || s_req == 4 || s_req == 8) s = s_req;
-    else
+    else {
       while (s < 8 && (long)p.ntiles * s * 2 <= cus && KT / (s * 2) >= 4) s *= 2;
+      if (s_req == 15 && s > 1) s /= 2;  // (tuning sweeps: half the count the rule gives)
+    }
     // (the slices must fit the chip, and ceil-dividing K must give exactly S non-empty slices)
     while (s > 1 && ((long)p.ntiles * s > cus || (KT + (KT + s - 1) / s - 1) / ((KT + s - 1) / s) != s)) s /= 2;
     p.ksplit = s;

@@ -71,6 +71,9 @@ bool xk_launch(const XkConfig& c, const GemmArgs& a, int workgroups, hipStream_t
       case 576: return xk_go<4, 5, 4, 2, 576>(a, workgroups, st, start, stop);  // no weight loads in the K loop
       case 1088: return xk_go<4, 5, 4, 2, 1088>(a, workgroups, st, start, stop);  // one x piece with every unit
       case 4160: return xk_go<4, 5, 4, 2, 4160>(a, workgroups, st, start, stop);  // four loader waves issue the x pieces
+      case 8256: return xk_go<4, 5, 4, 2, 8256>(a, workgroups, st, start, stop);  // + clocks spent in the counted wait / at the barrier
+      case 8258: return xk_go<4, 5, 4, 2, 8258>(a, workgroups, st, start, stop);  // ... without loads
+      case 16720: return xk_go<4, 5, 4, 2, 16720>(a, workgroups, st, start, stop);  // weight loads only, always the same (cached) stage, no B-fragment reads
       case 80: return xk_go<4, 5, 4, 2, 80>(a, workgroups, st, start, stop);      // loads, no B-fragment reads
       case 72: return xk_go<4, 5, 4, 2, 72>(a, workgroups, st, start, stop);      // loads, no dequantisation
       case 88: return xk_go<4, 5, 4, 2, 88>(a, workgroups, st, start, stop);      // loads, MFMAs, barrier

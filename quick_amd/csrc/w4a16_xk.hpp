@@ -372,9 +372,10 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
   constexpr int MID = FAST ? (PX == 1 ? XI : 6 + XI) : (NBUF - 3) * L + 2 + (UM - 1) * PER;
   static_assert(MID <= 63, "vmcnt field");
   unsigned cur = 0u, nxt = (unsigned)SLOT, fill = (unsigned)(NBUF - 1) * SLOT;  // slots of stage s, s + 1, s + NBUF - 1
+  unsigned long long seg_wait = 0, seg_bar = 0;
   auto stage = [&](auto jc, int s) __attribute__((always_inline)) {
     constexpr int J = decltype(jc)::value;
-    const int ktx = min(t.kt_lo + s + NBUF - 1, t.kt_hi - 1), ktw = min(t.kt_lo + s + WD, t.kt_hi - 1);
+    const int ktx = min(t.kt_lo + s + NBUF - 1, t.kt_hi - 1), ktw = (ABL & 16384) ? t.kt_lo : min(t.kt_lo + s + WD, t.kt_hi - 1);  // (16384: the same, cache-resident weight stage every time)
     read_w(xk_ic<(J + 1) % WD>{}, wnx);  // W(s + 1): landed since the wait that ended stage s - 1
     wide_compute<MB, 1, GM, (ABL & 27), true, 2>(wc, wnx, xrd + cur, xrd + nxt, dq, acc, carry, [&](int u) {
       if constexpr (!(ABL & 2)) {
@@ -410,6 +411,8 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
         }
       }
     });
+    unsigned long long tq0 = 0, tq1 = 0;
+    if constexpr (ABL & 8192) tq0 = __builtin_amdgcn_s_memtime();
     if constexpr (!(ABL & 2) && !(ABL & 128)) {  // x stage s + 2 and weight set s + 2 have landed ...
       bool s0 = false, s1 = false;
       if constexpr (J == 0) s0 = s == 0;
@@ -419,7 +422,13 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
       else if (s1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(END1) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");
     }
+    if constexpr (ABL & 8192) tq1 = __builtin_amdgcn_s_memtime();
     if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();  // ... in every wave; everybody is done with x stage s
+    if constexpr (ABL & 8192) {  // (experiment: shader clocks a wave spends in the counted wait / at the barrier, summed over the stages)
+      const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
+      seg_wait += tq1 - tq0;
+      seg_bar += tq2 - tq1;
+    }
     wc = wnx;
     fill = cur;
     cur = nxt;
@@ -674,6 +683,7 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
 #pragma unroll
       for (int i = 0; i < 6; ++i) o[i] = ph[i];
       o[6] = cyc;
+      if constexpr (ABL & 8192) o[7] = (seg_wait << 32) | (seg_bar & 0xffffffffull);
     }
   }
 }

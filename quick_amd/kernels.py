@@ -37,18 +37,28 @@ def _stream():
 
 _WORKSPACES = {}          # (device index, stream handle) -> zero-filled uint8 tensor; insertion order = recency
 _WORKSPACES_MAX = 16      # stream handles are recycled by the runtime: keep the few most recently used, drop the rest
+_CAPTURED = set()         # keys whose buffer a hipGraph capture has baked into kernel arguments: never evicted
+_KEEPALIVE = []           # buffers a capture used and that were outgrown since: a replayed graph still writes into them
 
 
 def _workspace(device, nbytes):
-    """Zero-filled scratch for the in-kernel split-K reduction, one per (device, stream), grown on demand.  The
-    library hands it back zeroed after every launch, so it is allocated and cleared only when it has to grow."""
+    """Zero-filled scratch for the in-kernel split-K reduction / K-slice exchange, one per (device, stream), grown on demand.
+    The library hands it back zeroed after every launch, so it is allocated and cleared only when it has to grow.  A buffer
+    that was used while its stream was being captured is pinned: the graph holds its address (counters and mailboxes that must
+    be zero on entry), so it is neither evicted by the LRU cap nor freed when a later, larger request replaces it."""
     key = (device.index, _stream())
+    capturing = torch.cuda.is_current_stream_capturing()
     ws = _WORKSPACES.pop(key, None)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None and key in _CAPTURED:
+            _KEEPALIVE.append(ws)
         ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
     _WORKSPACES[key] = ws                                  # most recently used last
-    while len(_WORKSPACES) > _WORKSPACES_MAX:
-        _WORKSPACES.pop(next(iter(_WORKSPACES)))           # (in-flight launches keep their buffer alive through the allocator's stream ordering)
+    if capturing:
+        _CAPTURED.add(key)
+    evictable = [k for k in _WORKSPACES if k not in _CAPTURED]
+    while len(evictable) > _WORKSPACES_MAX:
+        _WORKSPACES.pop(evictable.pop(0))                  # (in-flight launches keep their buffer alive through the allocator's stream ordering)
     return ws
 
 
@@ -131,7 +141,7 @@ def _tensor_version(t):
 
 
 class _Repacked:
-    __slots__ = ("refs", "versions", "packed")
+    __slots__ = ("refs", "versions", "packed", "stream", "event")
 
 
 _REPACK_CACHE = {}     # (data_ptr of qweight, scales, qzeros) -> _Repacked; entries die with the tensors they mirror
@@ -152,13 +162,24 @@ def reference_to_mi355x_cached(kernel, scaling_factors, zeros):
     versions = tuple(_tensor_version(t) for t in tensors)
     ent = _REPACK_CACHE.get(key)
     if ent is not None and ent.versions == versions and all(r() is t for r, t in zip(ent.refs, tensors)):
+        if kernel.is_cuda:
+            cur = torch.cuda.current_stream(kernel.device)
+            if cur != ent.stream:      # made on another stream: wait for the repack, and tell the allocator who else reads the copy
+                cur.wait_event(ent.event)
+                for t in ent.packed:
+                    t.record_stream(cur)
         return ent.packed
     ent = _Repacked()
+    ent.stream = ent.event = None
     if kernel.shape[0] * 4 % 128 == 0:
         ent.packed = repack_cuda_to_mi355x(kernel, scaling_factors, zeros)
     else:
         ent.packed = _padded_mi355x(kernel, scaling_factors, zeros)
     ent.versions = versions
+    if kernel.is_cuda:
+        ent.stream = torch.cuda.current_stream(kernel.device)
+        ent.event = torch.cuda.Event()
+        ent.event.record(ent.stream)
     drop = lambda _ref, key=key: _REPACK_CACHE.pop(key, None)
     ent.refs = tuple(weakref.ref(t, drop) for t in tensors)
     _REPACK_CACHE[key] = ent

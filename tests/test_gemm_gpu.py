@@ -46,7 +46,8 @@ GOLD = [p for p in golden_files("exact_") if "k64" not in p] + golden_files("qua
 
 @pytest.mark.parametrize("kernel_id,ksplit", [(0, 0), (SKINNY_DZ, 1), (SKINNY_DZ, 2), (SKINNY_EXACT, 1), (SKINNY_EXACT, 2),
                                               (TILED, 1), (TILED, 2), (3, 1), (3, 2), (3 | (8 << 4) | (2 << 8), 1),
-                                              (3 | (4 << 4) | (1 << 8), 2)])
+                                              (3 | (4 << 4) | (1 << 8), 2), (4, 0), (4 | (2 << 4), 2), (4 | (4 << 4), 1),
+                                              (4 | (4 << 4) | (2 << 8), 0)])
 @pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[:-4])
 def test_golden_fixture_forward(qa, device, path, kernel_id, ksplit):
     g = load_golden(path)
@@ -109,6 +110,7 @@ TILED_16WAVES = TILED | (4 << 8)      # 4 x 4 waves per workgroup
 TILED_WIDE = TILED | (1 << 29)        # 64 x 256 workgroup tiles (the planner's choice once they cover the 256 CUs: large M)
 TILED_BIG = TILED | (1 << 27)         # 128 x 256 tiles run by four waves with 128 accumulators each (large M)
 WIDE = 3                              # 32x32x16 MFMA kernel, one wave per SIMD, activations by LDS-DMA (large M)
+XK = 4                                # exchange-K kernels: 64- / 128-token tiles whose K slices run on different CUs and swap partial tiles
 
 
 def wide(mb, pairs):                  # explicit workgroup tile: mb * 32 tokens x pairs * 128 channels
@@ -338,7 +340,8 @@ def pin(device):
     return g, iw, s, z
 
 
-@pytest.mark.parametrize("kernel_id", [0, SKINNY_EXACT, SKINNY_DZ, TILED, WIDE], ids=["auto", "skinny-exact", "skinny-dz", "tiled", "wide"])
+@pytest.mark.parametrize("kernel_id", [0, SKINNY_EXACT, SKINNY_DZ, TILED, WIDE, 4 | (2 << 4), 4 | (4 << 4)],
+                         ids=["auto", "skinny-exact", "skinny-dz", "tiled", "wide", "xk64", "xk128"])
 def test_baseline_size_reference_pin(qa, device, pin, kernel_id):
     """K = N = 4096, g = 128: the HIP result against sampled outputs of the REFERENCE's CPU path on the same layer."""
     g, iw, s, z = pin
@@ -354,11 +357,13 @@ def test_baseline_size_reference_pin_at_bench_token_counts(qa, device, pin, M):
     reference-made value (rows of a GEMM are independent; test_baseline_rows_are_independent_of_batch)."""
     g, iw, s, z = pin
     x = np.tile(g["x"], (M // g["x"].shape[0], 1))
-    y = qa.gemm_forward(_dev(x, device), *_pack_dev(iw, s, z, device)).cpu().numpy().astype(np.float32)
+    packed = _pack_dev(iw, s, z, device)
     ref = g["y_ref"].astype(np.float32)
-    for rep in (0, M // 16 - 1):
-        assert float(np.abs(y[g["y_rows"] + 16 * rep, g["y_cols"]] - ref).max()) <= TOL * float(np.abs(ref).max())
-    assert float(np.abs(np.abs(y).sum(0) - g["col_abs_sum"] * (M // 16)).max()) <= TOL * float(g["col_abs_sum"].max()) * (M // 16)
+    for kernel_id in (0, XK | (2 << 4), XK | (4 << 4)):     # the planner's kernel, and the exchange-K tiles (K slices on different CUs)
+        y = qa.gemm_forward(_dev(x, device), *packed, kernel_id=kernel_id).cpu().numpy().astype(np.float32)
+        for rep in (0, M // 16 - 1):
+            assert float(np.abs(y[g["y_rows"] + 16 * rep, g["y_cols"]] - ref).max()) <= TOL * float(np.abs(ref).max())
+        assert float(np.abs(np.abs(y).sum(0) - g["col_abs_sum"] * (M // 16)).max()) <= TOL * float(g["col_abs_sum"].max()) * (M // 16)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -837,7 +842,21 @@ def test_random_shapes_against_dequantised_matmul(qa, device):
         assert torch.equal(y1, y2), (case, M, K, N, G, K_.plan_describe(M, K, N, G))
         err = (y1.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
         assert err <= TOL, (case, M, K, N, G, err, K_.plan_describe(M, K, N, G))
+        _check_sampled_columns_against_oracle(y1, x, qw, sc, qz, G, seed=case, what=(case, M, K, N, G, K_.plan_describe(M, K, N, G)))
     print(f"{case + 1} random shapes checked")
+
+
+def _check_sampled_columns_against_oracle(y, x, qw, sc, qz, G, seed, what, add=None, ncols=128, tol=TOL):
+    """Second net of the random-shape tests, independent of the GPU's own dequantisation kernel: `ncols` sampled output channels
+    of a layer made on the GPU, evaluated by the CPU oracle's closed form (oracle.unpack_mi355x_columns + w4a16_forward)."""
+    N = y.shape[1]
+    cols = np.unique(np.random.default_rng(seed).integers(0, N, ncols))
+    iw, s, z = oracle.unpack_mi355x_columns(qw.cpu().numpy(), sc.cpu().numpy(), qz.cpu().numpy(), cols)
+    ref = oracle.w4a16_forward(x.cpu().numpy(), iw, s, z, G).astype(np.float32)
+    if add is not None:
+        ref = ref + add[:, cols] if add.ndim == 2 else ref + add[cols]
+    got = y[:, torch.from_numpy(cols).to(y.device)].float().cpu().numpy()
+    assert float(np.abs(got - ref).max()) <= tol * max(float(np.abs(ref).max()), 1e-30), what
 
 
 def test_random_shapes_with_fused_epilogues_and_prologue(qa, device):
@@ -866,12 +885,16 @@ def test_random_shapes_with_fused_epilogues_and_prologue(qa, device):
         if kind == 4 and not K_.can_fuse_rmsnorm(M, K, N, G):
             kind = 1
         seen.add(kind)
+        what = (case, kind, M, K, N, G, K_.plan_describe(M, K, N, G))
         if kind == 0:
             y, ref = qa.gemm_forward(x, qw, sc, qz, bias=bias), x.float() @ w + bias.float()
+            _check_sampled_columns_against_oracle(y, x, qw, sc, qz, G, 1000 + case, what, add=bias.float().cpu().numpy())
         elif kind == 1:
             y, ref = qa.gemm_forward(x, qw, sc, qz, residual=res), x.float() @ w + res.float()
+            _check_sampled_columns_against_oracle(y, x, qw, sc, qz, G, 1000 + case, what, add=res.float().cpu().numpy())
         elif kind == 2:
             y, ref = qa.gemm_forward(x, qw, sc, qz, bias=bias, residual=res), x.float() @ w + bias.float() + res.float()
+            _check_sampled_columns_against_oracle(y, x, qw, sc, qz, G, 1000 + case, what, add=(bias.float()[None, :] + res.float()).cpu().numpy())
         elif kind == 3:
             gu = (x.float() @ w).half().view(M, N // 16, 2, 8)                 # gate / up interleaved by 8
             ref = (torch.nn.functional.silu(gu[:, :, 0].float()).half() * gu[:, :, 1]).reshape(M, N // 2).float()
@@ -942,3 +965,102 @@ def test_wide_tiles_epilogues_and_k_split(qa, device, M, K, N, G, kernel_id):
     y_act = qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kernel_id)
     torch.testing.assert_close(y_act, K_.silu_mul(qa.gemm_forward(xd, *packed, kernel_id=kernel_id)), rtol=2e-3, atol=2e-3)
 
+
+
+def test_fused_decode_step_llama2_7b_layer_matches_torch_glue(qa, device):
+    """The stack bench.py times, at its real widths: ONE Llama-2-7B decoder layer (4096 hidden, 11008 intermediate, 32 heads) at
+    bs = 1 and 16 -- the fused decode step (HIP glue kernels, GEMM epilogues, RMSNorm prologues) against the torch-op step."""
+    import dataclasses
+    from quick_amd.decoder import CONFIGS, SyntheticDecoder, decode_step_fused
+    cfg = dataclasses.replace(CONFIGS["llama2-7b"], layers=1, vocab=2048)
+    for batch in (1, 16):
+        ma = SyntheticDecoder(cfg, batch=batch, max_len=48, device=device, seed=5)
+        mb = SyntheticDecoder(cfg, batch=batch, max_len=48, device=device, seed=5)
+        ctx = 24
+        tokens = torch.randint(0, cfg.vocab, (batch, ctx), device=device)
+        ta = ma.forward(tokens, torch.arange(ctx, device=device), None)
+        tb = mb.forward(tokens, torch.arange(ctx, device=device), None)
+        assert torch.equal(ta, tb)
+        pos = torch.full((1,), ctx, dtype=torch.int64, device=device)
+        mask = torch.full((1, 1, 1, 48), float("-inf"), dtype=torch.float16, device=device)
+        mask[..., :ctx + 1] = 0
+        for step in range(2):
+            _, hid_f = decode_step_fused(mb, ta.view(batch, 1), pos)
+            x_ref = _torch_decode_hidden(ma, ta.view(batch, 1), pos, mask)
+            err = (hid_f.float() - x_ref.float()).abs().max() / x_ref.float().abs().max()
+            assert err <= 1e-2, (batch, step, float(err))
+            ta = (x_ref @ ma.lm_head.t()).argmax(-1)
+            pos += 1
+            mask[..., ctx + step + 1] = 0
+
+
+# ------------------------------------------------------------------------------------------------
+# exchange-K kernels (quick_amd/csrc/w4a16_xk.hpp): K slices of a tile on different CUs, partial tiles swapped through mailboxes
+# ------------------------------------------------------------------------------------------------
+def xk(mb, s=0):
+    return XK | (mb << 4) | (s << 8)
+
+
+@pytest.mark.parametrize("S", [1, 2, 4, 8])
+@pytest.mark.parametrize("mb", [2, 4], ids=["64tok", "128tok"])
+@pytest.mark.parametrize("M,K,N,G", [(300, 512, 512, 128), (77, 1152, 768, 128), (1, 1024, 1024, 128), (513, 1024, 256, 128),
+                                     (64, 2048, 384, 128), (130, 4096, 256, 256), (40, 1536, 128, 512)])
+def test_xk_family_against_oracle(qa, device, M, K, N, G, mb, S):
+    """Every slice count x both tile sizes: ragged token counts, odd stage counts (K / 128 not a multiple of S: the planner lowers S),
+    group sizes above 128; plain, bias + residual (bit for bit the two-step result), SiLU * mul where a wave finishes whole
+    32-token blocks; every result twice (the sums are taken in slice order: no dependence on timing)."""
+    from quick_amd import kernels as K_
+    kid = xk(mb, S)
+    plan = K_.plan_describe(M, K, N, G, kid)
+    assert plan.startswith("xk"), plan
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + K + N + G + S)
+    want = oracle.w4a16_forward(x, iw, s, z, G).astype(np.float32)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device)
+    bias = torch.linspace(-1, 1, N, device=device).half()
+    res = torch.randn(M, N, device=device).half()
+    y = qa.gemm_forward(xd, *packed, kernel_id=kid)
+    assert rel_err(y.cpu().numpy(), want) <= TOL, plan
+    assert torch.equal(y, qa.gemm_forward(xd, *packed, kernel_id=kid)), plan
+    yb = qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=kid)
+    two = (qa.gemm_forward(xd, *packed, bias=bias, kernel_id=kid).float() + res.float()).half()
+    assert torch.equal(yb, two), plan
+    assert rel_err(yb.cpu().numpy(), want + bias.float().cpu().numpy() + res.float().cpu().numpy()) <= TOL, plan
+    slices = int(plan.split("slices=")[1].split()[0])
+    if (mb // 2 * 16) % (16 * slices) == 0:
+        y_act = qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kid)
+        assert y_act.shape == (M, N // 2)
+        torch.testing.assert_close(y_act, K_.silu_mul(y), rtol=2e-3, atol=2e-3)
+    else:
+        with pytest.raises(NotImplementedError):
+            qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kid)
+
+
+def test_xk_exchange_under_uneven_load(qa, device):
+    """The mailbox protocol under uneven load: launches of different slice counts and tile sizes alternate on ONE workspace (the exchange
+    zone is shared and must be all-zero again after every launch) while a second stream keeps part of the chip busy with dense
+    GEMMs of changing size, so that the slices of a tile finish at different times and some arrive long before their partners.
+    Every word of every result is compared with the first launch's, and the first launch with the oracle."""
+    cases = []
+    for (M, K, N), kid in (((512, 4096, 4096), xk(4, 2)), ((512, 4096, 4096), xk(2, 1)), ((256, 4096, 4096), xk(4, 4)), ((128, 4096, 4096), xk(4, 8)),
+                           ((64, 4096, 4096), xk(2, 8)), ((64, 8192, 2048), xk(2, 4)), ((200, 2048, 1024), xk(2, 2)), ((130, 1024, 3072), xk(4, 2))):
+        x, iw, s, z = oracle.make_synthetic(M, K, N, 128, seed=M + N + K)
+        cols = np.unique(np.random.default_rng(M + N).integers(0, N, 96))
+        want = oracle.w4a16_forward(x, iw[:, cols], s[:, cols], z[:, cols], 128).astype(np.float32)
+        cases.append((_dev(x, device), _pack_dev(iw, s, z, device), kid, torch.from_numpy(cols).to(device), want))
+    side = torch.cuda.Stream()
+    a = torch.randn(2048, 2048, device=device).half()
+    first = [None] * len(cases)
+    for rep in range(12):
+        with torch.cuda.stream(side):
+            for i in range(3 + rep % 4):
+                n = 256 * (1 + (rep + i) % 8)
+                torch.matmul(a[:n], a)
+        for i, (xd, packed, kid, cols, want) in enumerate(cases):
+            y = qa.gemm_forward(xd, *packed, kernel_id=kid)
+            if first[i] is None:
+                first[i] = y
+                got = y[:, cols].float().cpu().numpy()
+                assert float(np.abs(got - want).max()) <= TOL * float(np.abs(want).max()), (rep, i)
+            assert torch.equal(y, first[i]), (rep, i)
+    torch.cuda.synchronize()

@@ -30,7 +30,7 @@ for spec in (args or ["512x4096x4096"]):
     ws = torch.zeros((need + DBG) // 8, dtype=torch.int64, device=dev)
     k16 = kid + (abl << 16)
     REP = 8
-    acc, cycs = [], []
+    acc, cycs, segs = [], [], []
     for i in range(40 + REP):   # the first 40 warm the clocks up; the rest are read back one by one: HBM-cold weights every time
         qw, sc, qz = sets[i % 40]
         ws[need // 8:].zero_()
@@ -44,6 +44,7 @@ for spec in (args or ["512x4096x4096"]):
             keep = d[:, 5] > 0
             acc.append(d[keep])
             cycs.append(raw[keep, 6].astype(np.float64))
+            segs.append(raw[keep, 7].astype(np.uint64))
     names = ["entry -> first fragments", "K loop", "K parities swapped through LDS", "slices exchanged (mailboxes)", "way out (image, stores acknowledged)"]
     tot = np.mean([d[:, 5].max() - d[:, 0].min() for d in acc])
     print(f"{spec} abl={abl} env={os.environ.get('QUICK_XK_ABL', '-')}: {plan}\n   {len(acc[0])} waves stamped, {REP} launches; first entry -> last wave done {tot:.2f} us"
@@ -54,5 +55,9 @@ for spec in (args or ["512x4096x4096"]):
     kl = np.mean([(d[:, 2] - d[:, 1]).mean() for d in acc])
     kc = np.mean([c.mean() for c in cycs])
     print(f"   K loop: {kc:.0f} shader clocks per wave in {kl:.2f} us = {kc / kl / 1000:.3f} GHz")
+    sw = np.mean([(g >> np.uint64(32)).astype(np.float64).mean() for g in segs])
+    sb = np.mean([(g & np.uint64(0xffffffff)).astype(np.float64).mean() for g in segs])
+    if sw + sb > 0:
+        print(f"   of those clocks: {sw:.0f} in the counted wait at the end of a stage, {sb:.0f} at the barrier (per wave, all stages)")
     r = np.array([[(d[:, i] - d[:, 0].min()).mean() for i in range(1, 6)] for d in acc]).mean(0)
     print("   phases reached since first entry (mean over waves): " + "  ".join(f"{v:.2f}" for v in r))
