@@ -1425,7 +1425,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
         while (sx > 1 && (T * sx > cus || (KT + (KT + sx - 1) / sx - 1) / ((KT + sx - 1) / sx) != sx)) sx /= 2;
         if (T * sx > 256) continue;  // (several rounds: the 128 x 256 / 256 x 256 tiles of the wide family are ahead, 0.8x in the sweep)
         const double f = (double)(T * sx) / 256.0, stages = (double)((KT + sx - 1) / sx);
-        const double cost = xc[c][0] + stages * (xc[c][1] + xc[c][2] * f) + (sx > 1 ? xc[c][3] + xc[c][4] * sx : 0.0) + xc[c][5] * f;
+        // (128-token tiles + 4 %: where the two are close the 64-token tile was the better pick in the audit that followed,
+        // 128 x 7168 x 7168 22.2 -> 21.0 us, 160 x 14336 x 4096 35.2 -> 32.7 [scripts/gpu_xk_audit.sh])
+        const double cost = (xc[c][0] + stages * (xc[c][1] + xc[c][2] * f) + (sx > 1 ? xc[c][3] + xc[c][4] * sx : 0.0) + xc[c][5] * f) * (c == 1 ? 1.04 : 1.0);
         if (cost < best) {
           best = cost;
           xk_auto_mb = mb;
@@ -1439,13 +1441,16 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     else if (model_tiled_mt) p.kernel = QUICK_KERNEL_TILED;
   }
   // [r03] 33..64 tokens where the rules above leave the 32-token tiled kernel with a K split: one 64-token exchange-K tile per CU
-  // instead, when its slices are few (<= 4) and long (>= 8 stages) and cover most of the chip -- Mistral's fused GQA qkv, 4096 x
-  // 6144, at 48 / 64 tokens 12.8 / 13.0 -> 10.6 / 10.8 us, 64 x 5120 x 5120 13.5 -> 11.6 [scripts/gpu_xk_sweep.sh]
+  // instead, when its slices are long (>= 8 stages) and cover most of the chip -- Mistral's fused GQA qkv, 4096 x 6144, at 48 / 64
+  // tokens 12.8 / 13.0 -> 10.6 / 10.8 us, 64 x 5120 x 5120 13.5 -> 11.6; with eight slices, 40..64 x 11008 / 14336 x 4096 (the down
+  // projections at batch 40..64): 16.6-19.8 -> 14.6-16.4 us in two sessions of three, 3 % behind in the third
+  // [scripts/gpu_xk_sweep.sh, gpu_xk_audit.sh]
   if (family == QUICK_KERNEL_AUTO && p.kernel == QUICK_KERNEL_TILED && G % 128 == 0 && M > 32 && M <= 64 && !mt_req && !waves_req) {
     const long T = N / 128;
     int sx = 1;
     while (sx < 8 && T * sx * 2 <= 256 && KT / (sx * 2) >= 4) sx *= 2;
-    if (sx <= 4 && T * sx >= 160 && T * sx <= cu_count() && KT % sx == 0 && KT / sx >= 8) {
+    while (sx > 1 && (KT + (KT + sx - 1) / sx - 1) / ((KT + sx - 1) / sx) != sx) sx /= 2;
+    if (T * sx >= 160 && T * sx <= cu_count() && KT / sx >= 8) {
       p.kernel = QUICK_KERNEL_XK;
       xk_auto_mb = 2;
     }

@@ -171,7 +171,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "grid=464x1x1" in plan(1, 4096, 22016)          # 1376 blocks in 3 rounds of <= 464
     assert "dequant=exact" in plan(8, 4096, 4096)            # one block per workgroup: the table does not pay
     assert plan(64, 4096, 4096).startswith("skinny ntw=4") and "deferred-zero-fragment" in plan(64, 4096, 4096)
-    assert plan(65, 4096, 4096).startswith("tiled")
+    assert plan(65, 4096, 4096).startswith("xk tokens=64") and "slices=4" in plan(65, 4096, 4096)   # r03: 32 exchange-K tiles x 4 K slices = one round
     assert plan(32, 4096, 8192).startswith("skinny ntw=4")   # 256 workgroups of 64 channels x 16 tokens: one round, 32 stages each
     assert plan(32, 4096, 12288).startswith("tiled")         # 384 of them would be two: the tiled kernel, no K split needed
     # K split until the 256 CUs are covered; the workspace is what workspace_bytes_ex says
@@ -179,7 +179,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "tokens=32 channels=128" in p and "ksplit=2" in p
     assert p.endswith(f"workspace={_lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, kernels.KERNEL_TILED, 0)}")
     p = plan(128, 4096, 4096)
-    assert p.endswith(f"workspace={_lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, 0, 0)}") and "ksplit=1" not in p
+    assert p.endswith(f"workspace={_lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, 0, 0)}") and "slices=4" in p
     assert "grid=80x3 ksplit=3" in plan(64, 8192, 10240)     # not only powers of two: 240 of 256 CUs (tiled and wide kernels alike)
     assert "grid=80x3 ksplit=3" in plan(64, 8192, 10240, kernel_id=kernels.KERNEL_TILED)
     # r01's tiled kernel (kernel_id TILED; the planner's own choice for G < 128): 256-channel tiles by how they quantise onto 256 CUs
@@ -194,11 +194,16 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "channels=256" in plan(8192, 4096, 22016, kernel_id=T)
     assert plan(512, 4096, 4096, G=64).startswith("tiled")                # small groups: the wide kernels need G % 128 == 0
     # r02: the wide kernels (32x32x16 MFMA, LDS-DMA) from 256 tokens, and from 64 once 64 x 128 tiles cover the chip
-    assert plan(512, 4096, 4096).startswith("wide tokens=64 channels=128 waves=8 ring=4 grid=256x1")   # one tile per CU: the LDS-DMA ring, eight waves
-    assert plan(256, 4096, 4096).startswith("wide") and plan(65, 4096, 4096).startswith("tiled tokens=32")   # 65..256 tokens: one launch-time model over both
-    assert "tiled tokens=32 channels=128 waves=8 grid=240x1 ksplit=1" in plan(160, 4096, 6144)                # five exact rows of 32-token tiles
-    assert plan(64, 4096, 22016).startswith("wide tokens=64") and plan(64, 4096, 12288).startswith("wide tokens=64")   # from 96 tiles of 64 x 128
-    assert "tokens=128 channels=128 waves=4 ring=0 grid=256x1" in plan(1024, 4096, 4096)  # 256 tiles of 128 x 128: one round
+    assert plan(512, 4096, 4096, kernel_id=kernels.KERNEL_WIDE | (2 << 4) | (1 << 8) | (1 << 15) | (4 << 22)).startswith(
+        "wide tokens=64 channels=128 waves=8 ring=4 grid=256x1")                                       # r02's pick there: the LDS-DMA ring, eight waves
+    # r03: the exchange-K tiles (weights in an AGPR queue, five x slots, K slices on different CUs) wherever their workgroups fit one round
+    assert plan(512, 4096, 4096).startswith("xk tokens=64 channels=128 waves=8 ring=5 queue=4 grid=256 slices=1")      # the bench line: one 64 x 128 tile per CU
+    assert "xk tokens=64" in plan(256, 4096, 4096) and "slices=2" in plan(256, 4096, 4096)
+    assert plan(160, 4096, 6144).startswith("xk tokens=64") and "slices=1" in plan(160, 4096, 6144)
+    assert plan(64, 4096, 22016).startswith("xk tokens=64") and "slices=2" in plan(64, 4096, 12288)   # 172 / 96 tiles of 64 x 128
+    assert plan(1024, 4096, 4096).startswith("xk tokens=128 channels=128 waves=8 ring=5 queue=4 grid=256 slices=1")   # 256 tiles of 128 x 128: one round
+    assert "slices=2" in plan(512, 11008, 4096) and "tokens=128" in plan(512, 11008, 4096)             # 128 tiles x 2 slices of 43 stages
+    assert plan(2048, 3584, 18944).startswith("wide")                                                  # several rounds: the wide family's larger tiles
     assert "tokens=128 channels=256" in plan(2048, 4096, 4096) and "tokens=256 channels=256" in plan(8192, 4096, 22016)
     assert "tokens=128 channels=256 waves=4 ring=0 grid=144x1" in plan(384, 4096, 12288)  # fitted launch-time model: 45.2 us against 49.4-64 for the others
     W = kernels.KERNEL_WIDE
@@ -213,13 +218,13 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "deferred-zero-table" in plan(12, 4096, 22016) and plan(16, 4096, 22016).startswith("skinny ntw=4")
     # third audit (17..64 tokens, layer shapes the rules were not tuned on): the four-tile skinny kernel by its own geometry
     assert plan(32, 4096, 6144).startswith("skinny ntw=4") and plan(32, 4096, 4096).startswith("skinny ntw=4")    # one round of workgroups, <= 64 stages each
-    assert plan(32, 5120, 5120).startswith("skinny ntw=4") and plan(64, 5120, 5120).startswith("tiled")           # 320 workgroups would be two rounds
-    assert plan(32, 13824, 5120).startswith("tiled") and plan(48, 14336, 4096).startswith("tiled")                # slices of > 64 stages
+    assert plan(32, 5120, 5120).startswith("skinny ntw=4") and plan(64, 5120, 5120).startswith("xk tokens=64")    # 320 skinny workgroups would be two rounds; r03: 40 tiles x 4 slices
+    assert plan(32, 13824, 5120).startswith("tiled") and "slices=8" in plan(48, 14336, 4096)                      # slices of > 64 stages; r03 from 33 tokens: 32 tiles x 8 slices of 14 stages
     assert "tokens=32 channels=128 waves=8 grid=192x1 ksplit=1" in plan(64, 4096, 12288, kernel_id=T)              # twice the tiles, nothing to reduce
     assert "tokens=64" in plan(48, 8192, 10240) and "ksplit=3" in plan(48, 8192, 10240)
-    assert plan(64, 11008, 4096).startswith("tiled tokens=32") and plan(48, 11008, 4096).startswith("tiled")
-    assert plan(64, 28672, 8192).startswith("wide tokens=64") and "ksplit=1" not in plan(64, 28672, 8192)         # long K slices fill the chip
-    assert plan(48, 28672, 8192).startswith("wide") and plan(64, 8192, 8192).startswith("wide") and plan(64, 4096, 8192).startswith("tiled")   # from 16 stages per slice
+    assert plan(64, 11008, 4096, kernel_id=T).startswith("tiled tokens=32") and "slices=8" in plan(48, 11008, 4096)
+    assert plan(64, 28672, 8192).startswith("xk tokens=64") and "slices=4" in plan(64, 28672, 8192)               # long K slices fill the chip
+    assert "slices=4" in plan(48, 28672, 8192) and "slices=4" in plan(64, 8192, 8192) and "slices=4" in plan(64, 4096, 8192)
     assert "deferred-zero-table" in plan(3, 13824, 5120) and "dequant=exact" in plan(3, 18944, 3584)              # M = 3: the table from 256 channel blocks
     assert plan(8, 11008, 4096).startswith("skinny ntw=2") and plan(6, 11008, 4096).startswith("skinny ntw=1")    # x too large for LDS: share the L2 fragments
     # forcing a family / a split through the kernel id and grid_split_k
