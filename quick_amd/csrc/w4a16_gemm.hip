@@ -1285,7 +1285,7 @@ static int cu_count() {
 //   15 tiled: 2 x 4 wave grid              16-20 tiled: ablation / phase stamps 21 skinny: flip the persistence default
 //   22-24 skinny: persistent slots per CU  25 skinny: exact dequantisation      26 skinny: force the table deferred-zero path
 //   27 tiled: force 128 x 256 four-wave tiles 28 skinny: no fragment deferred-zero   29 / 30 tiled: force / forbid 256-channel tiles
-static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) {
+static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, bool allow_xk = true) {
   Plan p{};
   const int KT = K / 128;
   const int family = kernel & 15, mt_req = (kernel >> 4) & 15, waves_req = ((kernel >> 8) & 15) * 4;
@@ -1414,7 +1414,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
     //   us = c + stages (b0 + b1 f) + [s > 1] (s0 + s1 s) + d f,   f = workgroups / 256
     // 64-token tiles: the r02 ring tile with the weights in an AGPR queue and five x slots, 3-6 % ahead of it wherever both run
     // (512 x 4096 x 4096 22.6 against 23.8 us); 128-token tiles with 2 / 4 slices: 384 x 11008 x 4096 1.16x, 640 x 4096 x 4096 1.12x.
-    if (best > 0) {
+    if (best > 0 && allow_xk) {
       static const double xc[2][6] = {{1.728, 0.3869, 0.1572, 2.320, 0.1693, 2.064}, {3.422, 0.4881, 0.3847, 1.214, 0.4284, 2.382}};
       const int cus = cu_count();
       for (int c = 0; c < 2; ++c) {
@@ -1445,7 +1445,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k) 
   // tokens 12.8 / 13.0 -> 10.6 / 10.8 us, 64 x 5120 x 5120 13.5 -> 11.6; with eight slices, 40..64 x 11008 / 14336 x 4096 (the down
   // projections at batch 40..64): 16.6-19.8 -> 14.6-16.4 us in two sessions of three, 3 % behind in the third
   // [scripts/gpu_xk_sweep.sh, gpu_xk_audit.sh]
-  if (family == QUICK_KERNEL_AUTO && p.kernel == QUICK_KERNEL_TILED && G % 128 == 0 && M > 32 && M <= 64 && !mt_req && !waves_req) {
+  if (allow_xk && family == QUICK_KERNEL_AUTO && p.kernel == QUICK_KERNEL_TILED && G % 128 == 0 && M > 32 && M <= 64 && !mt_req && !waves_req) {
     const long T = N / 128;
     int sx = 1;
     while (sx < 8 && T * sx * 2 <= 256 && KT / (sx * 2) >= 4) sx *= 2;
@@ -1718,6 +1718,16 @@ static size_t workspace_need(const Plan& p) {
   if (p.ksplit <= 1) return 0;
   if (p.kernel == QUICK_KERNEL_XK) return slabs_offset(p);
   return slabs_offset(p) + (size_t)p.ntiles * p.ksplit * p.slab_floats * sizeof(float);
+}
+
+// SiLU * mul in an exchange-K launch needs every wave to finish whole 32-token blocks (w4a16_xk.hpp, the way out)
+static bool xk_takes_silu(const Plan& p) { return (p.wide_mb / 2 * 16) % (16 * p.ksplit) == 0; }
+// The planner does not see the epilogue; where it picks an exchange-K launch that cannot carry SiLU * mul, the launch falls back to
+// the plan without those kernels.  The workspace must serve either.
+static Plan plan_for(int M, int K, int N, int G, int kernel, int grid_split_k, bool silu) {
+  Plan p = make_plan(M, K, N, G, kernel, grid_split_k);
+  if (silu && (kernel & 15) == QUICK_KERNEL_AUTO && p.kernel == QUICK_KERNEL_XK && !xk_takes_silu(p)) p = make_plan(M, K, N, G, kernel, grid_split_k, false);
+  return p;
 }
 
 static int group_mode(int G) { return G == 128 ? 0 : (G % 128 == 0 ? 1 : (G == 64 ? 2 : (G == 32 ? 3 : 4))); }
@@ -1995,7 +2005,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: bits 16-20 select timing experiments that only a QUICK_AMD_TOOLS build contains", kernel);
 #endif
   if (!x || !qweight || !scales || !qzeros || !y) return fail(QUICK_ERR_INVALID_ARGUMENT, "null tensor pointer");
-  const Plan p = make_plan(M, K, N, G, kernel, grid_split_k);
+  const Plan p = plan_for(M, K, N, G, kernel, grid_split_k, f.silu_mul != 0);
   if (f.silu_mul && (f.bias || f.residual)) return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual");
   if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
   if (f.ln_w && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8))))
@@ -2017,19 +2027,24 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   }
   if (p.kernel == QUICK_KERNEL_XK) {
     if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
-    if (a.span || (f.silu_mul && (p.wide_mb / 2 * 16) % (16 * p.ksplit) != 0))
-      return fail(QUICK_ERR_UNSUPPORTED, "exchange-K kernels: no span stamps; SiLU * mul only where a wave finishes whole 32-token blocks");
+    if (f.silu_mul && !xk_takes_silu(p))
+      return fail(QUICK_ERR_UNSUPPORTED, "exchange-K kernels: SiLU * mul only where a wave finishes whole 32-token blocks");
     // (tools builds: kernel bits 16-20 = 16 phase stamps only; 17 loads only; 18 no loads; 19 no loads, no B-fragment reads; 20 no cross-CU
     // exchange; 21 no loads, no dequantisation; 22 MFMAs + barrier; 23 no loads, no barrier; 24 MFMAs only -- all with the stamps)
     static const int xk_abl[9] = {64, 65, 66, 82, 68, 74, 90, 98, 122};
-    int abl = p.ablate == 0 ? 0 : ((p.ablate >= 16 && p.ablate <= 24) ? xk_abl[p.ablate - 16] : -1);
+    int abl = p.ablate == 0 ? (a.span ? 32 : 0) : ((p.ablate >= 16 && p.ablate <= 24) ? xk_abl[p.ablate - 16] : -1);  // (32: in-kernel span stamps, a measurement aid)
 #ifdef QUICK_AMD_TOOLS
     if (p.ablate)  // (experiments whose bits do not fit the kernel id: the ABL value itself, tools/xk_phases.py --env-abl)
-      if (const char* e = getenv("QUICK_XK_ABL")) abl = atoi(e);
+      if (const char* e = getenv("QUICK_XK_ABL")) abl = atoi(e) == 0 && a.span ? 32 : atoi(e);
 #endif
-    if (!xk_launch(XkConfig{p.wide_mb, p.ksplit, p.xk_nbuf, p.xk_wd, abl}, a, p.ntiles * p.ksplit, L.st, L.start, L.stop))
+    if (!xk_launch(XkConfig{p.wide_mb, p.ksplit, p.xk_nbuf, p.xk_wd, abl}, a, p.ntiles * p.ksplit, L.st, L.start, L.stop)) {
+      if (abl == 32) {
+        g_span_unsupported = true;
+        return fail(QUICK_ERR_UNSUPPORTED, "no span-stamped build of the kernel this shape runs");
+      }
       return fail(QUICK_ERR_UNSUPPORTED, "no exchange-K build for tokens=%d slices=%d ring=%d queue=%d%s", p.wide_mb * 32, p.ksplit, p.xk_nbuf,
                   p.xk_wd, abl ? " (timing-experiment bits need a QUICK_AMD_TOOLS build)" : "");
+    }
   } else if (p.kernel == QUICK_KERNEL_WIDE) {
     if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
     const int sel = p.wide_mb * 10 + p.wide_pairs;
@@ -2074,7 +2089,10 @@ const char* quick_amd_last_error(void) { return g_err; }
 size_t quick_w4a16_workspace_bytes_ex(int M, int K, int N, int group_size, int kernel, int grid_split_k) {
   if (check_shapes(M, K, N, group_size) != QUICK_OK) return 0;
   const Plan p = make_plan(M, K, N, group_size, kernel, grid_split_k);
-  return workspace_need(p);
+  size_t need = workspace_need(p);
+  if ((kernel & 15) == QUICK_KERNEL_AUTO && p.kernel == QUICK_KERNEL_XK && !xk_takes_silu(p))   // (the fallback of a SiLU * mul launch)
+    need = std::max(need, workspace_need(make_plan(M, K, N, group_size, kernel, grid_split_k, false)));
+  return need;
 }
 
 size_t quick_w4a16_workspace_bytes(int M, int K, int N, int group_size, int split_k_iters) {

@@ -80,6 +80,8 @@ bool xk_launch(const XkConfig& c, const GemmArgs& a, int workgroups, hipStream_t
       case 336: return xk_go<4, 5, 4, 2, 336>(a, workgroups, st, start, stop);    // weight loads only, no B-fragment reads
       default: return false;
     }
+    if (key == 254 && c.s == 1 && c.abl == 32768) return xk_go<2, 5, 4, 1, 32768>(a, workgroups, st, start, stop);  // write-through y stores
+    if (key == 254 && c.s == 1 && c.abl == 64) return xk_go<2, 5, 4, 1, 64>(a, workgroups, st, start, stop);
     if (key == 454 && c.s == 4 && c.abl == 64) return xk_go<4, 5, 4, 4, 64>(a, workgroups, st, start, stop);
     if (key == 254 && c.s == 8 && c.abl == 64) return xk_go<2, 5, 4, 8, 64>(a, workgroups, st, start, stop);
     return false;
@@ -91,8 +93,16 @@ bool xk_launch(const XkConfig& c, const GemmArgs& a, int workgroups, hipStream_t
   if (key == 456) return xk_go_s<4, 5, 6>(c.s, a, workgroups, st, start, stop);
   if (key == 244) return xk_go_s<2, 4, 4>(c.s, a, workgroups, st, start, stop);
 #else
-  if (c.abl) return false;
+  if (c.abl && c.abl != 32) return false;
 #endif
+  if (c.abl == 32) {  // in-kernel span stamps (quick_w4a16_gemm_span, bench.py): the shapes of the BASELINE sweep and their neighbours
+    if (key == 254 && c.s == 1) return xk_go<2, 5, 4, 1, 32>(a, workgroups, st, start, stop);
+    if (key == 254 && c.s == 2) return xk_go<2, 5, 4, 2, 32>(a, workgroups, st, start, stop);
+    if (key == 254 && c.s == 4) return xk_go<2, 5, 4, 4, 32>(a, workgroups, st, start, stop);
+    if (key == 454 && c.s == 1) return xk_go<4, 5, 4, 1, 32>(a, workgroups, st, start, stop);
+    if (key == 454 && c.s == 2) return xk_go<4, 5, 4, 2, 32>(a, workgroups, st, start, stop);
+    return false;
+  }
   if (key == 454) return xk_go_s<4, 5, 4>(c.s, a, workgroups, st, start, stop);
   if (key == 254) return xk_go_s<2, 5, 4>(c.s, a, workgroups, st, start, stop);
   return false;

@@ -252,6 +252,7 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
   static_assert(MB * 16384 <= NBUF * SLOT, "the K-parity exchange must fit in the ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF * SLOT
 
+  if constexpr (ABL & 32) span_stamp(a.span, 0);  // (32: per-wave start / end stamps of the in-kernel span clock, nothing else changes)
   unsigned long long ph[6], cyc = 0;  // (cyc: shader clocks spent in the K loop, s_memtime)
   if constexpr (ABL & 64) ph[0] = __builtin_amdgcn_s_memrealtime();
   const int lane = threadIdx.x & 63;
@@ -643,7 +644,14 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = (half_t)((float)v[r] + (float)res[r]);
           }
-          *(half8_t*)(ycol + (size_t)m * ldy) = v;
+          // Write-through (sc1): the end of the launch then finds nothing of y dirty in the XCD's L2 -- the boundary to the next
+          // kernel writes a plain-stored 4 MB result back at ~6 TB/s, 0.4-0.5 us of every 512-token step [r03 A/B, one session:
+          // 24.4-24.6 against 24.9-25.0 us per step of a 20-launch graph]; ABL bit 32768 (tools builds) keeps the plain stores.
+          if constexpr (!(ABL & 32768)) {
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ycol + (size_t)m * ldy), "v"(v) : "memory");
+          } else {
+            *(half8_t*)(ycol + (size_t)m * ldy) = v;
+          }
         }
       }
     };
@@ -670,11 +678,17 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
           for (int r = 0; r < GR; ++r) o[r] = (half_t)((float)o[r] + (float)a.residual[(size_t)m * a.N + n + r]);
         }
         half_t* yp = a.Y + (size_t)m * a.N + n;
-        if constexpr (GR == 4) *(half4_t*)yp = half4_t{o[0], o[1], o[2], o[3]};
-        else *(half2_t*)yp = half2_t{o[0], o[1]};
+        if constexpr (GR == 4) {
+          const half4_t ov = {o[0], o[1], o[2], o[3]};
+          asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(yp), "v"(ov) : "memory");
+        } else {
+          const half2_t ov = {o[0], o[1]};
+          asm volatile("global_store_dword %0, %1, off sc1" ::"v"(yp), "v"(ov) : "memory");
+        }
       }
     }
   }
+  if constexpr (ABL & 32) span_stamp(a.span, 1);
   if constexpr (ABL & 64) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ph[5] = __builtin_amdgcn_s_memrealtime();
