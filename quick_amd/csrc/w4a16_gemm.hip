@@ -1460,6 +1460,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   // x travels through a buffer descriptor with 32-bit offsets in the wide / exchange-K kernels: from 4 GiB of activations on, r01's
   // tiled kernel (64-bit pointers) runs instead
   if ((p.kernel == QUICK_KERNEL_WIDE || p.kernel == QUICK_KERNEL_XK) && (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32)) p.kernel = QUICK_KERNEL_TILED;
+  if (p.kernel == QUICK_KERNEL_XK && (size_t)M * (size_t)N * 2 >= ((size_t)1 << 32)) p.kernel = QUICK_KERNEL_TILED;  // (y through a buffer descriptor as well)
   if (p.kernel == QUICK_KERNEL_XK) {
     // exchange-K kernels (w4a16_xk.hpp): tile = mb * 32 tokens x 128 channels, eight waves; the S slices of a tile run on S compute
     // units at the same time and swap parts of their partial tiles, so S > 1 needs the whole grid co-resident: tiles * S <= CUs.

@@ -630,6 +630,8 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
       const int ldy = SILU ? a.N >> 1 : a.N;
       const int q = (int)threadIdx.x % CPR;
       half_t* ycol = a.Y + (SILU ? t.nb * 64 : t.nb * 128) + q * 8;
+      const unsigned ycol0 = (unsigned)((SILU ? t.nb * 64 : t.nb * 128) + q * 8);
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.Y, 0, (unsigned)((size_t)a.M * ldy * 2), 0x00020000);
       const half_t* rcol = (!SILU && a.residual) ? a.residual + t.nb * 128 + q * 8 : nullptr;
       constexpr int RPI = 512 / CPR;          // rows per pass of the workgroup
 #pragma unroll
@@ -647,8 +649,8 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
           // Write-through (sc1): the end of the launch then finds nothing of y dirty in the XCD's L2 -- the boundary to the next
           // kernel writes a plain-stored 4 MB result back at ~6 TB/s, 0.4-0.5 us of every 512-token step [r03 A/B, one session:
           // 24.4-24.6 against 24.9-25.0 us per step of a 20-launch graph]; ABL bit 32768 (tools builds) keeps the plain stores.
-          if constexpr (!(ABL & 32768)) {
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ycol + (size_t)m * ldy), "v"(v) : "memory");
+          if constexpr (!(ABL & 32768)) {  // (a buffer store the compiler knows: an asm store leaves its data registers unprotected)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, (unsigned)(((size_t)m * ldy + ycol0) * 2), 0, /*sc1*/ 16);
           } else {
             *(half8_t*)(ycol + (size_t)m * ldy) = v;
           }
@@ -678,12 +680,15 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
           for (int r = 0; r < GR; ++r) o[r] = (half_t)((float)o[r] + (float)a.residual[(size_t)m * a.N + n + r]);
         }
         half_t* yp = a.Y + (size_t)m * a.N + n;
-        if constexpr (GR == 4) {
+        (void)yp;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.Y, 0, (unsigned)((size_t)a.M * a.N * 2), 0x00020000);
+        const unsigned yoff = (unsigned)(((size_t)m * a.N + n) * 2);
+        if constexpr (GR == 4) {  // write-through, as the image path
           const half4_t ov = {o[0], o[1], o[2], o[3]};
-          asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(yp), "v"(ov) : "memory");
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), ry, yoff, 0, /*sc1*/ 16);
         } else {
           const half2_t ov = {o[0], o[1]};
-          asm volatile("global_store_dword %0, %1, off sc1" ::"v"(yp), "v"(ov) : "memory");
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, ov), ry, yoff, 0, /*sc1*/ 16);
         }
       }
     }
