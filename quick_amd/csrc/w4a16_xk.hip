@@ -80,6 +80,10 @@ bool xk_launch(const XkConfig& c, const GemmArgs& a, int workgroups, hipStream_t
       case 336: return xk_go<4, 5, 4, 2, 336>(a, workgroups, st, start, stop);    // weight loads only, no B-fragment reads
       default: return false;
     }
+    if (key == 254 && c.s == 1 && c.abl == 65536) return xk_go<2, 5, 4, 1, 65536>(a, workgroups, st, start, stop);  // staggered issue
+    if (key == 254 && c.s == 1 && c.abl == 65600) return xk_go<2, 5, 4, 1, 65600>(a, workgroups, st, start, stop);
+    if (key == 454 && c.s == 2 && c.abl == 65536) return xk_go<4, 5, 4, 2, 65536>(a, workgroups, st, start, stop);
+    if (key == 454 && c.s == 2 && c.abl == 65600) return xk_go<4, 5, 4, 2, 65600>(a, workgroups, st, start, stop);
     if (key == 254 && c.s == 1 && c.abl == 32768) return xk_go<2, 5, 4, 1, 32768>(a, workgroups, st, start, stop);  // write-through y stores
     if (key == 254 && c.s == 1 && c.abl == 64) return xk_go<2, 5, 4, 1, 64>(a, workgroups, st, start, stop);
     if (key == 454 && c.s == 4 && c.abl == 64) return xk_go<4, 5, 4, 4, 64>(a, workgroups, st, start, stop);

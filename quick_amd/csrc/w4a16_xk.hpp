@@ -400,6 +400,18 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
             return;
           }
         }
+        if constexpr (ABL & 65536) {
+          // (experiment: STAGGERED issue.  The barrier aligns the eight waves, so with fixed issue points all of them hand their
+          // vector-memory instructions to the CU's one address path in the same few hundred clocks and wait for it together -- both
+          // waves of every SIMD at once, nobody left to issue MFMAs.  Here wave (wn, wk) issues its whole share of the stage with
+          // unit (wn + 2 wk) % 4: two waves per unit, never the two of one SIMD.)
+          if (u == ((wn + 2 * wk) & 3)) {
+            issue_w(xk_ic<J>{}, ktw);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) issue_x(i, ktx, fill);
+          }
+          return;
+        }
         if constexpr (!(ABL & 512))
           if (u == 0) issue_w(xk_ic<J>{}, ktw);  // set J held W(s), which has been in VGPRs since stage s - 1
         if constexpr (!(ABL & 256)) {
