@@ -535,43 +535,65 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
         __syncthreads();
       }
     }
-    for (int r = 0; r < rows; ++r) {
-      const half_t* src = a.X + (size_t)(mb * 16 + r) * a.K + wg_begin * 128;
-      float inv = 0.f;
+    // Rows in batches of RB: the loads of a batch are all issued before the first of them is used.  One row at a time this loop was a
+    // chain of `rows` round trips to L2 (load -> LDS store -> unit sums -> table), 1.2-1.5 us of an 8-token launch [r02 stamps]; the
+    // deferred-zero table flavour lost to the exact path at 3..16 tokens for that reason alone.
+    constexpr int RB = 4;
+    for (int r0 = 0; r0 < rows; r0 += RB) {
+      float inv[RB];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) inv[j] = 0.f;
       if constexpr (DZ) {
         if (a.ln_w) {
-          float ss = 0.f;
 #pragma unroll
-          for (int w = 0; w < WAVES; ++w) ss += ((const float*)smem)[r * WAVES + w];
-          inv = rsqrtf(ss / (float)a.K + a.ln_eps);
+          for (int j = 0; j < RB; ++j) {
+            const int r = min(r0 + j, rows - 1);
+            float ss = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) ss += ((const float*)smem)[r * WAVES + w];
+            inv[j] = rsqrtf(ss / (float)a.K + a.ln_eps);
+          }
         }
       }
       for (int c = threadIdx.x; c < kc; c += WAVES * 64) {  // kc % 16 == 0: rows of 16 lanes are all in or all out
-        u32x4 v;
+        u32x4 v[RB];
+        bool normed = false;
         if constexpr (DZ) {
           if (a.ln_w) {  // fp16(fp16(x * inv) * weight): the rounding points of quick_rmsnorm_f16 (and of torch)
-            const half8_t xv = *(const half8_t*)(xlds + r * pitch + c * 16), gv = *(const half8_t*)(a.ln_w + c * 8);
-            half8_t o;
+            normed = true;
+            const half8_t gv = *(const half8_t*)(a.ln_w + c * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (half_t)((half_t)((float)xv[j] * inv) * gv[j]);
-            v = __builtin_bit_cast(u32x4, o);
-          } else {
-            v = *(const u32x4*)(src + c * 8);
+            for (int j = 0; j < RB; ++j) {
+              const half8_t xv = *(const half8_t*)(xlds + min(r0 + j, rows - 1) * pitch + c * 16);
+              half8_t o;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) o[i] = (half_t)((half_t)((float)xv[i] * inv[j]) * gv[i]);
+              v[j] = __builtin_bit_cast(u32x4, o);
+            }
           }
-        } else {
-          v = *(const u32x4*)(src + c * 8);
         }
-        *(u32x4*)(xlds + r * pitch + c * 16) = v;
-        if constexpr (DZ) {
-          const half2_t one2 = {(half_t)1.f, (half_t)1.f};
-          const float lo = __builtin_amdgcn_fdot2(as_h2(v[0]), one2, __builtin_amdgcn_fdot2(as_h2(v[2]), one2, 0.f, false), false);
-          const float hi = __builtin_amdgcn_fdot2(as_h2(v[1]), one2, __builtin_amdgcn_fdot2(as_h2(v[3]), one2, 0.f, false), false);
-          const float sa = lanes_sum<L>(lo + hi);
-          const float sc = lanes_sum<L>(1024.f * lo + 64.f * hi);
-          if ((lane & (L - 1)) == 0) {
-            float* t = tab0 + (c / L) * 32 + r;
-            t[0] = sa;
-            t[16] = -sc;
+        if (!normed) {
+#pragma unroll
+          for (int j = 0; j < RB; ++j)  // (past the last row: a replay of it, not stored)
+            v[j] = *(const u32x4*)(a.X + (size_t)(mb * 16 + min(r0 + j, rows - 1)) * a.K + wg_begin * 128 + c * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const int r = r0 + j;
+          if (r < rows) {  // workgroup-uniform
+            *(u32x4*)(xlds + r * pitch + c * 16) = v[j];
+            if constexpr (DZ) {
+              const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+              const float lo = __builtin_amdgcn_fdot2(as_h2(v[j][0]), one2, __builtin_amdgcn_fdot2(as_h2(v[j][2]), one2, 0.f, false), false);
+              const float hi = __builtin_amdgcn_fdot2(as_h2(v[j][1]), one2, __builtin_amdgcn_fdot2(as_h2(v[j][3]), one2, 0.f, false), false);
+              const float sa = lanes_sum<L>(lo + hi);
+              const float sc = lanes_sum<L>(1024.f * lo + 64.f * hi);
+              if ((lane & (L - 1)) == 0) {
+                float* t = tab0 + (c / L) * 32 + r;
+                t[0] = sa;
+                t[16] = -sc;
+              }
+            }
           }
         }
       }
@@ -1673,7 +1695,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       const bool balanced = (double)nblocks >= 0.8 * rounds * 256 * c;
       // (M = 3 from 256 blocks as well [third audit: never behind the exact path there, 13824 x 5120 16.3 -> 11.5 us, 4096 x 6144 6.7 -> 6.2,
       // 5120 x 5120 8.0 -> 7.4, 11008 x 4096 8.2 -> 7.9; with 224 blocks, 18944 x 3584, the exact path is ahead 12.8 against 13.9])
-      if (M <= 2 || (M == 3 && nblocks >= 256 && p.ksplit == 1) || ((kernel >> 26) & 1) || (rounds >= 2 && balanced && p.ksplit == 1)) {  // bit 26: tests force the path
+      // (r03: M = 4 as well -- with the rows of the x copy / table prologue batched four at a time the table flavour is ahead there too,
+      // 4 x 4096 x 4096 4.88 -> 4.60 us, 4 x 11008 x 4096 9.04 -> 8.28 [scripts/gpu_dz.sh]; from 6 tokens the exact path keeps its lead)
+      if (M <= 2 || (M <= 4 && nblocks >= 256 && p.ksplit == 1) || ((kernel >> 26) & 1) || (rounds >= 2 && balanced && p.ksplit == 1)) {  // bit 26: tests force the path
         p.dz = p.xlds = true;
         if (!flip && p.ksplit == 1 && rounds >= 2) p.grid_x = std::min(nblocks, ((nblocks + rounds - 1) / rounds + 7) & ~7);
         // One workgroup per CU and a long K: 16 waves instead of 8 -- twice the bytes in flight per CU and half the chain of
