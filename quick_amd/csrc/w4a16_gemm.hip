@@ -1252,6 +1252,7 @@ struct Plan {
   int tch;     // tiled: channels per workgroup tile, 128 or 256
   bool mfma32; // tiled: v_mfma_f32_32x32x16_f16 flavour (kernel bit 13; measured slower than 16x16x32 in r01)
   int xk_nbuf, xk_wd;  // exchange-K: x ring slots, weight queue depth (wide_mb = token tiles of 32, ksplit = slices that exchange)
+  bool xk_loader;      // exchange-K: the twelve-wave flavour (four loader waves; kernel bit 12)
 };
 
 // Where the main kernel goes: the stream, plus an optional event pair bound to that one dispatch
@@ -1396,10 +1397,15 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       // (64 x 128 tiles in more than one round: the double-buffered kernel, 2-4 workgroups per CU, instead of the ring's one --
       // 256 x 4096 x 12288 33.8 against 42.3 us; its own fit over the 219 such rows of the audits, 2.1 % rms)
       const bool rounds64 = mb == 2 && pairs == 1 && T * s > 256;
-      const double cost = rounds64 ? 5.25 - 0.05 * n + stages * (0.2382 * n + 0.3242 * f)
+      double cost = rounds64 ? 5.25 - 0.05 * n + stages * (0.2382 * n + 0.3242 * f)
                                    : cand[c].c + cand[c].a * n + stages * (cand[c].b_ceil * n + cand[c].b_frac * f) +
                                          (s > 1 ? cand[c].split0 + cand[c].split1 * s * (mb * 32.0 * pairs * 128 * 4 / 1e6) : 0.0) -
                                          (s == 2 && mb * pairs <= 8 ? 1.2 : 0.0);   // (two slices: the own partial stays in registers, measured after the fit)
+      // [r03 audit, profiles/r03_xk_audit.jsonl] tiles of <= 128 x 128 in SEVERAL rounds run 10-20 % behind this fit on the r03 boxes
+      // (measured / predicted, medians: 64 x 128 1.13-1.21, 64 x 256 1.14-1.21, 128 x 128 1.22 against 1.12 in one round; 128 x 256
+      // 1.04-1.10 and 256 x 256 1.01-1.05 as fitted): 640 x 5120 x 13824 121 us on 540 tiles against 101 on 162 of 256 x 256
+      static const double several_rounds[5] = {1.2, 1.2, 1.2, 1.0, 1.0};  // (replayed on the audit's rows, tools/audit_replay.py: mean gap 0.95 -> 0.37 %, worst 19 -> 7 %)
+      if (n >= 2.0) cost *= several_rounds[c];
       if (wide_mb == 0 || cost < best) {
         best = cost;
         wide_mb = mb;
@@ -1509,6 +1515,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     const int nb_req = (kernel >> 22) & 7, wd_req = (kernel >> 26) & 7;
     p.xk_nbuf = nb_req >= 3 ? nb_req : 5;
     p.xk_wd = wd_req >= 3 ? wd_req : 4;
+    p.xk_loader = ((kernel >> 12) & 1) != 0;
     const int groups = 8 / s;  // XCDs per K slice: they form a gm x gn grid over the (token, channel) tiles
     long best = -1;
     if (!((kernel >> 14) & 1) && ((long)p.ntiles * s) % 8 == 0)
@@ -2028,6 +2035,8 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
 #ifndef QUICK_AMD_TOOLS
   if ((kernel >> 16) & 31)  // the timing-experiment builds (wrong results on purpose, phase stamps) are not in the product library
     return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: bits 16-20 select timing experiments that only a QUICK_AMD_TOOLS build contains", kernel);
+  if ((kernel & 15) == QUICK_KERNEL_XK && ((kernel >> 12) & 1))  // the twelve-wave (loader waves) flavour: measured level with the eight-wave one, DESIGN.md 5.9
+    return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: the loader-wave flavour of the exchange-K kernels is only in a QUICK_AMD_TOOLS build", kernel);
 #endif
   if (!x || !qweight || !scales || !qzeros || !y) return fail(QUICK_ERR_INVALID_ARGUMENT, "null tensor pointer");
   const Plan p = plan_for(M, K, N, G, kernel, grid_split_k, f.silu_mul != 0);
@@ -2062,7 +2071,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     if (p.ablate)  // (experiments whose bits do not fit the kernel id: the ABL value itself, tools/xk_phases.py --env-abl)
       if (const char* e = getenv("QUICK_XK_ABL")) abl = atoi(e) == 0 && a.span ? 32 : atoi(e);
 #endif
-    if (!xk_launch(XkConfig{p.wide_mb, p.ksplit, p.xk_nbuf, p.xk_wd, abl}, a, p.ntiles * p.ksplit, L.st, L.start, L.stop)) {
+    if (!xk_launch(XkConfig{p.wide_mb, p.ksplit, p.xk_nbuf, p.xk_wd, abl, p.xk_loader ? 1 : 0}, a, p.ntiles * p.ksplit, L.st, L.start, L.stop)) {
       if (abl == 32) {
         g_span_unsupported = true;
         return fail(QUICK_ERR_UNSUPPORTED, "no span-stamped build of the kernel this shape runs");
@@ -2167,8 +2176,8 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
              p.xlds ? "lds" : "l2", p.dz ? (p.xlds ? "deferred-zero-table" : "deferred-zero-fragment") : "exact", p.grid_x,
              (M + 15) / 16, p.ksplit, p.ksplit, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_XK)
-    snprintf(text, text_bytes, "xk tokens=%d channels=128 waves=8 ring=%d queue=%d grid=%d slices=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
-             p.xk_nbuf, p.xk_wd, p.ntiles * p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
+    snprintf(text, text_bytes, "xk tokens=%d channels=128 waves=%d ring=%d queue=%d grid=%d slices=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
+             p.xk_loader ? 12 : 8, p.xk_loader ? 3 : p.xk_nbuf, p.xk_loader ? 5 : p.xk_wd, p.ntiles * p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_WIDE)
     snprintf(text, text_bytes, "wide tokens=%d channels=%d waves=%d ring=%d grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
              p.tch, p.waves, p.wide_nbuf, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));

@@ -41,6 +41,43 @@ static bool xk_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t 
   return true;
 }
 
+template <int MB, int S, int ABL = 0>
+static bool xl_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+  constexpr unsigned lds = (MB == 2 ? 4 : 3) * MB * 8192 + 5 * (8192 + 512);
+  const dim3 grid(workgroups), block(768);
+  const int gm = a.G == 128 ? 0 : (a.G % 128 == 0 ? 1 : -1);
+  if (gm < 0 || (ABL != 0 && gm != 0)) return false;
+#define QA_XL_K(GMV)                                                                                               \
+  do {                                                                                                             \
+    auto kfn = w4a16_xl_kernel<MB, GMV, S, ABL>;                                                                   \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipExtLaunchKernelGGL(kfn, grid, block, lds, st, start, stop, 0, a);                                           \
+  } while (0)
+  if constexpr (ABL != 0) {
+    QA_XL_K(0);
+  } else {
+    if (gm == 0) QA_XL_K(0);
+    else QA_XL_K(1);
+  }
+#undef QA_XL_K
+  return true;
+}
+
+template <int MB, int ABL = 0>
+static bool xl_go_s(int s, const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+  switch (s) {
+    case 1: return xl_go<MB, 1, ABL>(a, workgroups, st, start, stop);
+    case 2: return xl_go<MB, 2, ABL>(a, workgroups, st, start, stop);
+    case 4: return xl_go<MB, 4, ABL>(a, workgroups, st, start, stop);
+    case 8: return xl_go<MB, 8, ABL>(a, workgroups, st, start, stop);
+    default: return false;
+  }
+}
+
 template <int MB, int NBUF, int WD, int ABL = 0>
 static bool xk_go_s(int s, const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
   switch (s) {
@@ -53,6 +90,24 @@ static bool xk_go_s(int s, const GemmArgs& a, int workgroups, hipStream_t st, hi
 }
 
 bool xk_launch(const XkConfig& c, const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+  if (c.loader) {  // twelve waves: four loaders + eight compute waves (an experiment the product library does not carry)
+#ifdef QUICK_AMD_TOOLS
+    if (c.abl == 0) return c.mb == 4 ? xl_go_s<4>(c.s, a, workgroups, st, start, stop) : (c.mb == 2 ? xl_go_s<2>(c.s, a, workgroups, st, start, stop) : false);
+    if (c.abl == 32) {
+      if (c.mb == 2 && c.s == 1) return xl_go<2, 1, 32>(a, workgroups, st, start, stop);
+      if (c.mb == 4 && c.s == 2) return xl_go<4, 2, 32>(a, workgroups, st, start, stop);
+      if (c.mb == 4 && c.s == 1) return xl_go<4, 1, 32>(a, workgroups, st, start, stop);
+      return false;
+    }
+    if (c.abl == 64) {
+      if (c.mb == 2 && c.s == 1) return xl_go<2, 1, 64>(a, workgroups, st, start, stop);
+      if (c.mb == 4 && c.s == 2) return xl_go<4, 2, 64>(a, workgroups, st, start, stop);
+      if (c.mb == 4 && c.s == 4) return xl_go<4, 4, 64>(a, workgroups, st, start, stop);
+      if (c.mb == 2 && c.s == 8) return xl_go<2, 8, 64>(a, workgroups, st, start, stop);
+    }
+#endif
+    return false;
+  }
   const int key = c.mb * 100 + c.nbuf * 10 + c.wd;
 #ifdef QUICK_AMD_TOOLS
   if (c.abl) {  // timing experiments (tools builds): phase stamps, and the launch without the cross-CU exchange (wrong results)
@@ -71,6 +126,7 @@ bool xk_launch(const XkConfig& c, const GemmArgs& a, int workgroups, hipStream_t
       case 576: return xk_go<4, 5, 4, 2, 576>(a, workgroups, st, start, stop);  // no weight loads in the K loop
       case 1088: return xk_go<4, 5, 4, 2, 1088>(a, workgroups, st, start, stop);  // one x piece with every unit
       case 4160: return xk_go<4, 5, 4, 2, 4160>(a, workgroups, st, start, stop);  // four loader waves issue the x pieces
+      case 4672: return xk_go<4, 5, 4, 2, 4672>(a, workgroups, st, start, stop);  // ... and the compute waves issue no weight loads either
       case 8256: return xk_go<4, 5, 4, 2, 8256>(a, workgroups, st, start, stop);  // + clocks spent in the counted wait / at the barrier
       case 8258: return xk_go<4, 5, 4, 2, 8258>(a, workgroups, st, start, stop);  // ... without loads
       case 16720: return xk_go<4, 5, 4, 2, 16720>(a, workgroups, st, start, stop);  // weight loads only, always the same (cached) stage, no B-fragment reads

@@ -233,231 +233,11 @@ __device__ __forceinline__ XkTile xk_tile(const GemmArgs& a) {
 constexpr unsigned kXkZoneBytes = 16u << 20;   // exchange zone of the workspace (all-zero between launches), see workspace_need()
 constexpr unsigned kXkPollLimit = 1u << 22;    // polls of ~1 us before a wave gives up and traps (a slice that never came)
 
-// ABL (tools builds only): 64 = s_memrealtime stamps at the phase boundaries of every wave into a.dbg; 4 = no cross-CU exchange (the
-// own part is finished without the other slices: wrong results, the launch minus the exchange); 1 / 2 / 8 / 16 as in wide_compute (no
-// compute / no loads in the K loop / no dequantisation / no B-fragment reads); 32 = no barrier in the K loop; 128 = no counted wait at the
-// end of a stage; 256 / 512 = no x pieces / no weight loads in the K loop; 1024 = one x piece with every unit instead of two with two.
-template <int MB, int GM, int NBUF, int WD, int S, int ABL = 0>
-__global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(const GemmArgs a) {
-  constexpr int NW = 8, NG = 1;
-  constexpr bool LD = (ABL & 4096) != 0;  // experiment: four extra LOADER waves issue every x piece, the eight compute waves only their weights
-  constexpr int SLOT = MB * 8192;
-  constexpr int XI = MB;       // x LDS-DMA instructions per wave and stage (MB * 32 rows / (8 waves * 4 rows))
-  constexpr int L = XI + 2;    // vector-memory instructions per wave and stage (+ weights, + (scale, zero) word)
-  constexpr int NU = 4;        // units (k16 steps of this wave's parity) per stage
-  constexpr int PEND = (NBUF - 3) * L;
-  static_assert(GM <= 1 && (MB == 2 || MB == 4), "G % 128 == 0, 64- or 128-token tiles");
-  static_assert(NBUF >= 3 && NBUF * SLOT <= 160 * 1024 && WD >= NBUF - 1 && WD >= 3 && WD <= 6 && PEND <= 63, "ring / queue geometry");
-  static_assert(S == 1 || S == 2 || S == 4 || S == 8, "K slices per tile");
-  static_assert(MB * 16384 <= NBUF * SLOT, "the K-parity exchange must fit in the ring");
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF * SLOT
-
-  if constexpr (ABL & 32) span_stamp(a.span, 0);  // (32: per-wave start / end stamps of the in-kernel span clock, nothing else changes)
-  unsigned long long ph[6], cyc = 0;  // (cyc: shader clocks spent in the K loop, s_memtime)
-  if constexpr (ABL & 64) ph[0] = __builtin_amdgcn_s_memrealtime();
-  const int lane = threadIdx.x & 63;
-  const int wave = uniform(threadIdx.x >> 6);
-  const int wn = wave & 3, wk = wave >> 2;
-  const int rho = lane & 31, h = lane >> 5;
-  const XkTile t = xk_tile<MB, S>(a);
-  const int ct0 = (t.nb * 4 + wn) * 2;
-  const WideBufs<XI> b = wide_bufs<MB, 1, 2>(a, t.m0, ct0, lane, wave);
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned xdst = lds_base + (unsigned)wave * 1024u;  // + slot + i * 8 KiB
-  const unsigned xrd = (lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4)) ^ ((unsigned)wk << 5);
-
-  if constexpr (LD) {
-    static_assert(!LD || (NBUF == 5 && MB == 4), "loader experiment: 128-token tiles, five slots");
-    if (wave >= 8) {  // loader wave lw: piece i = rows 16 i + 4 lw + lane / 16 of the token tile, i = 0 .. 7
-      const unsigned lw = (unsigned)wave - 8u;
-      const unsigned row = 4u * lw + ((unsigned)lane >> 4);
-      unsigned voff[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        voff[i] = (unsigned)min(t.m0 + 16 * i + (int)row, a.M - 1) * (unsigned)a.K * 2u + 16u * (((unsigned)lane & 15u) ^ (row & 15u));
-      const unsigned dst = lds_base + lw * 1024u;
-      auto fillx = [&](int q, unsigned slot) {
-        const int kt = min(t.kt_lo + q, t.kt_hi - 1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) lds_dma16(b.x, voff[i], (unsigned)kt * 256u, dst + slot + i * 4096);
-      };
-      fillx(0, 0u); fillx(1, SLOT); fillx(2, 2 * SLOT); fillx(3, 3 * SLOT);
-      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // x stage 0
-      __builtin_amdgcn_s_barrier();                      // A
-      fillx(4, 4 * SLOT);
-      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // x stage 1
-      __builtin_amdgcn_s_barrier();                      // M (stage 0, before the first read of stage 1)
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // x stage 2
-      __builtin_amdgcn_s_barrier();                      // end of stage 0
-      unsigned slot = 0u;                                // slot of stage s + 4 = slot of stage s - 1
-      for (int s2 = 1; s2 < t.nstage; ++s2) {
-        fillx(s2 + 4, slot);
-        slot = slot + SLOT >= (unsigned)(NBUF * SLOT) ? 0u : slot + SLOT;
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // x stage s + 2
-        __builtin_amdgcn_s_barrier();                      // end of stage s
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                        // the ring is free
-      return;
-    }
-  }
-  auto issue_x = [&](int i, int kt, unsigned slot) {
-    if constexpr (!LD) lds_dma16(b.x, b.x_voff[i], (unsigned)kt * 256u, xdst + slot + i * (NW * 1024));
-  };
-  auto issue_w = [&](auto jc, int kt) {
-    const unsigned g = (unsigned)group_index<GM>(kt, 0, a.tpg, a.G);
-    XkSet<decltype(jc)::value>::issue(b.w, b.w_voff, (unsigned)kt * 1024u, b.s, b.s_voff, g * 64u);
-  };
-  auto read_w = [&](auto jc, WideW<1, GM>& w) {
-    XkSet<decltype(jc)::value>::read(w.lo[0], w.sz[0][0]);
-    w.hi[0] = w.lo[0];
-  };
-
-  floatx16 acc[1][MB];
-  wide_zero<MB, 1>(acc);
-  const DqConsts dq = make_dq_consts();
-
-  // FAST start (the shipped geometry, five slots / four sets): the prologue asks only for what stage 0 needs -- weight sets 0, 1 and x
-  // stage 0 (and 1 where stage 0 reads it from its second unit on: 64-token tiles) -- and stage 0 itself issues the rest of the
-  // ring next to its MFMAs.  Every CU's vector-memory path moves 64 B per clock: a prologue that asks for all four stages (164 KB
-  // at 128 tokens) spends ~1.5 us ISSUING before the first wait [r03 phase stamps: 2.6-2.8 us to the first MFMA, with or without
-  // waiting for stage 1].  Other geometries (tuning sweeps) keep the plain prologue, in the order the steady state would have
-  // issued it: [W(0 .. WD - NBUF)], then W(WD - NBUF + 1 + q), X(q) for q = 0 .. NBUF - 2.
-  constexpr bool FAST = NBUF == 5 && WD == 4 && !(ABL & 2) && !LD;
-  constexpr int DEPTH = wide_bdepth<MB, 1>();
-  constexpr int UM = NU - DEPTH;            // the unit of a stage that first reads the NEXT stage's tokens
-  constexpr int PX = UM >= 2 ? 1 : 2;       // x stages the FAST prologue asks for
-  constexpr int PER = XI / 2;               // steady state: x pieces with units 1 and 2 (nothing with the last unit of the stage)
-  auto x_stage = [&](int q) {               // all pieces of x stage q (q < NBUF: its slot is q)
-    const int kt = min(t.kt_lo + q, t.kt_hi - 1);
-#pragma unroll
-    for (int i = 0; i < XI; ++i) issue_x(i, kt, (unsigned)q * SLOT);
-  };
-  auto pro_w = [&](auto jc) { issue_w(jc, min(t.kt_lo + decltype(jc)::value, t.kt_hi - 1)); };
-  if constexpr (FAST) {
-    pro_w(xk_ic<0>{});
-    pro_w(xk_ic<1>{});
-    x_stage(0);
-    if constexpr (PX == 2) x_stage(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PX - 1) * XI) : "memory");  // weight sets 0, 1 and x stage 0 have landed
-  } else {
-    constexpr int E = WD - NBUF + 1;  // sets issued ahead of the first x stage
-    if constexpr (E > 0) pro_w(xk_ic<0>{});
-    if constexpr (E > 1) pro_w(xk_ic<1>{});
-    if constexpr (E > 2) pro_w(xk_ic<2>{});
-    if constexpr (E > 3) pro_w(xk_ic<3>{});
-    pro_w(xk_ic<E>{});
-    x_stage(0);
-    if constexpr (NBUF > 2) { pro_w(xk_ic<E + 1>{}); x_stage(1); }
-    if constexpr (NBUF > 3) { pro_w(xk_ic<E + 2>{}); x_stage(2); }
-    if constexpr (NBUF > 4) { pro_w(xk_ic<E + 3>{}); x_stage(3); }
-    static_assert(NBUF <= 5, "prologue written out for up to five slots");
-    // start as soon as x stage 0 and weight sets 0, 1 are there; stage 0 waits for x stage 1 itself, just before its first read of it
-    constexpr int INIT = LD ? 2 * (WD - 2) : (NBUF - 2) * L - (E == 0 ? 2 : 0);  // what the prologue issued behind X(0) (and W(1))
-    static_assert(INIT <= 63, "vmcnt field");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INIT) : "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  WideW<1, GM> wc, wnx;
-  read_w(xk_ic<0>{}, wc);
-  WideCarry<MB, 1, GM> carry;
-  wide_prepare<MB, 1, GM, true, 2>(carry, wc, xrd, dq);
-  if (wk) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses every VALU arbitration otherwise (MI355X_MICROARCH.md, two waves per SIMD)
-  if constexpr (ABL & 64) { ph[1] = __builtin_amdgcn_s_memrealtime(); cyc = __builtin_amdgcn_s_memtime(); }
-
-  // vmcnt bookkeeping.  Steady state: stage s issues [W(s + WD), X(s + NBUF - 1)] = L instructions per wave; "x stage s + 2 and weight
-  // set s + 2 have landed" at the end of stage s is vmcnt((NBUF - 3) L).  FAST: stage 0 issues W(2) W(3) W(4) X(PX) .. X(4), in that
-  // order, so X(2) is followed by 2 XI instructions at the end of stage 0 and X(3) by 2 XI + 2 at the end of stage 1; before its unit
-  // UM stage 0 waits for X(1) (followed by X(2) at 128 tokens; by W(2..4) and X(2) at 64, where X(1) was part of the prologue).
-  constexpr int END0 = FAST ? 2 * XI : PEND, END1 = FAST ? 2 * XI + 2 : PEND;
-  constexpr int MID = FAST ? (PX == 1 ? XI : 6 + XI) : (NBUF - 3) * L + 2 + (UM - 1) * PER;
-  static_assert(MID <= 63, "vmcnt field");
-  unsigned cur = 0u, nxt = (unsigned)SLOT, fill = (unsigned)(NBUF - 1) * SLOT;  // slots of stage s, s + 1, s + NBUF - 1
-  unsigned long long seg_wait = 0, seg_bar = 0;
-  auto stage = [&](auto jc, int s) __attribute__((always_inline)) {
-    constexpr int J = decltype(jc)::value;
-    const int ktx = min(t.kt_lo + s + NBUF - 1, t.kt_hi - 1), ktw = (ABL & 16384) ? t.kt_lo : min(t.kt_lo + s + WD, t.kt_hi - 1);  // (16384: the same, cache-resident weight stage every time)
-    read_w(xk_ic<(J + 1) % WD>{}, wnx);  // W(s + 1): landed since the wait that ended stage s - 1
-    wide_compute<MB, 1, GM, (ABL & 27), true, 2>(wc, wnx, xrd + cur, xrd + nxt, dq, acc, carry, [&](int u) {
-      if constexpr (!(ABL & 2)) {
-        bool first = false;
-        if constexpr (J == 0) first = s == 0;
-        if (first) {  // stage 0: wait for x stage 1 before the first read of it; FAST: fill the rest of the ring
-          if (u == UM) {
-            if constexpr (!LD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MID) : "memory");
-            __builtin_amdgcn_s_barrier();  // ... in every wave
-          }
-          if constexpr (FAST) {
-            if (u == 0) {
-              pro_w(xk_ic<2>{});
-              pro_w(xk_ic<3>{});
-              issue_w(xk_ic<0>{}, ktw);
-              x_stage(PX);
-            }
-            if (PX == 1 && u == 1) x_stage(2);
-            if (u == (PX == 1 ? 2 : 1)) x_stage(3);
-            if (u == (PX == 1 ? 3 : 2)) x_stage(4);   // (= this stage's own share: ktx, fill)
-            return;
-          }
-        }
-        if constexpr (ABL & 65536) {
-          // (experiment: STAGGERED issue.  The barrier aligns the eight waves, so with fixed issue points all of them hand their
-          // vector-memory instructions to the CU's one address path in the same few hundred clocks and wait for it together -- both
-          // waves of every SIMD at once, nobody left to issue MFMAs.  Here wave (wn, wk) issues its whole share of the stage with
-          // unit (wn + 2 wk) % 4: two waves per unit, never the two of one SIMD.)
-          if (u == ((wn + 2 * wk) & 3)) {
-            issue_w(xk_ic<J>{}, ktw);
-#pragma unroll
-            for (int i = 0; i < XI; ++i) issue_x(i, ktx, fill);
-          }
-          return;
-        }
-        if constexpr (!(ABL & 512))
-          if (u == 0) issue_w(xk_ic<J>{}, ktw);  // set J held W(s), which has been in VGPRs since stage s - 1
-        if constexpr (!(ABL & 256)) {
-          if constexpr ((ABL & 1024) && XI == 4) {
-            issue_x(u, ktx, fill);               // (experiment: one piece with every unit)
-          } else if (u == 1 || u == 2) {
-#pragma unroll
-            for (int i = 0; i < PER; ++i) issue_x((u - 1) * PER + i, ktx, fill);
-          }
-        }
-      }
-    });
-    unsigned long long tq0 = 0, tq1 = 0;
-    if constexpr (ABL & 8192) tq0 = __builtin_amdgcn_s_memtime();
-    if constexpr (!(ABL & 2) && !(ABL & 128)) {  // x stage s + 2 and weight set s + 2 have landed ...
-      bool s0 = false, s1 = false;
-      if constexpr (J == 0) s0 = s == 0;
-      if constexpr (J == 1) s1 = s == 1;
-      if constexpr (LD) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (only the weights: set s + 2 was issued two stages ago)
-      else if (s0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(END0) : "memory");
-      else if (s1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(END1) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");
-    }
-    if constexpr (ABL & 8192) tq1 = __builtin_amdgcn_s_memtime();
-    if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();  // ... in every wave; everybody is done with x stage s
-    if constexpr (ABL & 8192) {  // (experiment: shader clocks a wave spends in the counted wait / at the barrier, summed over the stages)
-      const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
-      seg_wait += tq1 - tq0;
-      seg_bar += tq2 - tq1;
-    }
-    wc = wnx;
-    fill = cur;
-    cur = nxt;
-    nxt = nxt + SLOT >= (unsigned)(NBUF * SLOT) ? 0u : nxt + SLOT;
-  };
-  for (int base = 0; base < t.nstage; base += WD) {
-    stage(xk_ic<0>{}, base);
-    if (base + 1 < t.nstage) stage(xk_ic<1>{}, base + 1);
-    if (base + 2 < t.nstage) stage(xk_ic<2>{}, base + 2);
-    if constexpr (WD > 3) if (base + 3 < t.nstage) stage(xk_ic<3 % WD>{}, base + 3);
-    if constexpr (WD > 4) if (base + 4 < t.nstage) stage(xk_ic<4 % WD>{}, base + 4);
-    if constexpr (WD > 5) if (base + 5 < t.nstage) stage(xk_ic<5 % WD>{}, base + 5);
-  }
-  if (wk) __builtin_amdgcn_s_setprio(0);
-  if constexpr (ABL & 64) { ph[2] = __builtin_amdgcn_s_memrealtime(); cyc = __builtin_amdgcn_s_memtime() - cyc; }
-
+// The way out shared by the exchange-K kernels: K parities swapped through LDS, slices exchanged through the mailboxes, finished rows
+// stored (see the header comment).  `acc`: this wave's partial sums over its K parity and its workgroup's K slice.
+template <int MB, int S, int ABL>
+__device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, floatx16 (&acc)[1][MB], char* smem, int lane, int wave, int wn, int wk,
+                                           int rho, int h, unsigned long long (&ph)[6]) {
   // ---- 1. the two K parities of a channel quarter swap halves through LDS ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the replayed loads of the last stages)
   __builtin_amdgcn_s_barrier();                     // the ring is free
@@ -705,6 +485,234 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
       }
     }
   }
+}
+
+// ABL (tools builds only): 64 = s_memrealtime stamps at the phase boundaries of every wave into a.dbg; 4 = no cross-CU exchange (the
+// own part is finished without the other slices: wrong results, the launch minus the exchange); 1 / 2 / 8 / 16 as in wide_compute (no
+// compute / no loads in the K loop / no dequantisation / no B-fragment reads); 32 = no barrier in the K loop; 128 = no counted wait at the
+// end of a stage; 256 / 512 = no x pieces / no weight loads in the K loop; 1024 = one x piece with every unit instead of two with two.
+template <int MB, int GM, int NBUF, int WD, int S, int ABL = 0>
+__global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(const GemmArgs a) {
+  constexpr int NW = 8, NG = 1;
+  constexpr bool LD = (ABL & 4096) != 0;  // experiment: four extra LOADER waves issue every x piece, the eight compute waves only their weights
+  constexpr int SLOT = MB * 8192;
+  constexpr int XI = MB;       // x LDS-DMA instructions per wave and stage (MB * 32 rows / (8 waves * 4 rows))
+  constexpr int L = XI + 2;    // vector-memory instructions per wave and stage (+ weights, + (scale, zero) word)
+  constexpr int NU = 4;        // units (k16 steps of this wave's parity) per stage
+  constexpr int PEND = (NBUF - 3) * L;
+  static_assert(GM <= 1 && (MB == 2 || MB == 4), "G % 128 == 0, 64- or 128-token tiles");
+  static_assert(NBUF >= 3 && NBUF * SLOT <= 160 * 1024 && WD >= NBUF - 1 && WD >= 3 && WD <= 6 && PEND <= 63, "ring / queue geometry");
+  static_assert(S == 1 || S == 2 || S == 4 || S == 8, "K slices per tile");
+  static_assert(MB * 16384 <= NBUF * SLOT, "the K-parity exchange must fit in the ring");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF * SLOT
+
+  if constexpr (ABL & 32) span_stamp(a.span, 0);  // (32: per-wave start / end stamps of the in-kernel span clock, nothing else changes)
+  unsigned long long ph[6], cyc = 0;  // (cyc: shader clocks spent in the K loop, s_memtime)
+  if constexpr (ABL & 64) ph[0] = __builtin_amdgcn_s_memrealtime();
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int wn = wave & 3, wk = wave >> 2;
+  const int rho = lane & 31, h = lane >> 5;
+  const XkTile t = xk_tile<MB, S>(a);
+  const int ct0 = (t.nb * 4 + wn) * 2;
+  const WideBufs<XI> b = wide_bufs<MB, 1, 2>(a, t.m0, ct0, lane, wave);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned xdst = lds_base + (unsigned)wave * 1024u;  // + slot + i * 8 KiB
+  const unsigned xrd = (lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4)) ^ ((unsigned)wk << 5);
+
+  if constexpr (LD) {
+    static_assert(!LD || (NBUF == 5 && MB == 4), "loader experiment: 128-token tiles, five slots");
+    if (wave >= 8) {  // loader wave lw: piece i = rows 16 i + 4 lw + lane / 16 of the token tile, i = 0 .. 7
+      const unsigned lw = (unsigned)wave - 8u;
+      const unsigned row = 4u * lw + ((unsigned)lane >> 4);
+      unsigned voff[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        voff[i] = (unsigned)min(t.m0 + 16 * i + (int)row, a.M - 1) * (unsigned)a.K * 2u + 16u * (((unsigned)lane & 15u) ^ (row & 15u));
+      const unsigned dst = lds_base + lw * 1024u;
+      auto fillx = [&](int q, unsigned slot) {
+        const int kt = min(t.kt_lo + q, t.kt_hi - 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds_dma16(b.x, voff[i], (unsigned)kt * 256u, dst + slot + i * 4096);
+      };
+      fillx(0, 0u); fillx(1, SLOT); fillx(2, 2 * SLOT); fillx(3, 3 * SLOT);
+      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // x stage 0
+      __builtin_amdgcn_s_barrier();                      // A
+      fillx(4, 4 * SLOT);
+      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // x stage 1
+      __builtin_amdgcn_s_barrier();                      // M (stage 0, before the first read of stage 1)
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // x stage 2
+      __builtin_amdgcn_s_barrier();                      // end of stage 0
+      unsigned slot = 0u;                                // slot of stage s + 4 = slot of stage s - 1
+      for (int s2 = 1; s2 < t.nstage; ++s2) {
+        fillx(s2 + 4, slot);
+        slot = slot + SLOT >= (unsigned)(NBUF * SLOT) ? 0u : slot + SLOT;
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // x stage s + 2
+        __builtin_amdgcn_s_barrier();                      // end of stage s
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // the ring is free
+      return;
+    }
+  }
+  auto issue_x = [&](int i, int kt, unsigned slot) {
+    if constexpr (!LD) lds_dma16(b.x, b.x_voff[i], (unsigned)kt * 256u, xdst + slot + i * (NW * 1024));
+  };
+  auto issue_w = [&](auto jc, int kt) {
+    const unsigned g = (unsigned)group_index<GM>(kt, 0, a.tpg, a.G);
+    XkSet<decltype(jc)::value>::issue(b.w, b.w_voff, (unsigned)kt * 1024u, b.s, b.s_voff, g * 64u);
+  };
+  auto read_w = [&](auto jc, WideW<1, GM>& w) {
+    XkSet<decltype(jc)::value>::read(w.lo[0], w.sz[0][0]);
+    w.hi[0] = w.lo[0];
+  };
+
+  floatx16 acc[1][MB];
+  wide_zero<MB, 1>(acc);
+  const DqConsts dq = make_dq_consts();
+
+  // FAST start (the shipped geometry, five slots / four sets): the prologue asks only for what stage 0 needs -- weight sets 0, 1 and x
+  // stage 0 (and 1 where stage 0 reads it from its second unit on: 64-token tiles) -- and stage 0 itself issues the rest of the
+  // ring next to its MFMAs.  Every CU's vector-memory path moves 64 B per clock: a prologue that asks for all four stages (164 KB
+  // at 128 tokens) spends ~1.5 us ISSUING before the first wait [r03 phase stamps: 2.6-2.8 us to the first MFMA, with or without
+  // waiting for stage 1].  Other geometries (tuning sweeps) keep the plain prologue, in the order the steady state would have
+  // issued it: [W(0 .. WD - NBUF)], then W(WD - NBUF + 1 + q), X(q) for q = 0 .. NBUF - 2.
+  constexpr bool FAST = NBUF == 5 && WD == 4 && !(ABL & 2) && !LD;
+  constexpr int DEPTH = wide_bdepth<MB, 1>();
+  constexpr int UM = NU - DEPTH;            // the unit of a stage that first reads the NEXT stage's tokens
+  constexpr int PX = UM >= 2 ? 1 : 2;       // x stages the FAST prologue asks for
+  constexpr int PER = XI / 2;               // steady state: x pieces with units 1 and 2 (nothing with the last unit of the stage)
+  auto x_stage = [&](int q) {               // all pieces of x stage q (q < NBUF: its slot is q)
+    const int kt = min(t.kt_lo + q, t.kt_hi - 1);
+#pragma unroll
+    for (int i = 0; i < XI; ++i) issue_x(i, kt, (unsigned)q * SLOT);
+  };
+  auto pro_w = [&](auto jc) { issue_w(jc, min(t.kt_lo + decltype(jc)::value, t.kt_hi - 1)); };
+  if constexpr (FAST) {
+    pro_w(xk_ic<0>{});
+    pro_w(xk_ic<1>{});
+    x_stage(0);
+    if constexpr (PX == 2) x_stage(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PX - 1) * XI) : "memory");  // weight sets 0, 1 and x stage 0 have landed
+  } else {
+    constexpr int E = WD - NBUF + 1;  // sets issued ahead of the first x stage
+    if constexpr (E > 0) pro_w(xk_ic<0>{});
+    if constexpr (E > 1) pro_w(xk_ic<1>{});
+    if constexpr (E > 2) pro_w(xk_ic<2>{});
+    if constexpr (E > 3) pro_w(xk_ic<3>{});
+    pro_w(xk_ic<E>{});
+    x_stage(0);
+    if constexpr (NBUF > 2) { pro_w(xk_ic<E + 1>{}); x_stage(1); }
+    if constexpr (NBUF > 3) { pro_w(xk_ic<E + 2>{}); x_stage(2); }
+    if constexpr (NBUF > 4) { pro_w(xk_ic<E + 3>{}); x_stage(3); }
+    static_assert(NBUF <= 5, "prologue written out for up to five slots");
+    // start as soon as x stage 0 and weight sets 0, 1 are there; stage 0 waits for x stage 1 itself, just before its first read of it
+    constexpr int INIT = LD ? 2 * (WD - 2) : (NBUF - 2) * L - (E == 0 ? 2 : 0);  // what the prologue issued behind X(0) (and W(1))
+    static_assert(INIT <= 63, "vmcnt field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INIT) : "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  WideW<1, GM> wc, wnx;
+  read_w(xk_ic<0>{}, wc);
+  WideCarry<MB, 1, GM> carry;
+  wide_prepare<MB, 1, GM, true, 2>(carry, wc, xrd, dq);
+  if (wk) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses every VALU arbitration otherwise (MI355X_MICROARCH.md, two waves per SIMD)
+  if constexpr (ABL & 64) { ph[1] = __builtin_amdgcn_s_memrealtime(); cyc = __builtin_amdgcn_s_memtime(); }
+
+  // vmcnt bookkeeping.  Steady state: stage s issues [W(s + WD), X(s + NBUF - 1)] = L instructions per wave; "x stage s + 2 and weight
+  // set s + 2 have landed" at the end of stage s is vmcnt((NBUF - 3) L).  FAST: stage 0 issues W(2) W(3) W(4) X(PX) .. X(4), in that
+  // order, so X(2) is followed by 2 XI instructions at the end of stage 0 and X(3) by 2 XI + 2 at the end of stage 1; before its unit
+  // UM stage 0 waits for X(1) (followed by X(2) at 128 tokens; by W(2..4) and X(2) at 64, where X(1) was part of the prologue).
+  constexpr int END0 = FAST ? 2 * XI : PEND, END1 = FAST ? 2 * XI + 2 : PEND;
+  constexpr int MID = FAST ? (PX == 1 ? XI : 6 + XI) : (NBUF - 3) * L + 2 + (UM - 1) * PER;
+  static_assert(MID <= 63, "vmcnt field");
+  unsigned cur = 0u, nxt = (unsigned)SLOT, fill = (unsigned)(NBUF - 1) * SLOT;  // slots of stage s, s + 1, s + NBUF - 1
+  unsigned long long seg_wait = 0, seg_bar = 0;
+  auto stage = [&](auto jc, int s) __attribute__((always_inline)) {
+    constexpr int J = decltype(jc)::value;
+    const int ktx = min(t.kt_lo + s + NBUF - 1, t.kt_hi - 1), ktw = (ABL & 16384) ? t.kt_lo : min(t.kt_lo + s + WD, t.kt_hi - 1);  // (16384: the same, cache-resident weight stage every time)
+    read_w(xk_ic<(J + 1) % WD>{}, wnx);  // W(s + 1): landed since the wait that ended stage s - 1
+    wide_compute<MB, 1, GM, (ABL & 27), true, 2>(wc, wnx, xrd + cur, xrd + nxt, dq, acc, carry, [&](int u) {
+      if constexpr (!(ABL & 2)) {
+        bool first = false;
+        if constexpr (J == 0) first = s == 0;
+        if (first) {  // stage 0: wait for x stage 1 before the first read of it; FAST: fill the rest of the ring
+          if (u == UM) {
+            if constexpr (!LD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MID) : "memory");
+            __builtin_amdgcn_s_barrier();  // ... in every wave
+          }
+          if constexpr (FAST) {
+            if (u == 0) {
+              pro_w(xk_ic<2>{});
+              pro_w(xk_ic<3>{});
+              issue_w(xk_ic<0>{}, ktw);
+              x_stage(PX);
+            }
+            if (PX == 1 && u == 1) x_stage(2);
+            if (u == (PX == 1 ? 2 : 1)) x_stage(3);
+            if (u == (PX == 1 ? 3 : 2)) x_stage(4);   // (= this stage's own share: ktx, fill)
+            return;
+          }
+        }
+        if constexpr (ABL & 65536) {
+          // (experiment: STAGGERED issue.  The barrier aligns the eight waves, so with fixed issue points all of them hand their
+          // vector-memory instructions to the CU's one address path in the same few hundred clocks and wait for it together -- both
+          // waves of every SIMD at once, nobody left to issue MFMAs.  Here wave (wn, wk) issues its whole share of the stage with
+          // unit (wn + 2 wk) % 4: two waves per unit, never the two of one SIMD.)
+          if (u == ((wn + 2 * wk) & 3)) {
+            issue_w(xk_ic<J>{}, ktw);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) issue_x(i, ktx, fill);
+          }
+          return;
+        }
+        if constexpr (!(ABL & 512))
+          if (u == 0) issue_w(xk_ic<J>{}, ktw);  // set J held W(s), which has been in VGPRs since stage s - 1
+        if constexpr (!(ABL & 256)) {
+          if constexpr ((ABL & 1024) && XI == 4) {
+            issue_x(u, ktx, fill);               // (experiment: one piece with every unit)
+          } else if (u == 1 || u == 2) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) issue_x((u - 1) * PER + i, ktx, fill);
+          }
+        }
+      }
+    });
+    unsigned long long tq0 = 0, tq1 = 0;
+    if constexpr (ABL & 8192) tq0 = __builtin_amdgcn_s_memtime();
+    if constexpr (!(ABL & 2) && !(ABL & 128)) {  // x stage s + 2 and weight set s + 2 have landed ...
+      bool s0 = false, s1 = false;
+      if constexpr (J == 0) s0 = s == 0;
+      if constexpr (J == 1) s1 = s == 1;
+      if constexpr (LD) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (only the weights: set s + 2 was issued two stages ago)
+      else if (s0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(END0) : "memory");
+      else if (s1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(END1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");
+    }
+    if constexpr (ABL & 8192) tq1 = __builtin_amdgcn_s_memtime();
+    if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();  // ... in every wave; everybody is done with x stage s
+    if constexpr (ABL & 8192) {  // (experiment: shader clocks a wave spends in the counted wait / at the barrier, summed over the stages)
+      const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
+      seg_wait += tq1 - tq0;
+      seg_bar += tq2 - tq1;
+    }
+    wc = wnx;
+    fill = cur;
+    cur = nxt;
+    nxt = nxt + SLOT >= (unsigned)(NBUF * SLOT) ? 0u : nxt + SLOT;
+  };
+  for (int base = 0; base < t.nstage; base += WD) {
+    stage(xk_ic<0>{}, base);
+    if (base + 1 < t.nstage) stage(xk_ic<1>{}, base + 1);
+    if (base + 2 < t.nstage) stage(xk_ic<2>{}, base + 2);
+    if constexpr (WD > 3) if (base + 3 < t.nstage) stage(xk_ic<3 % WD>{}, base + 3);
+    if constexpr (WD > 4) if (base + 4 < t.nstage) stage(xk_ic<4 % WD>{}, base + 4);
+    if constexpr (WD > 5) if (base + 5 < t.nstage) stage(xk_ic<5 % WD>{}, base + 5);
+  }
+  if (wk) __builtin_amdgcn_s_setprio(0);
+  if constexpr (ABL & 64) { ph[2] = __builtin_amdgcn_s_memrealtime(); cyc = __builtin_amdgcn_s_memtime() - cyc; }
+
+  xk_way_out<MB, S, ABL>(a, t, acc, smem, lane, wave, wn, wk, rho, h, ph);
   if constexpr (ABL & 32) span_stamp(a.span, 1);
   if constexpr (ABL & 64) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -715,6 +723,153 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
       for (int i = 0; i < 6; ++i) o[i] = ph[i];
       o[6] = cyc;
       if constexpr (ABL & 8192) o[7] = (seg_wait << 32) | (seg_bar & 0xffffffffull);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Loader-wave flavour (r03, second half): the same tile, compute core and way out, but the eight compute waves issue NO vector-memory
+// instruction at all.  Measured on the kernel above [profiles/r03_xk_anatomy.txt]: a vector-memory instruction blocks the wave that
+// issues it until the CU's address path takes it, and with the memory pipe kept full by the prefetch that is hundreds of clocks a
+// stage in which that wave issues no MFMA -- two weight loads per wave and stage alone cost the 128-token K loop 5 k of its 27 k
+// clocks, while x pieces issued by four EXTRA waves cost 1.4 k.  So: twelve waves.  Waves 8, 9 bring x in (LDS-DMA, a ring of three
+// slots: stage s + 2 is requested when stage s starts), waves 10, 11 the packed weights and the (scale, zero) words (LDS-DMA, a ring
+// of five slots, stage s + 4: HBM-cold, so three stages of slack); each loader waits for what the NEXT stage needs and joins the one
+// barrier of the stage.  The compute waves pick their 16 bytes of packed weights and their group word out of the slot with two LDS reads
+// a stage (what r02's ring kernel did) and otherwise see only LDS, VALU and the matrix core.  168 registers per wave (three per SIMD).
+// ------------------------------------------------------------------------------------------------
+template <int MB, int GM, int S, int ABL = 0>
+__global__ __launch_bounds__(768) void w4a16_xl_kernel(const GemmArgs a) {
+  constexpr int NXS = MB == 2 ? 4 : 3, NWS = 5;   // (64 tokens: a stage is too short for one stage of lookahead)
+  constexpr int SLOTX = MB * 8192, SLOTW = 8192 + 512;
+  constexpr int UM = 4 - wide_bdepth<MB, 1>();   // the unit of a stage that first reads the NEXT stage's tokens
+  static_assert(GM <= 1 && (MB == 2 || MB == 4), "G % 128 == 0, 64- or 128-token tiles");
+  static_assert(NXS * SLOTX + NWS * SLOTW <= 160 * 1024 && MB * 16384 <= NXS * SLOTX + NWS * SLOTW, "rings / K-parity exchange vs LDS");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [x ring][weight ring]
+
+  if constexpr (ABL & 32) span_stamp(a.span, 0);
+  unsigned long long ph[6], cyc = 0;
+  if constexpr (ABL & 64) ph[0] = __builtin_amdgcn_s_memrealtime();
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const XkTile t = xk_tile<MB, S>(a);
+  const int KT = a.K >> 7, NGRP = a.K / a.G;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned wring = lds_base + NXS * SLOTX;
+  auto ktq = [&](int q) { return min(t.kt_lo + q, t.kt_hi - 1); };  // (past the end of the slice: replays of its last stage)
+
+  if (wave >= 8) {
+    const unsigned lw = (unsigned)wave - 8u;
+    if (lw < 2u) {  // ---- x loader: piece i = rows 8 i + 4 lw + lane / 16 of the token tile
+      constexpr int NP = MB * 4;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (unsigned)a.M * (unsigned)a.K * 2u, 0x00020000);
+      unsigned voff[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const unsigned row = 8u * i + 4u * lw + ((unsigned)lane >> 4);
+        voff[i] = (unsigned)min(t.m0 + (int)row, a.M - 1) * (unsigned)a.K * 2u + 16u * (((unsigned)lane & 15u) ^ (row & 15u));
+      }
+      const unsigned dst = lds_base + lw * 1024u;
+      auto fillx = [&](int q, unsigned slot) {
+        const unsigned so = (unsigned)ktq(q) * 256u;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) lds_dma16(rx, voff[i], so, dst + slot + i * 2048);
+      };
+      constexpr int AHEAD = (NXS - 3) * NP;  // pieces that may still be in flight when "x stage s + 2 has landed"
+      fillx(0, 0u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // A: the compute waves start on x stage 0 ...
+      fillx(1, SLOTX);
+      if constexpr (NXS > 3) fillx(2, 2u * SLOTX);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD) : "memory");
+      __builtin_amdgcn_s_barrier();  // M: ... and read x stage 1 from unit UM of stage 0 on
+      unsigned slot = (unsigned)(NXS - 1) * SLOTX;  // slot of stage s + NXS - 1
+      for (int s2 = 0; s2 < t.nstage; ++s2) {
+        fillx(s2 + NXS - 1, slot);
+        slot = slot + SLOTX >= (unsigned)(NXS * SLOTX) ? 0u : slot + SLOTX;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD) : "memory");  // x stage s + 2 has landed
+        __builtin_amdgcn_s_barrier();                                  // end of stage s
+      }
+    } else {  // ---- weight loader wl: tiles 4 wl .. 4 wl + 3 of the workgroup's eight 16-channel tiles, and their group words
+      const unsigned wl = lw - 2u;
+      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.QW + (size_t)(t.nb * 8) * KT * 64), 0, 8u * (unsigned)KT * 1024u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint32_t*)a.S + (size_t)(t.nb * 8) * NGRP * 16), 0, 8u * (unsigned)NGRP * 64u, 0x00020000);
+      const unsigned wv = (unsigned)lane * 16u;
+      const unsigned sv = ((unsigned)lane >> 4) * (unsigned)NGRP * 64u + ((unsigned)lane & 15u) * 4u;
+      auto fillw = [&](int q, unsigned slot) {
+        const int kt = ktq(q);
+        const unsigned g = (unsigned)group_index<GM>(kt, 0, a.tpg, a.G);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          lds_dma16(rw, wv, (4u * wl + i) * (unsigned)KT * 1024u + (unsigned)kt * 1024u, wring + slot + (4u * wl + i) * 1024u);
+        lds_dma4(rs, sv, 4u * wl * (unsigned)NGRP * 64u + g * 64u, wring + slot + 8192u + wl * 256u);
+      };
+      fillw(0, 0u);
+      fillw(1, SLOTW);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // sets 0 and 1
+      __builtin_amdgcn_s_barrier();                      // A
+      fillw(2, 2u * SLOTW);
+      fillw(3, 3u * SLOTW);
+      __builtin_amdgcn_s_barrier();                      // M
+      unsigned slot = 4u * SLOTW;                         // slot of stage s + 4
+      for (int s2 = 0; s2 < t.nstage; ++s2) {
+        fillw(s2 + 4, slot);
+        slot = slot + SLOTW >= (unsigned)(NWS * SLOTW) ? 0u : slot + SLOTW;
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // set s + 2 has landed
+        __builtin_amdgcn_s_barrier();                       // end of stage s
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the replays behind the end of the slice)
+    __builtin_amdgcn_s_barrier();                      // the rings are free (xk_way_out's first barrier)
+    return;
+  }
+
+  // ---- compute waves
+  const int wn = wave & 3, wk = wave >> 2;
+  const int rho = lane & 31, h = lane >> 5;
+  const unsigned xrd = (lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4)) ^ ((unsigned)wk << 5);
+  typedef const __attribute__((address_space(3))) char* lds_ptr;
+  const unsigned wrd = wring + (unsigned)(2 * wn + (rho >> 4)) * 1024u + 16u * ((unsigned)(rho & 15) + 16u * (unsigned)(h + 2 * wk));
+  const unsigned srd = wring + 8192u + (unsigned)(2 * wn + (rho >> 4)) * 64u + (unsigned)(rho & 15) * 4u;
+  auto read_w = [&](WideW<1, GM>& w, unsigned slot) {
+    w.lo[0] = *(const __attribute__((address_space(3))) u32x4*)(lds_ptr)(uintptr_t)(wrd + slot);
+    w.hi[0] = w.lo[0];
+    w.sz[0][0] = *(const __attribute__((address_space(3))) uint32_t*)(lds_ptr)(uintptr_t)(srd + slot);
+  };
+  floatx16 acc[1][MB];
+  wide_zero<MB, 1>(acc);
+  const DqConsts dq = make_dq_consts();
+  __builtin_amdgcn_s_barrier();  // A: x stage 0 and weight sets 0, 1 have landed
+  WideW<1, GM> wc, wnx;
+  read_w(wc, 0u);
+  WideCarry<MB, 1, GM> carry;
+  wide_prepare<MB, 1, GM, true, 2>(carry, wc, xrd, dq);
+  if (wk) __builtin_amdgcn_s_setprio(1);
+  if constexpr (ABL & 64) { ph[1] = __builtin_amdgcn_s_memrealtime(); cyc = __builtin_amdgcn_s_memtime(); }
+  unsigned cur = 0u, nxt = (unsigned)SLOTX, wnext = (unsigned)SLOTW;
+  for (int s = 0; s < t.nstage; ++s) {
+    read_w(wnx, wnext);  // W(s + 1): landed since the barrier that ended stage s - 1
+    wide_compute<MB, 1, GM, 0, true, 2>(wc, wnx, xrd + cur, xrd + nxt, dq, acc, carry, [&](int u) {
+      if (u == UM && s == 0) __builtin_amdgcn_s_barrier();  // M (first stage only): x stage 1 has landed
+    });
+    __builtin_amdgcn_s_barrier();  // the loaders have x stage s + 2 and weight set s + 2; everybody is done with x stage s
+    wc = wnx;
+    cur = nxt;
+    nxt = nxt + SLOTX >= (unsigned)(NXS * SLOTX) ? 0u : nxt + SLOTX;
+    wnext = wnext + SLOTW >= (unsigned)(NWS * SLOTW) ? 0u : wnext + SLOTW;
+  }
+  if (wk) __builtin_amdgcn_s_setprio(0);
+  if constexpr (ABL & 64) { ph[2] = __builtin_amdgcn_s_memrealtime(); cyc = __builtin_amdgcn_s_memtime() - cyc; }
+  xk_way_out<MB, S, ABL>(a, t, acc, smem, lane, wave, wn, wk, rho, h, ph);
+  if constexpr (ABL & 32) span_stamp(a.span, 1);
+  if constexpr (ABL & 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ph[5] = __builtin_amdgcn_s_memrealtime();
+    if (a.dbg && lane == 0) {
+      unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) o[i] = ph[i];
+      o[6] = cyc;
     }
   }
 }

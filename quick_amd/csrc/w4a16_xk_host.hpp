@@ -12,6 +12,7 @@ struct XkConfig {
   int nbuf;  // x ring slots
   int wd;    // weight queue depth (stages)
   int abl;   // tools builds only: timing experiments / phase stamps
+  int loader = 0;  // 1: the twelve-wave flavour (four loader waves issue every vector-memory instruction; nbuf / wd do not apply)
 };
 constexpr size_t kXkZoneBytesHost = (size_t)16 << 20;  // == kXkZoneBytes (w4a16_xk.hpp)
 

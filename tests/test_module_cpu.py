@@ -143,7 +143,7 @@ def test_product_library_has_no_timing_experiments():
     """Kernel-id bits 16-20 select ablation builds (wrong results on purpose) and phase stamps: a QUICK_AMD_TOOLS build only.
     The product library rejects them before any GPU work and exports no such kernels."""
     lib = _lib.load()
-    for kid in (2 | (1 << 16), 3 | (16 << 16), 4 | (4 << 16), 1 << 16):
+    for kid in (2 | (1 << 16), 3 | (16 << 16), 4 | (4 << 16), 1 << 16, 4 | (1 << 12)):   # (the last: the loader-wave exchange-K flavour)
         rc = lib.quick_w4a16_gemm_f16_ex(None, None, None, None, None, None, None, 0, 512, 4096, 4096, 128, kid, 0, None)
         assert rc == 1 and "QUICK_AMD_TOOLS" in _lib.last_error(), (kid, rc, _lib.last_error())
     import subprocess
@@ -153,7 +153,7 @@ def test_product_library_has_no_timing_experiments():
         # ABL is the last-but-one template argument of the ring kernel and the last of the wide / tiled / xk kernels: every shipped build has 0
         # (ring: 32 = span stamps, a measurement aid that changes no result)
         bad = [l for l in syms.splitlines() if re.search(r"w4a16_wide_kernel<\d+, \d+, \d+, [1-9]\d*>", l) or
-               re.search(r"w4a16_xk_kernel<\d+, \d+, \d+, \d+, \d+, [1-9]\d*>", l) or
+               re.search(r"w4a16_xk_kernel<\d+, \d+, \d+, \d+, \d+, [1-9]\d*>", l) or "w4a16_xl_kernel" in l or
                re.search(r"w4a16_ring_kernel<\d+, \d+, \d+, \d+, (?!0,|32,)\d+, \d+>", l) or
                re.search(r"w4a16_tiled_kernel<\d+, \d+, \d+, \d+, [1-9]\d*, \d+>", l)]
         assert not bad, bad[:5]
