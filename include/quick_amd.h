@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QUICK_AMD_ABI_VERSION 1
+#define QUICK_AMD_ABI_VERSION 2
 
 /* status codes */
 #define QUICK_OK 0
@@ -135,6 +135,9 @@ typedef struct quick_gemm_fusion {
   const void* rmsnorm_weight;
   float rmsnorm_eps;
   int silu_mul;
+  const void* prefetch;   /* hint (ABI 2): [prefetch, prefetch + prefetch_bytes) is what the NEXT launch will stream -- a decode step knows */
+  size_t prefetch_bytes;  /* its next layer's weights.  Small-M kernels that can spare a wave per workgroup pull it into the memory-side */
+                          /* cache while they run; every other kernel ignores it.  No result depends on it. */
 } quick_gemm_fusion;
 int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* scales, const void* qzeros,
                                const quick_gemm_fusion* fusion, void* y, void* workspace, size_t workspace_bytes,
@@ -201,6 +204,12 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
                                     void* k_cache, void* v_cache, void* out, int batch, int n_heads, int n_kv_heads,
                                     int head_dim, int cache_len, float scale, void* hip_stream);
 int quick_silu_mul_f16(const void* gate_up, void* y, int rows, int intermediate, void* hip_stream);
+
+/* Pull [ptr, ptr + bytes) through HBM into the memory-side cache (one dword read per 128-byte line, results unused) with
+ * `workgroups` (<= 0: 64) workgroups of 256 threads.  A caller that knows which weights the NEXT launch will stream -- a
+ * decode step does -- issues this on a second stream while the current GEMM runs: the HBM pipe stays busy through the
+ * head and tail of the launches.  A hint: no result depends on it. */
+int quick_prefetch(const void* ptr, size_t bytes, int workgroups, void* hip_stream);
 
 /*
  * Format bridge.  "cuda order" is byte-for-byte what the reference's WQLinear_QUICK.from_linear

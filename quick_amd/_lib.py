@@ -11,7 +11,8 @@ _P, _I, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
 class GemmFusion(ctypes.Structure):
     """struct quick_gemm_fusion (include/quick_amd.h)."""
-    _fields_ = [("bias", _P), ("residual", _P), ("rmsnorm_weight", _P), ("rmsnorm_eps", ctypes.c_float), ("silu_mul", _I)]
+    _fields_ = [("bias", _P), ("residual", _P), ("rmsnorm_weight", _P), ("rmsnorm_eps", ctypes.c_float), ("silu_mul", _I),
+                ("prefetch", _P), ("prefetch_bytes", _Z)]
 
 
 _SIGNATURES = {
@@ -32,6 +33,7 @@ _SIGNATURES = {
     "quick_decode_attention_f16": (_I, [_P] * 5 + [_I] * 5 + [ctypes.c_float, _P]),
     "quick_decode_rope_attention_f16": (_I, [_P] * 7 + [_I] * 5 + [ctypes.c_float, _P]),
     "quick_silu_mul_f16": (_I, [_P, _P, _I, _I, _P]),
+    "quick_prefetch": (_I, [_P, _Z, _I, _P]),
     "quick_amd_dispatch_floor": (_I, [_I, _P, _P]),
     "quick_repack_cuda_to_mi355x": (_I, [_P] * 6 + [_I, _I, _I, _P]),
     "quick_repack_mi355x_to_cuda": (_I, [_P] * 6 + [_I, _I, _I, _P]),
@@ -57,7 +59,7 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if lib.quick_amd_abi_version() != 1:
+        if lib.quick_amd_abi_version() != 2:
             raise ImportError("libquick_amd.so ABI version mismatch; rebuild with `python -m quick_amd.build --force`")
         _lib = lib
     return _lib

@@ -501,6 +501,23 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict_
   *(half8_t*)(y + i8 * 8) = o;
 }
 
+// Touch one dword of every 128-byte line of [p, p + lines * 128): the memory side (Infinity Cache, 256 MiB) keeps what HBM
+// delivered, so a later launch streams these bytes from the cache.  The loads are never used; a wave ends when they have landed.
+template <int DW>  // dwords touched per 128-byte line: 1, 2 (one per 64 bytes), 4 (one per 32 bytes); 32 = every byte (16-byte loads)
+__global__ void __launch_bounds__(256) prefetch_kernel(const unsigned* __restrict__ p, size_t lines, unsigned* sink) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  unsigned acc = 0;
+  if constexpr (DW == 32) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < lines * 8; i += stride) {
+      const u32x4 v = ((const u32x4*)p)[i];
+      acc |= v[0] | v[1] | v[2] | v[3];
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < lines * DW; i += stride) acc |= p[i * (32 / DW)];
+  }
+  if (acc == 0x9e3779b9u && sink) *sink = acc;  // (keeps the loads alive; sink is null)
+}
+
 }  // namespace quick_amd
 
 using namespace quick_amd;
@@ -584,6 +601,19 @@ int quick_silu_mul_f16(const void* gate_up, void* y, int rows, int intermediate,
   const size_t n8 = (size_t)rows * intermediate / 8;
   hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
                      (const half_t*)gate_up, (half_t*)y, intermediate, n8);
+  return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+}
+
+int quick_prefetch(const void* ptr, size_t bytes, int workgroups, void* hip_stream) {
+  if (!ptr || bytes < 128) return QUICK_OK;
+  const int dw = workgroups >> 16;  // (probe builds: bits 16.. choose the touch density; 0 = one dword per line)
+  workgroups &= 0xffff;
+  if (workgroups <= 0) workgroups = 64;
+  unsigned* sink = nullptr;  // (the kernel's store exists only so that the compiler keeps the loads)
+  const size_t lines = bytes / 128;
+  const unsigned g = (unsigned)std::min<size_t>((size_t)workgroups, (lines + 255) / 256);
+  auto k = dw == 32 ? prefetch_kernel<32> : (dw == 4 ? prefetch_kernel<4> : (dw == 2 ? prefetch_kernel<2> : prefetch_kernel<1>));
+  hipLaunchKernelGGL(k, dim3(g), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned*)ptr, lines, sink);
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
 }
 
