@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QUICK_AMD_ABI_VERSION 2
+#define QUICK_AMD_ABI_VERSION 1
 
 /* status codes */
 #define QUICK_OK 0
@@ -135,9 +135,6 @@ typedef struct quick_gemm_fusion {
   const void* rmsnorm_weight;
   float rmsnorm_eps;
   int silu_mul;
-  const void* prefetch;   /* hint (ABI 2): [prefetch, prefetch + prefetch_bytes) is what the NEXT launch will stream -- a decode step knows */
-  size_t prefetch_bytes;  /* its next layer's weights.  Small-M kernels that can spare a wave per workgroup pull it into the memory-side */
-                          /* cache while they run; every other kernel ignores it.  No result depends on it. */
 } quick_gemm_fusion;
 int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* scales, const void* qzeros,
                                const quick_gemm_fusion* fusion, void* y, void* workspace, size_t workspace_bytes,
@@ -205,10 +202,9 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
                                     int head_dim, int cache_len, float scale, void* hip_stream);
 int quick_silu_mul_f16(const void* gate_up, void* y, int rows, int intermediate, void* hip_stream);
 
-/* Pull [ptr, ptr + bytes) through HBM into the memory-side cache (one dword read per 128-byte line, results unused) with
- * `workgroups` (<= 0: 64) workgroups of 256 threads.  A caller that knows which weights the NEXT launch will stream -- a
- * decode step does -- issues this on a second stream while the current GEMM runs: the HBM pipe stays busy through the
- * head and tail of the launches.  A hint: no result depends on it. */
+/* Measurement aid (tools/prefetch_probe.py): pull [ptr, ptr + bytes) through HBM into the memory-side cache -- one
+ * dword read per 128-byte line, results unused -- with `workgroups` (low 16 bits; 0 = 64) workgroups of 256 threads; bits 16..
+ * choose the touch density (0 / 1: one dword per line, 2, 4, 32 = every byte).  No library path calls it. */
 int quick_prefetch(const void* ptr, size_t bytes, int workgroups, void* hip_stream);
 
 /*

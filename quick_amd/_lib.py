@@ -11,8 +11,7 @@ _P, _I, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
 class GemmFusion(ctypes.Structure):
     """struct quick_gemm_fusion (include/quick_amd.h)."""
-    _fields_ = [("bias", _P), ("residual", _P), ("rmsnorm_weight", _P), ("rmsnorm_eps", ctypes.c_float), ("silu_mul", _I),
-                ("prefetch", _P), ("prefetch_bytes", _Z)]
+    _fields_ = [("bias", _P), ("residual", _P), ("rmsnorm_weight", _P), ("rmsnorm_eps", ctypes.c_float), ("silu_mul", _I)]
 
 
 _SIGNATURES = {
@@ -59,7 +58,7 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if lib.quick_amd_abi_version() != 2:
+        if lib.quick_amd_abi_version() != 1:
             raise ImportError("libquick_amd.so ABI version mismatch; rebuild with `python -m quick_amd.build --force`")
         _lib = lib
     return _lib

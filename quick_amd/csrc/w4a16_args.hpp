@@ -25,8 +25,6 @@ struct GemmArgs {
   const half_t* ln_w;  // deferred-zero skinny kernel: RMSNorm weight [K] applied to x on its way into LDS, or null
   float ln_eps;
   unsigned long long* span;  // measurement aid: per-wave start / end stamps in s_memrealtime ticks (100 MHz), see span_stamp; or null
-  const unsigned* pf;        // touch hint (skinny PF flavours): the NEXT launch's weights, pulled into the memory-side cache by one extra wave per workgroup; or null
-  unsigned pf_lines;         // ... in 128-byte lines
 };
 
 // In-kernel wall-clock span of a launch: first wave's start -> last wave's end on the constant 100 MHz counter.  The

@@ -401,34 +401,8 @@ __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[
 // the Llama-2-70B shapes at M = 16 [r01]).
 // (span stamps: written out at the kernel's own two exits -- moving the body into a forceinline device function called between
 // two stamps changed hipcc's code for the deferred-zero paths into something that fails the parity tests [r02])
-// PF flavours carry ONE EXTRA wave per workgroup (the last) that does nothing but touch its share of a.pf -- one dword of every
-// 128-byte line, results unused -- and ends; s_endpgm waits for the loads, the barriers of the workgroup only count the surviving
-// waves.  The compute waves' own load queues never see those loads (a wave's loads return in order: touches issued by a compute wave
-// would sit in front of, or behind, its own stream), and the HBM pipe has work through the head and tail of the launch.
-template <int NTW, int WAVES, int GM, bool XLDS, bool DZ, bool LN = false, bool SPAN = false, bool PF = false>
-__global__ __launch_bounds__((WAVES + (PF ? 1 : 0)) * 64) void w4a16_skinny_kernel(const GemmArgs a) {
-  unsigned* pf_flag = nullptr;
-  if constexpr (PF) {
-    __shared__ unsigned pf_done;  // set by compute wave 0 behind its last barrier
-    pf_flag = &pf_done;
-    if (threadIdx.x >= WAVES * 64) {
-      if ((threadIdx.x & 63) == 0) pf_done = 0u;  // (before this wave's first barrier, hence before anybody can set it)
-      const unsigned nwg = gridDim.x * gridDim.y * gridDim.z, wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      unsigned t = 0;  // (read-write operand: the register stays t's for the whole loop -- the loads write it long after their issue)
-      for (unsigned i = wg * 64 + (threadIdx.x & 63); i < a.pf_lines; i += nwg * 64)
-        asm volatile("global_load_dword %0, %1, off" : "+v"(t) : "v"(a.pf + (size_t)i * 32) : "memory");
-      // Keep the workgroup's barriers company while the loads are in flight: a wave that waits at s_endpgm for its loads still counts
-      // as alive, and the compute waves would stand at their first barrier until the touches have come back from HBM.  One barrier here
-      // per barrier there; once the compute waves have ended a barrier falls through at once and the flag says so.
-      unsigned done;
-      do {
-        __builtin_amdgcn_s_barrier();
-        done = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)&pf_done);
-      } while (!done);
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(t)::"memory");
-      return;
-    }
-  }
+template <int NTW, int WAVES, int GM, bool XLDS, bool DZ, bool LN = false, bool SPAN = false>
+__global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
   if constexpr (SPAN) span_stamp(a.span, 0);
   constexpr bool PERSIST = XLDS;
   static_assert(!LN || (DZ && !XLDS && NTW >= 2), "the register-level RMSNorm lives in the fragment deferred-zero flavour");
@@ -630,9 +604,6 @@ __global__ __launch_bounds__((WAVES + (PF ? 1 : 0)) * 64) void w4a16_skinny_kern
   while (true) {
     QA_SKINNY_STEP(cB, cA);
     QA_SKINNY_STEP(cA, cB);
-  }
-  if constexpr (PF) {
-    if (threadIdx.x == 0) *(volatile unsigned*)pf_flag = 1u;  // behind this wave's last barrier: the touch wave may end
   }
   if constexpr (SPAN) span_stamp(a.span, 1);
 #undef QA_SKINNY_STEP
@@ -1811,18 +1782,6 @@ static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) 
     g_span_unsupported = true;
     return;
   }
-  if constexpr (WAVES <= 8 && XLDS && DZ && NTW == 1 && !LN) {  // touch-hint flavours (G = 128): one extra wave per workgroup
-    if (a.pf && group_mode(a.G) == 0 && lds + 1024 <= kLdsPerCu) {  // (the flag word is static LDS)
-      auto kfn = w4a16_skinny_kernel<NTW, WAVES, 0, XLDS, DZ, LN, false, true>;
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu - 1024);
-        attr_set = true;
-      }
-      hipExtLaunchKernelGGL(kfn, grid, dim3(WAVES * 64 + 64), (unsigned)lds, L.st, L.start, L.stop, 0, a);
-      return;
-    }
-  }
 #define QA_SKINNY(GMV)                                                                                             \
   do {                                                                                                             \
     auto kfn = w4a16_skinny_kernel<NTW, WAVES, GMV, XLDS, DZ, LN>;                                                 \
@@ -2066,8 +2025,6 @@ struct Fusion {
   const void* ln_w = nullptr;
   float ln_eps = 0.f;
   int silu_mul = 0;
-  const void* prefetch = nullptr;  // hint: bytes the next launch will stream
-  size_t prefetch_bytes = 0;
 };
 
 static int run_gemm(const void* x, const void* qweight, const void* scales, const void* qzeros, const Fusion& f, void* y,
@@ -2088,11 +2045,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   if (f.ln_w && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8))))
     return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
-             (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr, (const half_t*)f.ln_w, f.ln_eps, nullptr, nullptr, 0u};
-  if (f.prefetch && f.prefetch_bytes >= 128) {
-    a.pf = (const unsigned*)f.prefetch;
-    a.pf_lines = (unsigned)std::min<size_t>(f.prefetch_bytes / 128, 0x7fffffffu);
-  }
+             (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr, (const half_t*)f.ln_w, f.ln_eps};
   // (phase stamps: the LAST 2 MiB of the workspace, behind whatever a K split needs)
   if (p.ablate >= 16 && workspace && workspace_bytes >= (size_t)4096 * 8 * 64 + workspace_need(p))
     a.dbg = (unsigned long long*)((char*)workspace + workspace_bytes - (size_t)4096 * 8 * 64);
@@ -2201,8 +2154,6 @@ int quick_w4a16_gemm_f16_fused(const void* x, const void* qweight, const void* s
     f.ln_w = fusion->rmsnorm_weight;
     f.ln_eps = fusion->rmsnorm_eps;
     f.silu_mul = fusion->silu_mul;
-    f.prefetch = fusion->prefetch;
-    f.prefetch_bytes = fusion->prefetch_bytes;
   }
   return run_gemm(x, qweight, scales, qzeros, f, y, workspace, workspace_bytes, M, K, N, group_size, kernel, grid_split_k, L);
 }

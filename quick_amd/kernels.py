@@ -111,12 +111,11 @@ def _check_gemm(in_feats, kernel, scaling_factors, zeros, bias, residual, out, r
 
 
 def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=KERNEL_AUTO, grid_split_k=0, residual=None,
-                 out=None, rmsnorm_weight=None, rmsnorm_eps=1e-5, silu_mul=False, prefetch=None):
+                 out=None, rmsnorm_weight=None, rmsnorm_eps=1e-5, silu_mul=False):
     """y [M, N] fp16 = in_feats [M, K] @ dequant(kernel, scaling_factors, zeros) (+ bias) (+ residual), MI355X-order
     weights.  ``out`` (optional, may be ``residual``) receives the result.  ``rmsnorm_weight`` [K] normalises in_feats on
     the way in (see can_fuse_rmsnorm); ``silu_mul`` treats the output channels as gate/up interleaved in blocks of 8 and
-    returns silu(gate) * up, [M, N/2].  ``prefetch``: a tensor the NEXT launch will stream (its packed weights) -- a hint the
-    small-M kernels use to keep HBM busy through their head and tail; no result depends on it."""
+    returns silu(gate) * up, [M, N/2]."""
     M, K, N, G, out = _check_gemm(in_feats, kernel, scaling_factors, zeros, bias, residual, out, rmsnorm_weight, silu_mul)
     lib = _lib.load()
     if M == 0:
@@ -126,9 +125,7 @@ def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=
         ws = _workspace(in_feats.device, ws_bytes) if ws_bytes else None
         fusion = _lib.GemmFusion(bias.data_ptr() if bias is not None else None,
                                  residual.data_ptr() if residual is not None else None,
-                                 rmsnorm_weight.data_ptr() if rmsnorm_weight is not None else None, rmsnorm_eps, int(silu_mul),
-                                 prefetch.data_ptr() if prefetch is not None else None,
-                                 prefetch.numel() * prefetch.element_size() if prefetch is not None else 0)
+                                 rmsnorm_weight.data_ptr() if rmsnorm_weight is not None else None, rmsnorm_eps, int(silu_mul))
         rc = lib.quick_w4a16_gemm_f16_fused(
             in_feats.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(), ctypes.byref(fusion),
             out.data_ptr(),
@@ -356,7 +353,7 @@ def rope_attention(qkv, cos_table, sin_table, pos, k_cache, v_cache, out, n_head
 
 
 def prefetch(t, workgroups=0, stream=None):
-    """Hint: pull tensor `t` through HBM into the memory-side cache on `stream` (default: the current one); quick_prefetch."""
+    """Measurement aid: pull tensor `t` through HBM into the memory-side cache on `stream` (default: the current one); quick_prefetch."""
     st = _stream() if stream is None else stream.cuda_stream
     rc = _lib.load().quick_prefetch(t.data_ptr(), t.numel() * t.element_size(), workgroups, st)
     if rc != _OK:

@@ -1,7 +1,9 @@
-"""Does pulling the NEXT launch's weights into the memory-side cache on a second stream shorten a chain of small-M GEMMs?
-A chain of L launches over distinct weight sets (> 320 MiB in total, so every set comes from HBM) is captured in a hipGraph
-three ways: plain; with quick_prefetch of set i + 1 on a side stream forked when launch i is enqueued; one set only (the
-cache-resident bound).  Usage: python tools/prefetch_probe.py --shapes 1x4096x4096,1x4096x22016 [--workgroups 64] [--ahead 1]"""
+"""Does pulling the NEXT launch's weights into the memory-side cache shorten a chain of small-M GEMMs?  (It does not: DESIGN.md 8.)
+A chain of L launches over distinct weight sets (> 320 MiB in total, so every set comes from HBM) is captured in a hipGraph: plain;
+one set only (hot: the L2-resident bound); quick_prefetch of set i + 1 on a side stream forked when launch i is enqueued (fork);
+quick_prefetch of set i and then the launch on it, same stream (pair; pfonly = the touch kernels alone).  The in-kernel variant -- one
+extra wave per workgroup touching the next set -- is in the history (commit "Experiment: pulling the next launch's weights ..."),
+its numbers in profiles/r03_prefetch_probe.txt.  Usage: python tools/prefetch_probe.py --shapes 1x4096x4096,1x4096x22016 --workgroups 64,256"""
 import argparse
 import os
 import sys
@@ -20,7 +22,7 @@ def main():
     ap.add_argument("--ahead", type=int, default=1)
     ap.add_argument("--frac", type=float, default=1.0, help="fraction of the next weight matrix to pull")
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--kernel-id", type=int, default=0, help="kernel id of the 'hint' and 'plainid' chains (e.g. 1 | 1 << 22: one persistent slot per CU)")
+    ap.add_argument("--kernel-id", type=int, default=0, help="kernel id of the GEMM launches")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev).manual_seed(7)
@@ -38,22 +40,22 @@ def main():
         def chain(mode, wg):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
+                main = torch.cuda.current_stream()
                 for i in range(L):
                     qw, sc, qz = sets[0] if mode == "hot" else sets[i % n_sets]
+                    if mode == "fork":      # second stream, forked when launch i is enqueued: pull set i + 1
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        side.wait_event(ev)
+                        kernels.prefetch(sets[(i + 1) % n_sets][0], wg, side)
                     if mode in ("pair", "pfonly"):   # same stream: pull set i, then run on it
                         kernels.prefetch(qw, wg)
-                    if mode == "hint":      # the launch itself pulls the next set
-                        kernels.gemm_forward(x, qw, sc, qz, prefetch=sets[(i + 1) % n_sets][0], kernel_id=a.kernel_id)
-                    elif mode == "hint_tiny":   # the extra wave with (almost) nothing to touch: what the ninth wave itself costs
-                        kernels.gemm_forward(x, qw, sc, qz, prefetch=sets[(i + 1) % n_sets][0].view(-1)[:64], kernel_id=a.kernel_id)
-                    elif mode == "hint_hot":    # own stream cache-resident (set 0), cold touches
-                        kernels.gemm_forward(x, *sets[0], prefetch=sets[(i + 1) % n_sets][0], kernel_id=a.kernel_id)
-                    elif mode == "hint_same":   # touch what was touched before: the touches hit
-                        kernels.gemm_forward(x, qw, sc, qz, prefetch=sets[0][0], kernel_id=a.kernel_id)
-                    elif mode == "plainid":
+                    if mode != "pfonly":
                         kernels.gemm_forward(x, qw, sc, qz, kernel_id=a.kernel_id)
-                    elif mode != "pfonly":
-                        kernels.gemm_forward(x, qw, sc, qz)
+                if mode == "fork":
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    main.wait_event(ev)
             return g
 
         line = [f"{shape:>16}"]
@@ -64,10 +66,11 @@ def main():
         with torch.cuda.graph(warm):
             for _ in range(4):
                 wx @ wx
-        modes = [("plain", 0), ("hot", 0), ("hint", 0), ("hint_tiny", 0), ("hint_hot", 0), ("hint_same", 0)]
-        for w in [w for w in a.workgroups.split(",") if w]:
+        modes = [("plain", 0), ("hot", 0)]
+        for w in [int(w) for w in a.workgroups.split(",") if w]:
+            modes.append(("fork", w))
             for dw in (1, 2, 4, 32):
-                modes += [("pfonly", int(w) | (dw << 16)), ("pair", int(w) | (dw << 16))]
+                modes += [("pfonly", w | (dw << 16)), ("pair", w | (dw << 16))]
         for mode, wg in modes:
             g = chain(mode, wg)
             g.replay()
