@@ -202,6 +202,17 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
                                     int head_dim, int cache_len, float scale, void* hip_stream);
 int quick_silu_mul_f16(const void* gate_up, void* y, int rows, int intermediate, void* hip_stream);
 
+/* lm_head of a decode step with the greedy arg-max folded in (the reference: torch linear + max on the fp16 layer AWQ leaves
+ * unquantised, examples/benchmark.py:54-57): h = RMSNorm(x[batch, hidden]) * norm_weight (quick_rmsnorm_f16's rounding; norm_weight
+ * may be null: h = x), logits[b, v] = h[b, :] . weight[v, :] (fp16 [vocab, hidden], fp32 sums, rounded to fp16),
+ * next_token[b] (int64) = the lowest index among the largest fp16 logits.  hidden_out [batch, hidden] and logits [batch, vocab]
+ * are optional outputs (null: not written).  batch <= 4, hidden % 512 == 0, batch * hidden <= 36864; QUICK_ERR_UNSUPPORTED
+ * otherwise (the caller falls back to its GEMM library).  workspace: quick_lm_head_workspace_bytes(batch), any content. */
+size_t quick_lm_head_workspace_bytes(int batch);
+int quick_lm_head_argmax_f16(const void* x, const void* norm_weight, float eps, const void* weight, void* hidden_out, void* logits,
+                             void* next_token, void* workspace, size_t workspace_bytes, int batch, int vocab, int hidden,
+                             void* hip_stream);
+
 /* Measurement aid (tools/prefetch_probe.py): pull [ptr, ptr + bytes) through HBM into the memory-side cache -- one
  * dword read per 128-byte line, results unused -- with `workgroups` (low 16 bits; 0 = 64) workgroups of 256 threads; bits 16..
  * choose the touch density (0 / 1: one dword per line, 2, 4, 32 = every byte).  No library path calls it. */

@@ -33,6 +33,8 @@ _SIGNATURES = {
     "quick_decode_rope_attention_f16": (_I, [_P] * 7 + [_I] * 5 + [ctypes.c_float, _P]),
     "quick_silu_mul_f16": (_I, [_P, _P, _I, _I, _P]),
     "quick_prefetch": (_I, [_P, _Z, _I, _P]),
+    "quick_lm_head_workspace_bytes": (_Z, [_I]),
+    "quick_lm_head_argmax_f16": (_I, [_P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P]),
     "quick_amd_dispatch_floor": (_I, [_I, _P, _P]),
     "quick_repack_cuda_to_mi355x": (_I, [_P] * 6 + [_I, _I, _I, _P]),
     "quick_repack_mi355x_to_cuda": (_I, [_P] * 6 + [_I, _I, _I, _P]),

@@ -503,6 +503,158 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict_
 
 // Touch one dword of every 128-byte line of [p, p + lines * 128): the memory side (Infinity Cache, 256 MiB) keeps what HBM
 // delivered, so a later launch streams these bytes from the cache.  The loads are never used; a wave ends when they have landed.
+// ------------------------------------------------------------------------------------------------
+// lm_head of a decode step: logits[b, v] = h[b, :] . W[v, :] (fp16 weights [V, H], fp32 sums, fp16 logits), h = RMSNorm(x) * nw when
+// nw is given, else x; with the greedy arg-max folded in.  The reference leaves this layer in fp16 (AWQ does not quantise lm_head)
+// and runs torch's linear + max (examples/benchmark.py:54-57); at one token per sequence that is a 262 MB stream (Llama-2-7B) which
+// hipBLASLt moves at 3.1 TB/s -- 85 us of a 1.40 ms step with the arg-max [r01 trace].  Here: every wave streams blocks of four
+// vocabulary rows, 16 bytes per lane and 512-element chunk, one chunk ahead; h sits in LDS (normalised there by every workgroup
+// for itself); fdot2 into fp32; the four sums of a block reduced across the wave by DPP; the arg-max travels as one 64-bit key
+// (order-preserving bits of the fp16 logit, then the complement of the index: the maximum is the largest logit at the lowest
+// index) per wave -> per workgroup -> a second one-workgroup launch.  B <= 4 sequences (B * 16 accumulators).
+__device__ __forceinline__ unsigned long long argmax_key(half_t logit, unsigned idx) {
+  const unsigned bits = __builtin_bit_cast(unsigned, (float)logit);
+  const unsigned k = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);
+  return ((unsigned long long)k << 32) | (0xffffffffu - idx);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {  // sum of the 64 lanes, delivered as a wave-uniform value
+  v = lanes_sum<16>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+}
+
+template <int B>
+__global__ __launch_bounds__(512) void lm_head_kernel(const half_t* __restrict__ x, const half_t* __restrict__ nw, float eps,
+                                                      const half_t* __restrict__ W, int V, int H, half_t* __restrict__ hidden_out,
+                                                      half_t* __restrict__ logits, unsigned long long* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* xs = (half_t*)smem;                                             // [B][H]
+  __shared__ float part[8];
+  __shared__ unsigned long long wbest[8][B];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // h = RMSNorm(x) * nw with quick_rmsnorm_f16's rounding points, or x itself
+  for (int b = 0; b < B; ++b) {
+    const half_t* xr = x + (size_t)b * H;
+    float inv = 1.f;
+    if (nw) {
+      // (the sum of squares in rmsnorm_kernel's own order -- 256 threads, four wave sums -- so that h is that kernel's, bit for bit)
+      float ss = 0.f;
+      if (threadIdx.x < 256) {
+        for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+          const half8_t v = *(const half8_t*)(xr + i);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+        }
+      }
+      ss = wave_sum(ss);
+      __syncthreads();  // (part of the previous row has been read)
+      if (lane == 0) part[wave] = ss;
+      __syncthreads();
+      inv = rsqrtf((part[0] + part[1] + part[2] + part[3]) / H + eps);
+    }
+    for (int i = threadIdx.x * 8; i < H; i += 512 * 8) {
+      half8_t v = *(const half8_t*)(xr + i);
+      if (nw) {
+        const half8_t g = *(const half8_t*)(nw + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (half_t)((half_t)((float)v[j] * inv) * g[j]);
+      }
+      *(half8_t*)(xs + (size_t)b * H + i) = v;
+      if (hidden_out && blockIdx.x == 0) *(half8_t*)(hidden_out + (size_t)b * H + i) = v;
+    }
+  }
+  __syncthreads();
+
+  const int NC = H / 512, nblk = (V + 3) / 4, nwaves = gridDim.x * 8;
+  unsigned long long best[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) best[b] = 0ull;
+  int blk = blockIdx.x * 8 + wave;
+  if (blk < nblk) {
+    const half_t* wl = W + lane * 8;
+    // weight chunks travel one ahead of the one being used, across the wave's blocks (two ahead measured no faster: more registers);
+    // behind the last block the sequence replays that block (loads nobody uses)
+    u32x4 cur[4], nxt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cur[r] = *(const u32x4*)(wl + (size_t)min(blk * 4 + r, V - 1) * H);
+    while (true) {
+      float acc[4][B];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+      const int nblk_next = blk + nwaves < nblk ? blk + nwaves : blk;
+      for (int c = 0; c < NC; ++c) {
+        const bool last = c + 1 == NC;
+        const int lb = last ? nblk_next : blk, lc = last ? 0 : c + 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nxt[r] = *(const u32x4*)(wl + (size_t)min(lb * 4 + r, V - 1) * H + lc * 512);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const u32x4 xv = *(const u32x4*)(xs + (size_t)b * H + c * 512 + lane * 8);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[r][b] = __builtin_amdgcn_fdot2(as_h2(cur[r][i]), as_h2(xv[i]), acc[r][b], false);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cur[r] = nxt[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = blk * 4 + r;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const half_t lg = (half_t)wave_sum_dpp(acc[r][b]);
+          if (row < V) {  // wave-uniform
+            if (logits && lane == 0) logits[(size_t)b * V + row] = lg;
+            const unsigned long long k = argmax_key(lg, (unsigned)row);
+            best[b] = k > best[b] ? k : best[b];
+          }
+        }
+      }
+      if (blk + nwaves >= nblk) break;
+      blk += nwaves;
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) wbest[wave][b] = best[b];
+  }
+  __syncthreads();
+  if (threadIdx.x < B) {
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) m = wbest[w][threadIdx.x] > m ? wbest[w][threadIdx.x] : m;
+    partial[(size_t)blockIdx.x * B + threadIdx.x] = m;
+  }
+}
+
+// the arg-max over the workgroups' keys: one workgroup, thread t takes partial[t], partial[t + 256], ...
+__global__ __launch_bounds__(256) void lm_head_argmax_kernel(const unsigned long long* __restrict__ partial, int nwg, int B, long* __restrict__ out) {
+  __shared__ unsigned long long red[4];
+  for (int b = 0; b < B; ++b) {
+    unsigned long long m = 0ull;
+    for (int i = threadIdx.x; i < nwg; i += 256) m = partial[(size_t)i * B + b] > m ? partial[(size_t)i * B + b] : m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long t = __shfl_xor(m, o);
+      m = t > m ? t : m;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int w = 1; w < 4; ++w) m = red[w] > m ? red[w] : m;
+      out[b] = (long)(0xffffffffu - (unsigned)(m & 0xffffffffu));
+    }
+  }
+}
+
 template <int DW>  // dwords touched per 128-byte line: 1, 2 (one per 64 bytes), 4 (one per 32 bytes); 32 = every byte (16-byte loads)
 __global__ void __launch_bounds__(256) prefetch_kernel(const unsigned* __restrict__ p, size_t lines, unsigned* sink) {
   const size_t stride = (size_t)gridDim.x * 256;
@@ -601,6 +753,43 @@ int quick_silu_mul_f16(const void* gate_up, void* y, int rows, int intermediate,
   const size_t n8 = (size_t)rows * intermediate / 8;
   hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
                      (const half_t*)gate_up, (half_t*)y, intermediate, n8);
+  return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
+}
+
+size_t quick_lm_head_workspace_bytes(int batch) { return (size_t)512 * (batch > 0 ? batch : 1) * 8; }
+
+int quick_lm_head_argmax_f16(const void* x, const void* norm_weight, float eps, const void* weight, void* hidden_out, void* logits,
+                             void* next_token, void* workspace, size_t workspace_bytes, int batch, int vocab, int hidden,
+                             void* hip_stream) {
+  if (!x || !weight || !next_token || !workspace) return QUICK_ERR_INVALID_ARGUMENT;
+  if (batch < 1 || batch > 4 || vocab < 1 || hidden < 512 || hidden % 512 != 0) return QUICK_ERR_UNSUPPORTED;
+  if (workspace_bytes < quick_lm_head_workspace_bytes(batch)) return QUICK_ERR_WORKSPACE;
+  const size_t lds = (size_t)batch * hidden * 2;
+  if (lds > 72 * 1024) return QUICK_ERR_UNSUPPORTED;  // two workgroups per CU
+  const int nblk = (vocab + 3) / 4;
+  const unsigned grid = (unsigned)std::min(512, (nblk + 7) / 8);
+  hipStream_t st = (hipStream_t)hip_stream;
+#define QA_LM(BV)                                                                                                     \
+  do {                                                                                                                \
+    auto kfn = lm_head_kernel<BV>;                                                                                    \
+    static bool attr_set = false;                                                                                     \
+    if (!attr_set) {                                                                                                  \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);             \
+      attr_set = true;                                                                                                \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), (unsigned)lds, st, (const half_t*)x, (const half_t*)norm_weight, eps, \
+                       (const half_t*)weight, vocab, hidden, (half_t*)hidden_out, (half_t*)logits,                    \
+                       (unsigned long long*)workspace);                                                               \
+  } while (0)
+  switch (batch) {
+    case 1: QA_LM(1); break;
+    case 2: QA_LM(2); break;
+    case 3: QA_LM(3); break;
+    default: QA_LM(4); break;
+  }
+#undef QA_LM
+  hipLaunchKernelGGL(lm_head_argmax_kernel, dim3(1), dim3(256), 0, st, (const unsigned long long*)workspace, (int)grid, batch,
+                     (long*)next_token);
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
 }
 

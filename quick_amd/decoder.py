@@ -14,6 +14,8 @@ Differences from the reference's layer wiring, both on the GEMM side of the boun
 """
 from dataclasses import dataclass
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -192,6 +194,9 @@ def decode_step_fused(model: SyntheticDecoder, tok, pos):
             kernels.rmsnorm(x, l["ln2"], out=model._h)
             kernels.gemm_forward(model._h, gu.qweight, gu.scales, gu.qzeros, out=model._act, silu_mul=True)
         _gemm(l["down"], model._act, x, residual=x)
+    if B <= 4 and H % 512 == 0 and B * H <= 36864 and os.environ.get("QUICK_AMD_TORCH_LM_HEAD") != "1":  # (the variable: A/B runs)   # final RMSNorm + fp16 lm_head + greedy arg-max: one weight stream, two launches
+        tok, hidden, _ = kernels.lm_head_argmax(x, model.lm_head, model.norm, want_hidden=True)
+        return tok, hidden
     hidden = kernels.rmsnorm(x, model.norm)
     return (hidden @ model.lm_head.t()).argmax(-1), hidden
 

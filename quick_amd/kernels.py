@@ -352,6 +352,34 @@ def rope_attention(qkv, cos_table, sin_table, pos, k_cache, v_cache, out, n_head
     return out
 
 
+_LM_WS = {}
+
+
+def lm_head_argmax(x, weight, norm_weight=None, eps=1e-5, want_hidden=False, want_logits=False):
+    """Greedy next token of a decode step: argmax(RMSNorm(x) @ weight.T) in two launches (quick_lm_head_argmax_f16); x [B, H] fp16,
+    weight [V, H] fp16, B <= 4.  Returns (next_token [B] int64, hidden [B, H] or None, logits [B, V] or None).  Raises
+    NotImplementedError where the kernel has no build (the caller then runs torch)."""
+    B, H = x.shape
+    V = weight.shape[0]
+    lib = _lib.load()
+    key = (x.device.index, B)
+    if key not in _LM_WS:
+        _LM_WS[key] = torch.empty(lib.quick_lm_head_workspace_bytes(B), dtype=torch.uint8, device=x.device)
+    ws = _LM_WS[key]
+    tok = torch.empty(B, dtype=torch.int64, device=x.device)
+    hidden = torch.empty_like(x) if want_hidden else None
+    logits = torch.empty((B, V), dtype=torch.float16, device=x.device) if want_logits else None
+    rc = lib.quick_lm_head_argmax_f16(x.data_ptr(), norm_weight.data_ptr() if norm_weight is not None else None, eps, weight.data_ptr(),
+                                      hidden.data_ptr() if hidden is not None else None,
+                                      logits.data_ptr() if logits is not None else None, tok.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      B, V, H, _stream())
+    if rc == 4:
+        raise NotImplementedError("quick_lm_head_argmax_f16: batch <= 4, hidden % 512 == 0")
+    if rc != _OK:
+        raise RuntimeError(f"quick_lm_head_argmax_f16 failed ({rc})")
+    return tok, hidden, logits
+
+
 def prefetch(t, workgroups=0, stream=None):
     """Measurement aid: pull tensor `t` through HBM into the memory-side cache on `stream` (default: the current one); quick_prefetch."""
     st = _stream() if stream is None else stream.cuda_stream

@@ -772,6 +772,35 @@ def test_fused_decode_step_matches_torch_glue(qa, device):
             mask[..., ctx + step + 1] = 0
 
 
+@pytest.mark.parametrize("B,V,H,norm", [(1, 32000, 4096, True), (2, 32000, 4096, True), (4, 32000, 4096, False), (3, 777, 1024, True),
+                                          (1, 1000, 512, False), (4, 128256, 8192, True), (1, 5, 512, True)])
+def test_lm_head_argmax_against_torch(qa, device, B, V, H, norm):
+    """Final RMSNorm + fp16 lm_head + greedy arg-max in two launches (quick_lm_head_argmax_f16) against torch: the hidden state bit for
+    bit (quick_rmsnorm_f16's rounding), the logits within fp16 rounding of an fp32 product, the token = the lowest index among the
+    largest of the kernel's own fp16 logits, and that logit within rounding of torch's maximum."""
+    from quick_amd import kernels
+    g = torch.Generator(device=device).manual_seed(V + H + B)
+    x = torch.randn(B, H, device=device, generator=g).half()
+    w = (torch.randn(V, H, device=device, generator=g) * 0.02).half()
+    nw = (1 + 0.1 * torch.randn(H, device=device, generator=g)).half() if norm else None
+    tok, hidden, logits = kernels.lm_head_argmax(x, w, nw, want_hidden=True, want_logits=True)
+    torch.cuda.synchronize()
+    h_ref = kernels.rmsnorm(x, nw) if norm else x
+    assert torch.equal(hidden, h_ref)
+    ref = h_ref.float() @ w.float().t()
+    torch.testing.assert_close(logits.float(), ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    for b in range(B):
+        top = logits[b].max()
+        first = int((logits[b] == top).nonzero()[0])
+        assert int(tok[b]) == first, (b, int(tok[b]), first)
+        assert abs(float(top) - float(ref[b].max())) <= 2e-3 * float(ref[b].abs().max()) + 1e-3
+    # without the optional outputs: same token
+    tok2, h2, l2 = kernels.lm_head_argmax(x, w, nw)
+    assert h2 is None and l2 is None and torch.equal(tok2, tok)
+    with pytest.raises(NotImplementedError):
+        kernels.lm_head_argmax(torch.zeros(5, H, device=device, dtype=torch.float16), w, nw)
+
+
 def _torch_decode_hidden(model, tok, pos, mask):
     """SyntheticDecoder.forward for T = 1, returning the final normed hidden state instead of the argmax."""
     import torch.nn.functional as F
