@@ -19,6 +19,10 @@ timeout 120 python tools/xk_phases.py --kernel $(v 4 4) 256x4096x4096
 timeout 120 python tools/xk_phases.py --kernel $(v 2 8) 64x4096x4096
 echo "# 128 x 128 tile, two slices, 512 x 4096 x 4096: timing experiments (results wrong on purpose)"
 for a in 17 18 19 21 22 24 20; do timeout 120 python tools/xk_phases.py --abl $a 512x4096x4096; done
-for e in 80 72 88 320 576 336 16720 192 1088 4160 8256; do timeout 120 python tools/xk_phases.py --env-abl $e 512x4096x4096; done
+for e in 80 72 88 320 576 336 16720 192 1088 4160 4672 8256; do timeout 120 python tools/xk_phases.py --env-abl $e 512x4096x4096; done
+echo "# the twelve-wave flavour (loader waves bring x and weights; kernel bit 12, tools builds): correct results"
+timeout 120 python tools/xk_phases.py --kernel $(( $(v 4 2) | (1 << 12) )) 512x4096x4096
+timeout 120 python tools/xk_phases.py --kernel $(( $(v 2 1) | (1 << 12) )) 512x4096x4096
 ) 2>&1 | grep -v amdgpu.ids > $out/xk_anatomy.txt
+timeout 300 python tools/time_lm_head.py > $out/lm_head.txt 2>&1
 tail -30 gpurun_out/r03_round.log
