@@ -109,6 +109,10 @@ size_t quick_w4a16_workspace_bytes(int M, int K, int N, int group_size, int spli
  *   bits 26-28  SKINNY: 26 force the table deferred-zero path, 28 no fragment deferred-zero path; TILED: 27 force 128 x 256
  *               four-wave tiles; XK: weight queue depth in stages (3..6)
  *   bits 29-30  TILED: force / forbid 256-channel tiles
+ * Environment: QUICK_AMD_EXCHANGE_CUS=<n> -- the K slices of an XK launch run on different compute units AT THE SAME TIME and poll each
+ * other's mailboxes, so tiles x slices workgroups must be co-resident; the planner counts on the device's CU count.  A process whose
+ * queues see fewer CUs (a CU mask) sets this to that number (0: never split K this way); otherwise such a launch would spin until
+ * its poll limit traps.
  * A combination the library has no build for returns QUICK_ERR_UNSUPPORTED; results never depend on the field
  * beyond fp32 summation order (and bit 25's rounding). */
 int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scales, const void* qzeros,

@@ -1286,6 +1286,17 @@ static size_t skinny_lds_bytes(int M, int G, int ntw, int waves, int kt_per_spli
 }
 
 // compute units of the current device (256 on MI355X); 256 when there is no device to ask (plan_describe on a CPU-only host)
+static int cu_count();
+// CUs the K slices of an exchange-K launch may count on being CO-RESIDENT.  The slices of a tile poll each other's mailboxes: a launch
+// whose workgroups cannot all run at once (a CU mask on the queue, CUs reserved by the runtime) would spin until the poll limit traps.
+// The device attribute does not see such masks; QUICK_AMD_EXCHANGE_CUS=<n> tells the planner (0: never split K across CUs that way).
+static int exchange_cus() {
+  static const int env = [] {
+    const char* e = getenv("QUICK_AMD_EXCHANGE_CUS");
+    return e && *e ? std::max(0, atoi(e)) : -1;
+  }();
+  return env >= 0 ? std::min(env, cu_count()) : cu_count();
+}
 static int cu_count() {
   static thread_local int cached_dev = -2, cached = 256;
   int dev = -1;
@@ -1444,7 +1455,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // (512 x 4096 x 4096 22.6 against 23.8 us); 128-token tiles with 2 / 4 slices: 384 x 11008 x 4096 1.16x, 640 x 4096 x 4096 1.12x.
     if (best > 0 && allow_xk) {
       static const double xc[2][6] = {{1.728, 0.3869, 0.1572, 2.320, 0.1693, 2.064}, {3.422, 0.4881, 0.3847, 1.214, 0.4284, 2.382}};
-      const int cus = cu_count();
+      const int cus = exchange_cus();
       for (int c = 0; c < 2; ++c) {
         const int mb = c == 0 ? 2 : 4;
         const long T = (long)((M + mb * 32 - 1) / (mb * 32)) * (N / 128);
@@ -1476,7 +1487,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   if (allow_xk && family == QUICK_KERNEL_AUTO && p.kernel == QUICK_KERNEL_TILED && G % 128 == 0 && M > 32 && M <= 64 && !mt_req && !waves_req) {
     const long T = N / 128;
     int sx = 1;
-    while (sx < 8 && T * sx * 2 <= 256 && KT / (sx * 2) >= 4) sx *= 2;
+    while (sx < 8 && T * sx * 2 <= std::min(256, exchange_cus()) && KT / (sx * 2) >= 4) sx *= 2;
     while (sx > 1 && (KT + (KT + sx - 1) / sx - 1) / ((KT + sx - 1) / sx) != sx) sx /= 2;
     if (T * sx >= 160 && T * sx <= cu_count() && KT / sx >= 8) {
       p.kernel = QUICK_KERNEL_XK;
@@ -1495,7 +1506,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // bits 4-7: mb (2, 4; 0 = by M), bits 8-11: S (1, 2, 4, 8; 0 = as many as fit), bits 22-24: x ring slots, bits 26-28: weight queue depth
     const int mb = xk_auto_mb ? xk_auto_mb : ((mt_req == 2 || mt_req == 4) ? mt_req : (M > 64 ? 4 : 2));
     const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / 128;
-    const int cus = cu_count();
+    const int cus = exchange_cus();
     p.wide_mb = mb;
     p.wide_pairs = 1;
     p.tch = 128;

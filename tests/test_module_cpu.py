@@ -159,6 +159,25 @@ def test_product_library_has_no_timing_experiments():
         assert not bad, bad[:5]
 
 
+def test_exchange_cus_override_keeps_k_slices_on_one_cu():
+    """QUICK_AMD_EXCHANGE_CUS tells the planner how many CUs the K slices of an exchange-K launch may count on being co-resident
+    (a CU mask the device attribute does not show); 0 = never split K across CUs that way.  Read once per process: subprocesses."""
+    import subprocess
+    import sys
+    code = ("from quick_amd import kernels; print(kernels.plan_describe(65, 4096, 4096, 128)); "
+            "print(kernels.plan_describe(512, 4096, 4096, 128, kernel_id=4 | (4 << 4) | (2 << 8)))")
+    def run(env):
+        e = dict(os.environ, **env)
+        return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=e).stdout.strip().splitlines()[-2:]
+    auto, forced = run({})
+    assert "slices=4" in auto and "slices=2" in forced
+    for cus in ("0", "100"):          # 64 tiles of 64 tokens / 128 tiles of 128 tokens: two slices each do not fit 100 CUs
+        auto, forced = run({"QUICK_AMD_EXCHANGE_CUS": cus})
+        assert "slices=4" not in auto and "slices=2" not in auto and "slices=1" in forced, (cus, auto, forced)
+    auto, forced = run({"QUICK_AMD_EXCHANGE_CUS": "128"})      # 64 tiles x 2 slices fit, 128 tiles x 2 do not
+    assert auto.startswith("xk") and "slices=2" in auto and "slices=1" in forced
+
+
 def test_plan_describe_pins_the_shape_heuristics():
     """quick_w4a16_plan_describe is host-only; the expectations are the r01 measurements quoted in make_plan()."""
     from quick_amd import kernels
