@@ -1253,6 +1253,7 @@ struct Plan {
   bool mfma32; // tiled: v_mfma_f32_32x32x16_f16 flavour (kernel bit 13; measured slower than 16x16x32 in r01)
   int xk_nbuf, xk_wd;  // exchange-K: x ring slots, weight queue depth (wide_mb = token tiles of 32, ksplit = slices that exchange)
   bool xk_loader;      // exchange-K: the twelve-wave flavour (four loader waves; kernel bit 12)
+  int xk_kq;           // exchange-K: K groups of waves per workgroup, 2 (eight waves) or 4 (sixteen; kernel bit 13)
 };
 
 // Where the main kernel goes: the stream, plus an optional event pair bound to that one dispatch
@@ -1520,13 +1521,22 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       if (s_req == 15 && s > 1) s /= 2;  // (tuning sweeps: half the count the rule gives)
     }
     // (the slices must fit the chip, and ceil-dividing K must give exactly S non-empty slices)
-    while (s > 1 && ((long)p.ntiles * s > cus || (KT + (KT + s - 1) / s - 1) / ((KT + s - 1) / s) != s)) s /= 2;
+    // 64-token tiles with K slices need <= 128 registers and 80 KiB of LDS: TWO workgroups are resident per CU (four waves per SIMD)
+    // (tools builds, forced slice counts: measured slower than one slice on one CU -- 512 x 4096 x 4096 25.8 against 22.8 us)
+#ifdef QUICK_AMD_TOOLS
+    const long cap = mb == 2 ? 2L * cus : cus;
+#else
+    const long cap = cus;
+#endif
+    while (s > 1 && ((long)p.ntiles * s > ((s_req == 2 || s_req == 4 || s_req == 8) ? cap : (long)cus) || (KT + (KT + s - 1) / s - 1) / ((KT + s - 1) / s) != s)) s /= 2;
     p.ksplit = s;
     p.kt_per_split = (KT + s - 1) / s;
     const int nb_req = (kernel >> 22) & 7, wd_req = (kernel >> 26) & 7;
     p.xk_nbuf = nb_req >= 3 ? nb_req : 5;
     p.xk_wd = wd_req >= 3 ? wd_req : 4;
     p.xk_loader = ((kernel >> 12) & 1) != 0;
+    // sixteen waves (bit 13): 64-token tiles with ONE slice whose K range is a whole number of 256-k stages
+    p.xk_kq = (((kernel >> 13) & 1) && mb == 2 && s == 1 && KT % 2 == 0 && KT >= 4 && p.xk_nbuf == 5 && p.xk_wd == 4 && !p.xk_loader) ? 4 : 2;
     const int groups = 8 / s;  // XCDs per K slice: they form a gm x gn grid over the (token, channel) tiles
     long best = -1;
     if (!((kernel >> 14) & 1) && ((long)p.ntiles * s) % 8 == 0)
@@ -2046,8 +2056,8 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
 #ifndef QUICK_AMD_TOOLS
   if ((kernel >> 16) & 31)  // the timing-experiment builds (wrong results on purpose, phase stamps) are not in the product library
     return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: bits 16-20 select timing experiments that only a QUICK_AMD_TOOLS build contains", kernel);
-  if ((kernel & 15) == QUICK_KERNEL_XK && ((kernel >> 12) & 1))  // the twelve-wave (loader waves) flavour: measured level with the eight-wave one, DESIGN.md 5.9
-    return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: the loader-wave flavour of the exchange-K kernels is only in a QUICK_AMD_TOOLS build", kernel);
+  if ((kernel & 15) == QUICK_KERNEL_XK && ((kernel >> 12) & 3))  // the twelve-wave (loader waves, bit 12) and sixteen-wave (bit 13) flavours: measured level with the eight-wave one, DESIGN.md 5.9
+    return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: the loader-wave / sixteen-wave flavours of the exchange-K kernels are only in a QUICK_AMD_TOOLS build", kernel);
 #endif
   if (!x || !qweight || !scales || !qzeros || !y) return fail(QUICK_ERR_INVALID_ARGUMENT, "null tensor pointer");
   const Plan p = plan_for(M, K, N, G, kernel, grid_split_k, f.silu_mul != 0);
@@ -2082,7 +2092,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     if (p.ablate)  // (experiments whose bits do not fit the kernel id: the ABL value itself, tools/xk_phases.py --env-abl)
       if (const char* e = getenv("QUICK_XK_ABL")) abl = atoi(e) == 0 && a.span ? 32 : atoi(e);
 #endif
-    if (!xk_launch(XkConfig{p.wide_mb, p.ksplit, p.xk_nbuf, p.xk_wd, abl, p.xk_loader ? 1 : 0}, a, p.ntiles * p.ksplit, L.st, L.start, L.stop)) {
+    if (!xk_launch(XkConfig{p.wide_mb, p.ksplit, p.xk_nbuf, p.xk_wd, abl, p.xk_kq, p.xk_loader ? 1 : 0}, a, p.ntiles * p.ksplit, L.st, L.start, L.stop)) {
       if (abl == 32) {
         g_span_unsupported = true;
         return fail(QUICK_ERR_UNSUPPORTED, "no span-stamped build of the kernel this shape runs");
@@ -2188,7 +2198,7 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
              (M + 15) / 16, p.ksplit, p.ksplit, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_XK)
     snprintf(text, text_bytes, "xk tokens=%d channels=128 waves=%d ring=%d queue=%d grid=%d slices=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
-             p.xk_loader ? 12 : 8, p.xk_loader ? 3 : p.xk_nbuf, p.xk_loader ? 5 : p.xk_wd, p.ntiles * p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
+             p.xk_loader ? 12 : (p.xk_kq == 4 ? 16 : 8), p.xk_loader ? 3 : p.xk_nbuf, p.xk_loader ? 5 : p.xk_wd, p.ntiles * p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_WIDE)
     snprintf(text, text_bytes, "wide tokens=%d channels=%d waves=%d ring=%d grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
              p.tch, p.waves, p.wide_nbuf, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));

@@ -14,15 +14,15 @@ static_assert(kXkZoneBytesHost == kXkZoneBytes, "exchange zone size");
 
 XkConfig xk_default_config(int mb, int s) { return XkConfig{mb, s, 5, 4, 0}; }
 
-template <int MB, int NBUF, int WD, int S, int ABL = 0>
+template <int MB, int NBUF, int WD, int S, int ABL = 0, int KQ = 2>
 static bool xk_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
-  constexpr unsigned lds = NBUF * MB * 8192;
-  const dim3 grid(workgroups), block((ABL & 4096) ? 768 : 512);
+  constexpr unsigned lds = NBUF * MB * 8192 * (KQ / 2);
+  const dim3 grid(workgroups), block(KQ == 4 ? 1024 : ((ABL & 4096) ? 768 : 512));
   const int gm = a.G == 128 ? 0 : (a.G % 128 == 0 ? 1 : -1);
   if (gm < 0) return false;
 #define QA_XK_K(GMV)                                                                                               \
   do {                                                                                                             \
-    auto kfn = w4a16_xk_kernel<MB, GMV, NBUF, WD, S, ABL>;                                                         \
+    auto kfn = w4a16_xk_kernel<MB, GMV, NBUF, WD, S, ABL, KQ>;                                                     \
     static bool attr_set = false;                                                                                  \
     if (!attr_set) {                                                                                               \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
@@ -108,6 +108,16 @@ bool xk_launch(const XkConfig& c, const GemmArgs& a, int workgroups, hipStream_t
 #endif
     return false;
   }
+  if (c.kq == 4) {  // sixteen waves, four per SIMD (an experiment the product library does not carry: level with eight waves)
+#ifdef QUICK_AMD_TOOLS
+    if (c.mb != 2 || c.s != 1 || c.nbuf != 5 || c.wd != 4) return false;
+    if (c.abl == 0) return xk_go<2, 5, 4, 1, 0, 4>(a, workgroups, st, start, stop);
+    if (c.abl == 32) return xk_go<2, 5, 4, 1, 32, 4>(a, workgroups, st, start, stop);
+    if (c.abl == 64) return xk_go<2, 5, 4, 1, 64, 4>(a, workgroups, st, start, stop);
+    if (c.abl == 262208) return xk_go<2, 5, 4, 1, 262208, 4>(a, workgroups, st, start, stop);  // the two halves in step (no skew)
+#endif
+    return false;
+  }
   const int key = c.mb * 100 + c.nbuf * 10 + c.wd;
 #ifdef QUICK_AMD_TOOLS
   if (c.abl) {  // timing experiments (tools builds): phase stamps, and the launch without the cross-CU exchange (wrong results)
@@ -140,6 +150,11 @@ bool xk_launch(const XkConfig& c, const GemmArgs& a, int workgroups, hipStream_t
     if (key == 254 && c.s == 1 && c.abl == 65600) return xk_go<2, 5, 4, 1, 65600>(a, workgroups, st, start, stop);
     if (key == 454 && c.s == 2 && c.abl == 65536) return xk_go<4, 5, 4, 2, 65536>(a, workgroups, st, start, stop);
     if (key == 454 && c.s == 2 && c.abl == 65600) return xk_go<4, 5, 4, 2, 65600>(a, workgroups, st, start, stop);
+    if (key == 254 && c.s == 1 && c.abl == 131072) return xk_go<2, 5, 4, 1, 131072>(a, workgroups, st, start, stop);  // <= 128 registers: two workgroups per CU
+    if (key == 254 && c.s == 1 && c.abl == 131136) return xk_go<2, 5, 4, 1, 131136>(a, workgroups, st, start, stop);
+    if (key == 244 && c.s == 1 && c.abl == 131072) return xk_go<2, 4, 4, 1, 131072>(a, workgroups, st, start, stop);
+    if (key == 244 && c.s == 1 && c.abl == 131136) return xk_go<2, 4, 4, 1, 131136>(a, workgroups, st, start, stop);
+    if (key == 244 && c.s == 1 && c.abl == 64) return xk_go<2, 4, 4, 1, 64>(a, workgroups, st, start, stop);
     if (key == 254 && c.s == 1 && c.abl == 32768) return xk_go<2, 5, 4, 1, 32768>(a, workgroups, st, start, stop);  // write-through y stores
     if (key == 254 && c.s == 1 && c.abl == 64) return xk_go<2, 5, 4, 1, 64>(a, workgroups, st, start, stop);
     if (key == 454 && c.s == 4 && c.abl == 64) return xk_go<4, 5, 4, 4, 64>(a, workgroups, st, start, stop);

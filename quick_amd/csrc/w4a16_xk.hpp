@@ -487,15 +487,114 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
   }
 }
 
+// Way out of the sixteen-wave kernel (64 x 128 tile, one slice, K quarters wk = 0 .. 3 per channel quarter wn).  A wave holds two
+// 32-token blocks x 16 registers of partial sums = 8 quads (block j, quad c); quad (j, c) is FINISHED by wave wk' = 2 j + c / 2 of the
+// same channel quarter, which adds the four partials in K order.  Then the f16 image of the tile in LDS and whole rows out, as in
+// xk_way_out.  Token of (j, rho): m0 + 32 j + rho; channels of quad c: 128 nb + 32 wn + 8 c + 4 h + (0 .. 3).
+template <int ABL>
+__device__ __forceinline__ void xk_way_out16(const GemmArgs& a, const XkTile& t, floatx16 (&acc)[1][2], char* smem, int lane, int wave, int wn, int wk,
+                                             int rho, int h, unsigned long long (&ph)[6]) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the replayed loads of the last stages)
+  __builtin_amdgcn_s_barrier();                     // the ring is free
+  floatx4* ex = (floatx4*)smem;                     // inbox [wave (wn, owner)][source slot 0 .. 2][quad 0 .. 1][lane]
+  auto quad = [&](int j, int c) { const floatx16& v = acc[0][j]; return floatx4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]}; };
+  float fin[8];
+  auto reduce = [&](auto wkc) __attribute__((always_inline)) {
+    constexpr int WK = decltype(wkc)::value;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {  // send the two quads owner o finishes
+      if (o == WK) continue;
+      floatx4* out = ex + (size_t)(((wn + 4 * o) * 3 + (WK < o ? WK : WK - 1)) * 2) * 64 + lane;
+      out[0] = quad(o >> 1, 2 * (o & 1));
+      out[64] = quad(o >> 1, 2 * (o & 1) + 1);
+    }
+    __syncthreads();
+    const floatx4* in = ex + (size_t)((wave * 3) * 2) * 64 + lane;
+    const floatx4 own0 = quad(WK >> 1, 2 * (WK & 1)), own1 = quad(WK >> 1, 2 * (WK & 1) + 1);
+    floatx4 s0, s1;
+#pragma unroll
+    for (int src = 0; src < 4; ++src) {  // K order, the own partial at position WK
+      const floatx4 v0 = src == WK ? own0 : in[((src < WK ? src : src - 1) * 2) * 64];
+      const floatx4 v1 = src == WK ? own1 : in[((src < WK ? src : src - 1) * 2 + 1) * 64];
+      if (src == 0) { s0 = v0; s1 = v1; }
+      else { s0 += v0; s1 += v1; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { fin[r] = s0[r]; fin[4 + r] = s1[r]; }
+  };
+  if (wk == 0) reduce(xk_ic<0>{});
+  else if (wk == 1) reduce(xk_ic<1>{});
+  else if (wk == 2) reduce(xk_ic<2>{});
+  else reduce(xk_ic<3>{});
+  if constexpr (ABL & 64) ph[3] = ph[4] = __builtin_amdgcn_s_memrealtime();
+  const int j = wk >> 1, c0 = 2 * (wk & 1);
+  __syncthreads();  // (the inboxes have been read)
+  auto image = [&](auto siluc) __attribute__((always_inline)) {
+    constexpr bool SILU = decltype(siluc)::value != 0;
+    constexpr int CPR = SILU ? 8 : 16;
+    const unsigned r7 = (unsigned)rho & 7u;
+    char* wrow = smem + (j * 32 + rho) * (CPR * 16) + h * 8;
+    if constexpr (SILU) {
+      half4_t o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = silu_mul_f16((half_t)fin[r], (half_t)fin[4 + r]);
+      const unsigned q = (unsigned)wn * 2 + (unsigned)(c0 >> 1);
+      *(half4_t*)(wrow + ((q ^ r7) << 4)) = o;
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c = c0 + cc;
+        half4_t bv = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        if (a.bias) bv = *(const half4_t*)(a.bias + t.nb * 128 + wn * 32 + 8 * c + 4 * h);
+        half4_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)(fin[4 * cc + r] + (float)bv[r]);
+        const unsigned q = (unsigned)wn * 4 + (unsigned)c;
+        *(half4_t*)(wrow + ((q ^ r7) << 4)) = o;
+      }
+    }
+    __syncthreads();
+    const int ldy = SILU ? a.N >> 1 : a.N;
+    const int q = (int)threadIdx.x % CPR;
+    const unsigned ycol0 = (unsigned)((SILU ? t.nb * 64 : t.nb * 128) + q * 8);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.Y, 0, (unsigned)((size_t)a.M * ldy * 2), 0x00020000);
+    const half_t* rcol = (!SILU && a.residual) ? a.residual + t.nb * 128 + q * 8 : nullptr;
+    constexpr int RPI = 1024 / CPR;  // rows per pass of the workgroup: 64 (one pass) or 128 (half the threads)
+    const int lr = (int)threadIdx.x / CPR;
+    if (lr < 64) {
+      half8_t v = *(const half8_t*)(smem + (lr * CPR + (q ^ (lr & 7))) * 16);
+      const int m = t.m0 + lr;
+      if (m < a.M) {
+        if (rcol) {
+          const half8_t res = *(const half8_t*)(rcol + (size_t)m * a.N);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = (half_t)((float)v[r] + (float)res[r]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, (unsigned)(((size_t)m * ldy + ycol0) * 2), 0, /*sc1*/ 16);
+      }
+    }
+    (void)RPI;
+  };
+  if (a.silu_mul) image(xk_ic<1>{});
+  else image(xk_ic<0>{});
+}
+
 // ABL (tools builds only): 64 = s_memrealtime stamps at the phase boundaries of every wave into a.dbg; 4 = no cross-CU exchange (the
 // own part is finished without the other slices: wrong results, the launch minus the exchange); 1 / 2 / 8 / 16 as in wide_compute (no
 // compute / no loads in the K loop / no dequantisation / no B-fragment reads); 32 = no barrier in the K loop; 128 = no counted wait at the
 // end of a stage; 256 / 512 = no x pieces / no weight loads in the K loop; 1024 = one x piece with every unit instead of two with two.
-template <int MB, int GM, int NBUF, int WD, int S, int ABL = 0>
-__global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(const GemmArgs a) {
-  constexpr int NW = 8, NG = 1;
+// KQ = 4 (64-token tiles, one slice): SIXTEEN waves = 4 (N) x 4 (K) -- four waves per SIMD.  A stage is 256 k: waves 0-7 run the
+// first 128 k of it exactly as the eight-wave kernel runs a stage (same pieces, same weight loads, same counted waits), waves 8-15
+// the second 128 k in the other half of the slot; one barrier per stage for all sixteen; the four K quarters of a channel quarter
+// are summed through LDS on the way out.  [r03: two co-resident eight-wave workgroups per CU (tools build, <= 128 registers) run a
+// 64 x 128 x 4096 tile in 24.4 k clocks each-equivalent where one alone takes 33.8 k -- scripts/gpu_occ.sh]
+template <int MB, int GM, int NBUF, int WD, int S, int ABL = 0, int KQ = 2>
+__global__ __launch_bounds__(KQ == 4 ? 1024 : ((ABL & 4096) ? 768 : 512), (KQ == 4 || (ABL & 131072)) ? 4 : 1) void w4a16_xk_kernel(const GemmArgs a) {  // (131072, tools: <= 128 registers, two workgroups per CU)
+  constexpr int KH = KQ / 2;   // 128-k halves of a stage
+  constexpr int NW = 4 * KQ, NG = 1;
+  static_assert(KQ == 2 || (KQ == 4 && MB == 2 && S == 1 && !(ABL & 4096)), "sixteen waves: 64-token tiles, one slice");
   constexpr bool LD = (ABL & 4096) != 0;  // experiment: four extra LOADER waves issue every x piece, the eight compute waves only their weights
-  constexpr int SLOT = MB * 8192;
+  constexpr int SLOT = MB * 8192 * KH;
   constexpr int XI = MB;       // x LDS-DMA instructions per wave and stage (MB * 32 rows / (8 waves * 4 rows))
   constexpr int L = XI + 2;    // vector-memory instructions per wave and stage (+ weights, + (scale, zero) word)
   constexpr int NU = 4;        // units (k16 steps of this wave's parity) per stage
@@ -511,14 +610,18 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
   if constexpr (ABL & 64) ph[0] = __builtin_amdgcn_s_memrealtime();
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
-  const int wn = wave & 3, wk = wave >> 2;
+  const int wn = wave & 3, wk = wave >> 2;   // wk: K parity (bit 0) and, with sixteen waves, the 128-k half of the stage (bit 1)
+  const int wave8 = wave & 7, half = wave >> 3;
   const int rho = lane & 31, h = lane >> 5;
-  const XkTile t = xk_tile<MB, S>(a);
+  XkTile t = xk_tile<MB, S>(a);
   const int ct0 = (t.nb * 4 + wn) * 2;
-  const WideBufs<XI> b = wide_bufs<MB, 1, 2>(a, t.m0, ct0, lane, wave);
+  const WideBufs<XI> b = wide_bufs<MB, 1, 2>(a, t.m0, ct0, lane, wave8);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned xdst = lds_base + (unsigned)wave * 1024u;  // + slot + i * 8 KiB
-  const unsigned xrd = (lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4)) ^ ((unsigned)wk << 5);
+  const unsigned xdst = lds_base + (unsigned)wave8 * 1024u + (unsigned)half * (MB * 8192u);  // + slot + i * 8 KiB
+  const unsigned xrd = ((lds_base + (unsigned)rho * 256u + (unsigned)((h ^ (rho & 15)) << 4)) ^ ((unsigned)(wk & 1) << 5)) + (unsigned)half * (MB * 8192u);
+  // k-tile (128 k) of this wave in stage q of the tile's K range; past the end: a replay of the last one (prefetches nobody uses)
+  auto ktof = [&](int q) { return min(t.kt_lo + KH * q + half, t.kt_hi - 1); };
+  if constexpr (KQ == 4) t.nstage /= KH;   // (K % 256 == 0: make_plan)
 
   if constexpr (LD) {
     static_assert(!LD || (NBUF == 5 && MB == 4), "loader experiment: 128-token tiles, five slots");
@@ -556,7 +659,7 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
     }
   }
   auto issue_x = [&](int i, int kt, unsigned slot) {
-    if constexpr (!LD) lds_dma16(b.x, b.x_voff[i], (unsigned)kt * 256u, xdst + slot + i * (NW * 1024));
+    if constexpr (!LD) lds_dma16(b.x, b.x_voff[i], (unsigned)kt * 256u, xdst + slot + i * (8 * 1024));
   };
   auto issue_w = [&](auto jc, int kt) {
     const unsigned g = (unsigned)group_index<GM>(kt, 0, a.tpg, a.G);
@@ -583,11 +686,11 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
   constexpr int PX = UM >= 2 ? 1 : 2;       // x stages the FAST prologue asks for
   constexpr int PER = XI / 2;               // steady state: x pieces with units 1 and 2 (nothing with the last unit of the stage)
   auto x_stage = [&](int q) {               // all pieces of x stage q (q < NBUF: its slot is q)
-    const int kt = min(t.kt_lo + q, t.kt_hi - 1);
+    const int kt = ktof(q);
 #pragma unroll
     for (int i = 0; i < XI; ++i) issue_x(i, kt, (unsigned)q * SLOT);
   };
-  auto pro_w = [&](auto jc) { issue_w(jc, min(t.kt_lo + decltype(jc)::value, t.kt_hi - 1)); };
+  auto pro_w = [&](auto jc) { issue_w(jc, ktof(decltype(jc)::value)); };
   if constexpr (FAST) {
     pro_w(xk_ic<0>{});
     pro_w(xk_ic<1>{});
@@ -630,9 +733,12 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
   unsigned long long seg_wait = 0, seg_bar = 0;
   auto stage = [&](auto jc, int s) __attribute__((always_inline)) {
     constexpr int J = decltype(jc)::value;
-    const int ktx = min(t.kt_lo + s + NBUF - 1, t.kt_hi - 1), ktw = (ABL & 16384) ? t.kt_lo : min(t.kt_lo + s + WD, t.kt_hi - 1);  // (16384: the same, cache-resident weight stage every time)
+    const int ktx = ktof(s + NBUF - 1), ktw = (ABL & 16384) ? t.kt_lo : ktof(s + WD);  // (16384: the same, cache-resident weight stage every time)
     read_w(xk_ic<(J + 1) % WD>{}, wnx);  // W(s + 1): landed since the wait that ended stage s - 1
     wide_compute<MB, 1, GM, (ABL & 27), true, 2>(wc, wnx, xrd + cur, xrd + nxt, dq, acc, carry, [&](int u) {
+      if constexpr (KQ == 4 && !(ABL & 262144)) {
+        if (u == 2) __builtin_amdgcn_s_barrier();  // sixteen waves: the OTHER half's end of stage (see the skew below)
+      }
       if constexpr (!(ABL & 2)) {
         bool first = false;
         if constexpr (J == 0) first = s == 0;
@@ -701,6 +807,13 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
     cur = nxt;
     nxt = nxt + SLOT >= (unsigned)(NBUF * SLOT) ? 0u : nxt + SLOT;
   };
+  // Sixteen waves: the two halves share nothing in the K loop but the workgroup's one barrier.  Run in step, all four waves of a SIMD
+  // reach the end of a stage -- counted wait, barrier, first fragments of the next stage -- together and the matrix pipe idles through
+  // it.  So the second half runs HALF A STAGE behind the first: it starts one barrier late, every wave joins a barrier in the middle
+  // of its stage (the other half's end of stage) and at its own end, and the first half joins one more at the very end.
+  if constexpr (KQ == 4 && !(ABL & 262144)) {
+    if (half) __builtin_amdgcn_s_barrier();
+  }
   for (int base = 0; base < t.nstage; base += WD) {
     stage(xk_ic<0>{}, base);
     if (base + 1 < t.nstage) stage(xk_ic<1>{}, base + 1);
@@ -709,10 +822,14 @@ __global__ __launch_bounds__((ABL & 4096) ? 768 : 512) void w4a16_xk_kernel(cons
     if constexpr (WD > 4) if (base + 4 < t.nstage) stage(xk_ic<4 % WD>{}, base + 4);
     if constexpr (WD > 5) if (base + 5 < t.nstage) stage(xk_ic<5 % WD>{}, base + 5);
   }
+  if constexpr (KQ == 4 && !(ABL & 262144)) {
+    if (!half) __builtin_amdgcn_s_barrier();
+  }
   if (wk) __builtin_amdgcn_s_setprio(0);
   if constexpr (ABL & 64) { ph[2] = __builtin_amdgcn_s_memrealtime(); cyc = __builtin_amdgcn_s_memtime() - cyc; }
 
-  xk_way_out<MB, S, ABL>(a, t, acc, smem, lane, wave, wn, wk, rho, h, ph);
+  if constexpr (KQ == 4) xk_way_out16<ABL>(a, t, acc, smem, lane, wave, wn, wk, rho, h, ph);
+  else xk_way_out<MB, S, ABL>(a, t, acc, smem, lane, wave, wn, wk, rho, h, ph);
   if constexpr (ABL & 32) span_stamp(a.span, 1);
   if constexpr (ABL & 64) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

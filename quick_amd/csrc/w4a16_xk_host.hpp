@@ -12,6 +12,7 @@ struct XkConfig {
   int nbuf;  // x ring slots
   int wd;    // weight queue depth (stages)
   int abl;   // tools builds only: timing experiments / phase stamps
+  int kq = 2;      // K groups of waves inside the workgroup: 2 (eight waves) or 4 (sixteen waves: 64-token tiles, one slice, K % 256 == 0)
   int loader = 0;  // 1: the twelve-wave flavour (four loader waves issue every vector-memory instruction; nbuf / wd do not apply)
 };
 constexpr size_t kXkZoneBytesHost = (size_t)16 << 20;  // == kXkZoneBytes (w4a16_xk.hpp)
