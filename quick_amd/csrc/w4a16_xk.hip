@@ -155,6 +155,9 @@ bool xk_launch(const XkConfig& c, const GemmArgs& a, int workgroups, hipStream_t
     if (key == 244 && c.s == 1 && c.abl == 131072) return xk_go<2, 4, 4, 1, 131072>(a, workgroups, st, start, stop);
     if (key == 244 && c.s == 1 && c.abl == 131136) return xk_go<2, 4, 4, 1, 131136>(a, workgroups, st, start, stop);
     if (key == 244 && c.s == 1 && c.abl == 64) return xk_go<2, 4, 4, 1, 64>(a, workgroups, st, start, stop);
+    if (key == 254 && c.s == 1 && c.abl == 524352) return xk_go<2, 5, 4, 1, 524352>(a, workgroups, st, start, stop);    // a barrier behind every second stage only
+    if (key == 254 && c.s == 1 && c.abl == 1572928) return xk_go<2, 5, 4, 1, 1572928>(a, workgroups, st, start, stop);  // ... every fourth
+    if (key == 454 && c.s == 2 && c.abl == 524352) return xk_go<4, 5, 4, 2, 524352>(a, workgroups, st, start, stop);
     if (key == 254 && c.s == 1 && c.abl == 32768) return xk_go<2, 5, 4, 1, 32768>(a, workgroups, st, start, stop);  // write-through y stores
     if (key == 254 && c.s == 1 && c.abl == 64) return xk_go<2, 5, 4, 1, 64>(a, workgroups, st, start, stop);
     if (key == 454 && c.s == 4 && c.abl == 64) return xk_go<4, 5, 4, 4, 64>(a, workgroups, st, start, stop);

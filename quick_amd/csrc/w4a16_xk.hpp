@@ -796,7 +796,9 @@ __global__ __launch_bounds__(KQ == 4 ? 1024 : ((ABL & 4096) ? 768 : 512), (KQ ==
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");
     }
     if constexpr (ABL & 8192) tq1 = __builtin_amdgcn_s_memtime();
-    if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();  // ... in every wave; everybody is done with x stage s
+    if constexpr (ABL & 524288) {  // (timing experiment, results may be wrong: a barrier only behind every second / fourth stage)
+      if ((s & ((ABL & 1048576) ? 3 : 1)) == 1) __builtin_amdgcn_s_barrier();
+    } else if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();  // ... in every wave; everybody is done with x stage s
     if constexpr (ABL & 8192) {  // (experiment: shader clocks a wave spends in the counted wait / at the barrier, summed over the stages)
       const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
       seg_wait += tq1 - tq0;
