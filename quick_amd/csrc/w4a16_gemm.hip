@@ -1596,10 +1596,16 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     if (!mt_req && M > 8 && M <= 32 && (long)K * N >= 40L * 1000 * 1000) {  // (M = 17..32: 11008 x 4096 16.6 -> 13.5 us)
       // (the table flavour up to M = 12: at M = 16 the 4-tile fragment flavour is ahead, 4096 x 22016 18.3 -> 16.9 us, 4096 x
       // 28672 20.3 -> 19.3 [r02 audit])
+      // [r03 audit on the final kernels, scripts/gpu_small_audit2.sh: as a bare GEMM the table flavour is ahead at M = 16 as well up to
+      // ~120 M weights -- 4096 x 22016 17.0 -> 14.8 us, 4096 x 28672 18.2 -> 16.8; 8192 x 57344 keeps the four tiles.]
+      // Not taken: these layers are the gate_up projections, which carry the RMSNorm prologue in a decode step, and the table flavour
+      // normalises its 16 rows one after the other -- Llama-2-7B / Mistral-7B at batch 16 lost 5-8 % tok/s with it [bench_decode.py].
       const bool dz_ok = mblocks == 1 && M <= 12 && !no_xlds && !((kernel >> 25) & 1) && N / 16 >= 1024 &&
                          skinny_lds_bytes(M, G, 1, 8, KT, true, true, true) <= kLdsPerCu;
       if (!dz_ok) mt_auto = 4;
-    } else if (!mt_req && M >= 6 && M <= 8 && N >= 8192 && N / 16 < 1024 && (size_t)M * (K * 2 + 16) > (size_t)64 * 1024) {
+    } else if (!mt_req && M >= 5 && M <= 8 && N >= 8192 && N / 16 < 1024 && (G % 128 == 0 || (M >= 6 && (size_t)M * (K * 2 + 16) > (size_t)64 * 1024))) {
+      // (r03: with G % 128 == 0 from M = 5 and at any K -- the four-tile kernel then takes its fragments from L2, below: 4096 x 12288
+      // M = 5, 6 8.4-8.6 -> 7.6 us)
       // (only where the 4-tile kernel takes its fragments straight from L2: its LDS-copy flavour is slower, M = 6, 7 at K = 4096)
       mt_auto = 4;  // at M = 8: 4096 x 12288 11.0 -> 10.3 us, 8192 x 10240 18.7 -> 16.6 us, 28672 x 8192 49 -> 34 us; from
     }               // 1024 blocks (4096 x 22016, 8192 x 57344) the deferred-zero path stays ahead, and so it does at M <= 4
@@ -1608,13 +1614,18 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // 6.3 / 7.6 us, 8192 x 8192 M = 6 14.7 -> 10.1, 28672 x 8192 M = 3, 4 33.5 -> 25.4]; large layers keep the 4 tiles from M = 9
     if (!mt_req && mblocks == 1 && N / 16 > 256 && N / 16 <= 512 && G % 128 == 0) {
       if (KT >= 128) mt_auto = M >= 3 ? 4 : mt_auto;  // (a very long K: four tiles and a 2-way K split, 28672 x 8192 M = 3..8 24.8-25.1 us)
-      else if (M >= 4 && M <= 8) mt_auto = 2;
-      else if (M > 8 && (long)K * N < 40L * 1000 * 1000) mt_auto = 2;
+      // [r03 audit, scripts/gpu_small_audit2.sh] up to 320 blocks (N = 5120) four tiles from seven tokens (5120 x 5120 M = 8 .. 16 8.0-9.5 ->
+      // 7.6-8.5 us); above, two tiles up to twelve tokens (8192 x 8192 M = 10 11.8 -> 11.0)
+      else if (N / 16 <= 320) mt_auto = M >= 7 ? 4 : (M >= 4 ? 2 : mt_auto);
+      // (4096 x 6144 keeps two tiles at 13..16 tokens although four with a two-way K split are 2-5 % ahead: the split would cost the
+      // RMSNorm prologue of Mistral's fused qkv a launch)
+      else if (M >= 4 && (M <= 12 || (long)K * N < 40L * 1000 * 1000)) mt_auto = 2;
     }
     // M = 7, 8 with a long K (>= 10240: the x copy is far beyond the 64 KiB LDS budget) where the exact path would take its fragments
     // from L2 once per 16 channels: two tiles per workgroup share them (8 x 11008 x 4096 10.0 -> 9.2 us, 14336 x 4096 12.2 -> 11.4,
     // 18944 x 3584 14.7 -> 13.1; at M = 6 it is a tie) [audits]
-    if (!mt_req && mt_auto == 1 && M >= 7 && M <= 8 && N / 16 <= 256 && G % 128 == 0 && K >= 10240) mt_auto = 2;
+    // (r03 audit: four tiles, 8 x 11008 x 4096 9.3 -> 8.8 us, 8 x 14336 x 4096 11.4 -> 10.3)
+    if (!mt_req && mt_auto == 1 && M >= 7 && M <= 8 && N / 16 <= 256 && G % 128 == 0 && K >= 10240) mt_auto = 4;
     p.mt = mt_req ? mt_req : mt_auto;
     if (p.mt != 1 && p.mt != 2) p.mt = 4;
     while (p.mt > 1 && (N / 16) % p.mt != 0) p.mt /= 2;
@@ -1738,8 +1749,12 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
           p.waves = 16;
       }
     }
+    // [r03 audit on the final kernels, 5..16 tokens x 12 layer shapes, scripts/gpu_small_audit2.sh] From five tokens the copy of x into
+    // LDS loses to fragments straight from L2 wherever the table flavour above does not run: 5 / 6 x 4096 x 4096 5.1 -> 4.4 / 4.7 us,
+    // 5 / 6 x 4096 x 6144 6.6 -> 5.7, 10 x 11008 x 4096 11.9 -> 8.9 (a four-way K split with the copy).  G % 128 == 0 (what was measured).
+    const bool l2_frag = G % 128 == 0 && (M >= 5 || (M == 4 && p.mt >= 2));   // (4 x 4096 x 6144, two tiles: 6.2 -> 5.8 us)
     if (!p.dz && !exact && !((kernel >> 28) & 1) && p.mt >= 2 && G % 128 == 0 &&  // (G < 128: 4 units per tile, spills)
-        (no_xlds || M > 16 || (size_t)std::min(M, 16) * (p.kt_per_split * 256 + 16) > (size_t)64 * 1024)) {
+        (no_xlds || l2_frag || M > 16 || (size_t)std::min(M, 16) * (p.kt_per_split * 256 + 16) > (size_t)64 * 1024)) {
       // fragment flavour of the deferred-zero path: several channel tiles per workgroup, x fragments straight from L2,
       // the unit sums from one extra MFMA per k-step (kernel bit 28 forbids it)
       p.dz = true;
@@ -1747,7 +1762,10 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     } else if (!p.dz) {
       // exact path: x through LDS while the copy is small (64 KiB), else fragments straight from L2; persistent
       // launches measured within +-5 % of one block per workgroup [r01] and are off unless asked for
-      p.xlds = !no_xlds && M <= 16 && (size_t)std::min(M, 16) * (p.kt_per_split * 256 + 16) <= (size_t)64 * 1024;
+      p.xlds = !no_xlds && !l2_frag && M <= 16 && (size_t)std::min(M, 16) * (p.kt_per_split * 256 + 16) <= (size_t)64 * 1024;
+      // ... and a one-tile launch with a short K runs sixteen waves (twice the loads in flight per CU; K = 4096: M = 5 .. 16 4.4-5.9 ->
+      // 4.3-5.9 us, 3-5 % at 6..12 tokens; at K = 11008 eight waves stay ahead)
+      if (l2_frag && !waves_req && p.mt == 1 && p.ksplit == 1 && KT <= 32 && mblocks == 1) p.waves = 16;
       const int slots = std::max(1, 256 * (cu_req ? cu_req : 2) / mblocks);
       if (p.xlds && (flip || cu_req) && p.ksplit == 1 && nblocks > slots) {  // the fragments-from-L2 variants cannot
         const int rounds = (nblocks + slots - 1) / slots;

@@ -236,6 +236,10 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(16, 4096, 6144).startswith("skinny ntw=2") and "deferred-zero-fragment" in plan(16, 4096, 6144)    # 384 blocks: one round of 192
     assert plan(6, 8192, 8192).startswith("skinny ntw=2") and plan(4, 28672, 8192).startswith("skinny ntw=4")
     assert "deferred-zero-table" in plan(12, 4096, 22016) and plan(16, 4096, 22016).startswith("skinny ntw=4")
+    assert plan(16, 8192, 57344).startswith("skinny ntw=4")
+    # r03 audit: from five tokens no LDS copy of x outside the table flavour; one-tile launches with K = 4096 run sixteen waves
+    assert plan(6, 4096, 4096).startswith("skinny ntw=1 waves=16 x=l2 dequant=exact") and "waves=8 x=lds" in plan(4, 4096, 4096)
+    assert plan(6, 4096, 12288).startswith("skinny ntw=4 waves=8 x=l2") and plan(10, 11008, 4096).startswith("skinny ntw=4 waves=8 x=l2")
     # third audit (17..64 tokens, layer shapes the rules were not tuned on): the four-tile skinny kernel by its own geometry
     assert plan(32, 4096, 6144).startswith("skinny ntw=4") and plan(32, 4096, 4096).startswith("skinny ntw=4")    # one round of workgroups, <= 64 stages each
     assert plan(32, 5120, 5120).startswith("skinny ntw=4") and plan(64, 5120, 5120).startswith("xk tokens=64")    # 320 skinny workgroups would be two rounds; r03: 40 tiles x 4 slices
@@ -246,7 +250,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(64, 28672, 8192).startswith("xk tokens=64") and "slices=4" in plan(64, 28672, 8192)               # long K slices fill the chip
     assert "slices=4" in plan(48, 28672, 8192) and "slices=4" in plan(64, 8192, 8192) and "slices=4" in plan(64, 4096, 8192)
     assert "deferred-zero-table" in plan(3, 13824, 5120) and "dequant=exact" in plan(3, 18944, 3584)              # M = 3: the table from 256 channel blocks
-    assert plan(8, 11008, 4096).startswith("skinny ntw=2") and plan(6, 11008, 4096).startswith("skinny ntw=1")    # x too large for LDS: share the L2 fragments
+    assert plan(8, 11008, 4096).startswith("skinny ntw=4") and plan(6, 11008, 4096).startswith("skinny ntw=1")    # x too large for LDS: share the L2 fragments (r03 audit: among four tiles)
     # forcing a family / a split through the kernel id and grid_split_k
     assert plan(512, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny")
     assert "ksplit=4" in plan(64, 4096, 4096, kernel_id=kernels.KERNEL_TILED, grid_split_k=4)
