@@ -1715,7 +1715,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // workgroups -- each walks the channel blocks b, b + grid, ... with the chunk pipeline running across blocks -- so
     // that the x copy and the table are paid once per workgroup.  Slots per CU c in {1, 2} (what LDS allows): two
     // co-resident workgroups finish a block each ~1.6x slower than one alone [r01 sweep], so pick the c with the
-    // smaller rounds(c) * (c == 1 ? 1 : 1.6).  With M > 2 the copy + table only pay off from two blocks per workgroup
+    // smaller rounds(c) * (c == 1 ? 1 : 1.8).  With M > 2 the copy + table only pay off from two blocks per workgroup
     // [r01: N = 4096, M = 8: 7.1 us against 5.4 us exact]; below that the exact path runs.
     p.dz = false;
     const size_t lds_dz = skinny_lds_bytes(M, G, 1, p.waves, p.kt_per_split, true, true, true);
@@ -1723,7 +1723,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     if (!no_xlds && !exact && p.mt == 1 && M <= 16 && fit >= 1) {
       int c = 1;
       if (cu_req) c = std::min(cu_req, 8);
-      else if (fit >= 2 && ((nblocks + 511) / 512) * 1.6 < (double)((nblocks + 255) / 256)) c = 2;
+      // (r03 audit, scripts/gpu_tiny_audit.sh: 1.8 -- 1792 blocks, 4096 x 28672, run 7 rounds of one per CU in 13.1 us against 4 rounds of
+      // two in 13.8 at M = 1 .. 4; 1376 blocks, 4096 x 22016, stay with 3 rounds of two: 10.7 against 11.2)
+      else if (fit >= 2 && ((nblocks + 511) / 512) * 1.8 < (double)((nblocks + 255) / 256)) c = 2;
       int rounds = (nblocks + 256 * c - 1) / (256 * c);
       if (!cu_req && M > 2 && rounds < 2 && c == 2) {
         c = 1;
