@@ -1811,7 +1811,7 @@ static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) 
   const size_t lds = skinny_lds_bytes(a.M, a.G, NTW, WAVES, p.kt_per_split, p.grid_x < a.N / (16 * NTW), XLDS, DZ) + (LN ? 1024 : 0);
   if (a.span) {  // in-kernel span stamps: separate instantiations, for the small-M kernels the BASELINE sweep and the decode shapes run
     constexpr bool stamped = !LN && ((WAVES == 8 && ((NTW == 1 && XLDS && DZ) || (NTW == 1 && !XLDS && !DZ) || (NTW == 4 && !XLDS && DZ))) ||
-                                     (WAVES == 16 && NTW == 1 && XLDS && DZ));
+                                     (WAVES == 16 && NTW == 1 && ((XLDS && DZ) || (!XLDS && !DZ))));
     if constexpr (stamped) {
       if (group_mode(a.G) == 0) {
         auto kfn = w4a16_skinny_kernel<NTW, WAVES, 0, XLDS, DZ, LN, true>;
