@@ -46,6 +46,9 @@ extern "C" {
 #define QUICK_KERNEL_WIDE 3   /* large M: 32x32x16 MFMA, one wave per SIMD, operands by LDS-DMA (G % 128 == 0; else TILED runs) */
 #define QUICK_KERNEL_XK 4     /* 64- / 128-token tiles, eight waves, the K slices of a tile on different CUs exchange partial tiles
                                  (G % 128 == 0; else TILED runs) */
+#define QUICK_KERNEL_XW 5     /* 128 x 256 tiles, four waves of 128 tokens x 64 channels (one per SIMD), hand-placed K loop; 1 / 2 / 4 K slices
+                                 of a tile on different CUs exchange fp16 parts and give up on partners that are not there
+                                 (G / 128 a power of two, N % 256 == 0; else TILED runs) */
 
 int quick_amd_abi_version(void);
 const char* quick_amd_last_error(void);

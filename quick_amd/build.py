@@ -22,8 +22,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libquick_amd.so")
 TOOLS_LIB = os.path.join(LIBDIR, "libquick_amd_tools.so")
-SOURCES = ["w4a16_gemm.hip", "w4a16_xk.hip", "repack.hip", "decode_ops.hip"]
-HEADERS = ["w4a16_common.hpp", "w4a16_args.hpp", "w4a16_wide.hpp", "w4a16_xk.hpp", "w4a16_xk_host.hpp",
+SOURCES = ["w4a16_gemm.hip", "w4a16_xk.hip", "w4a16_xw.hip", "repack.hip", "decode_ops.hip"]
+HEADERS = ["w4a16_common.hpp", "w4a16_args.hpp", "w4a16_wide.hpp", "w4a16_xk.hpp", "w4a16_xk_host.hpp", "w4a16_xw.hpp", "w4a16_xw_host.hpp", "w4a16_xw_loop.inc",
            os.path.join("..", "..", "include", "quick_amd.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"]

@@ -28,6 +28,7 @@
 #include "w4a16_args.hpp"
 #include "w4a16_wide.hpp"
 #include "w4a16_xk_host.hpp"
+#include "w4a16_xw_host.hpp"
 namespace quick_amd {
 
 // ------------------------------------------------------------------------------------------------
@@ -1254,6 +1255,7 @@ struct Plan {
   int xk_nbuf, xk_wd;  // exchange-K: x ring slots, weight queue depth (wide_mb = token tiles of 32, ksplit = slices that exchange)
   bool xk_loader;      // exchange-K: the twelve-wave flavour (four loader waves; kernel bit 12)
   int xk_kq;           // exchange-K: K groups of waves per workgroup, 2 (eight waves) or 4 (sixteen; kernel bit 13)
+  int poll_log2;       // XW: log2 of the ticks (10 ns) a wave waits for a partner slice before it gives its block up (0 = the kernel's default)
 };
 
 // Where the main kernel goes: the stream, plus an optional event pair bound to that one dispatch
@@ -1501,7 +1503,42 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   // tiled kernel (64-bit pointers) runs instead
   if ((p.kernel == QUICK_KERNEL_WIDE || p.kernel == QUICK_KERNEL_XK) && (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32)) p.kernel = QUICK_KERNEL_TILED;
   if (p.kernel == QUICK_KERNEL_XK && (size_t)M * (size_t)N * 2 >= ((size_t)1 << 32)) p.kernel = QUICK_KERNEL_TILED;  // (y through a buffer descriptor as well)
-  if (p.kernel == QUICK_KERNEL_XK) {
+  if (p.kernel == QUICK_KERNEL_XW && (G % 128 != 0 || ((G / 128) & (G / 128 - 1)) != 0 || N % 256 != 0 || (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32) ||
+                                      (size_t)M * (size_t)N * 2 >= ((size_t)1 << 32)))
+    p.kernel = QUICK_KERNEL_TILED;  // (the loop shifts the k tile by log2(G / 128); 256-channel tiles; 32-bit buffer offsets)
+  if (p.kernel == QUICK_KERNEL_XW) {
+    // 128 x 256 tiles, four waves, hand-placed K loop (w4a16_xw.hpp); S = 1, 2, 4 K slices per tile on S compute units.  Nobody has to be
+    // co-resident (a wave that waits too long gives its block up, the last partner finishes it), but the exchange zone holds S * S boxes
+    // of a tile's fp16 image / S per tile: tiles * S <= 256.  bits 8-11: S (0 = as many as fit the CUs); bits 22-26: log2 of the poll
+    // limit in ticks of 10 ns (tests: 1 = every wave gives up at once).
+    const int MBk = (M + 127) / 128, NBk = N / 256;
+    p.wide_mb = 4;
+    p.wide_pairs = 2;
+    p.tch = 256;
+    p.waves = 4;
+    p.ntiles = MBk * NBk;
+    const int s_req = grid_split_k > 0 ? grid_split_k : (kernel >> 8) & 15;
+    int s = 1;
+    if (s_req == 1 || s_req == 2 || s_req == 4) s = s_req;
+    else
+      while (s < 4 && (long)p.ntiles * s * 2 <= cu_count() && KT / (s * 2) >= 4) s *= 2;
+    while (s > 1 && ((long)p.ntiles * s > 256 || (KT + (KT + s - 1) / s - 1) / ((KT + s - 1) / s) != s)) s /= 2;
+    p.ksplit = s;
+    p.kt_per_split = (KT + s - 1) / s;
+    p.poll_log2 = (kernel >> 22) & 31;
+    if (const char* e = getenv("QUICK_AMD_EXCHANGE_POLL_LOG2")) p.poll_log2 = std::max(0, std::min(31, atoi(e)));
+    const int groups = 8 / s;
+    long best = -1;
+    if (!((kernel >> 14) & 1) && ((long)p.ntiles * s) % 8 == 0)
+      for (int gm = 1; gm <= groups; gm *= 2) {
+        if (MBk % gm != 0 || NBk % (groups / gm) != 0) continue;
+        const long cost = (long)(MBk / gm) * 256 + (long)(NBk * gm / groups) * 128;  // bytes per k and XCD: x rows (2 B) + weight columns (1/2 B)
+        if (best < 0 || cost < best) {
+          best = cost;
+          p.xcd_gm = gm;
+        }
+      }
+  } else if (p.kernel == QUICK_KERNEL_XK) {
     // exchange-K kernels (w4a16_xk.hpp): tile = mb * 32 tokens x 128 channels, eight waves; the S slices of a tile run on S compute
     // units at the same time and swap parts of their partial tiles, so S > 1 needs the whole grid co-resident: tiles * S <= CUs.
     // bits 4-7: mb (2, 4; 0 = by M), bits 8-11: S (1, 2, 4, 8; 0 = as many as fit), bits 22-24: x ring slots, bits 26-28: weight queue depth
@@ -1789,7 +1826,7 @@ static size_t counters_bytes(const Plan&) { return (size_t)kMaxSplitTiles * 4; }
 static size_t slabs_offset(const Plan& p) { return counters_bytes(p) + kXkZoneBytesHost; }
 static size_t workspace_need(const Plan& p) {
   if (p.ksplit <= 1) return 0;
-  if (p.kernel == QUICK_KERNEL_XK) return slabs_offset(p);
+  if (p.kernel == QUICK_KERNEL_XK || p.kernel == QUICK_KERNEL_XW) return slabs_offset(p);
   return slabs_offset(p) + (size_t)p.ntiles * p.ksplit * p.slab_floats * sizeof(float);
 }
 
@@ -2044,7 +2081,7 @@ static void launch_wide(const Plan& p, const GemmArgs& a, const Launch& L) {
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
 #ifdef QUICK_AMD_TOOLS
-  if constexpr ((MB == 2 && PAIRS == 1) || (MB == 8 && PAIRS == 2))
+  if constexpr ((MB == 2 && PAIRS == 1) || (MB == 8 && PAIRS == 2) || (MB == 4 && PAIRS == 2))
     if (p.ablate && a.G == 128) {  // timing experiments (results are wrong on purpose)
       auto kfn1 = w4a16_wide_kernel<MB, PAIRS, 0, 1>;
       auto kfn2 = w4a16_wide_kernel<MB, PAIRS, 0, 2>;
@@ -2072,7 +2109,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
                     void* workspace, size_t workspace_bytes, int M, int K, int N, int G, int kernel, int grid_split_k,
                     const Launch& L) {
   if (int rc = check_shapes(M, K, N, G)) return rc;
-  if ((kernel & 15) > QUICK_KERNEL_XK || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+  if ((kernel & 15) > QUICK_KERNEL_XW || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
 #ifndef QUICK_AMD_TOOLS
   if ((kernel >> 16) & 31)  // the timing-experiment builds (wrong results on purpose, phase stamps) are not in the product library
     return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: bits 16-20 select timing experiments that only a QUICK_AMD_TOOLS build contains", kernel);
@@ -2098,9 +2135,22 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     if (!workspace || workspace_bytes < need)
       return fail(QUICK_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     a.counters = (unsigned*)workspace;  // zero on entry (caller's contract), zero again when the launch completes
-    a.slabs = (float*)((char*)workspace + (p.kernel == QUICK_KERNEL_XK ? counters_bytes(p) : slabs_offset(p)));  // (exchange-K: the zone)
+    a.slabs = (float*)((char*)workspace + ((p.kernel == QUICK_KERNEL_XK || p.kernel == QUICK_KERNEL_XW) ? counters_bytes(p) : slabs_offset(p)));  // (exchange-K / XW: the zone)
   }
-  if (p.kernel == QUICK_KERNEL_XK) {
+  if (p.kernel == QUICK_KERNEL_XW) {
+    if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
+    int abl = a.span ? 32 : 0;
+#ifdef QUICK_AMD_TOOLS
+    if (p.ablate == 16) abl = 64;       // phase stamps
+    else if (p.ablate == 20) abl = 68;  // ... and no exchange (wrong results)
+    else if (p.ablate) return fail(QUICK_ERR_INVALID_ARGUMENT, "XW: timing-experiment bits 16 (stamps) and 20 (no exchange) only");
+#endif
+    a.xcd_gm |= p.poll_log2 << 8;  // (the kernel reads the tile-order rows from the low byte)
+    if (!xw_launch(p.ksplit, abl, a, p.ntiles * p.ksplit, L.st, L.start, L.stop)) {
+      if (abl == 32) g_span_unsupported = true;
+      return fail(QUICK_ERR_UNSUPPORTED, "no 128 x 256 four-wave build for slices=%d abl=%d", p.ksplit, abl);
+    }
+  } else if (p.kernel == QUICK_KERNEL_XK) {
     if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
     if (f.silu_mul && !xk_takes_silu(p))
       return fail(QUICK_ERR_UNSUPPORTED, "exchange-K kernels: SiLU * mul only where a wave finishes whole 32-token blocks");
@@ -2216,6 +2266,9 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
     snprintf(text, text_bytes, "skinny ntw=%d waves=%d x=%s dequant=%s grid=%dx%dx%d ksplit=%d workspace=%zu", p.mt, p.waves,
              p.xlds ? "lds" : "l2", p.dz ? (p.xlds ? "deferred-zero-table" : "deferred-zero-fragment") : "exact", p.grid_x,
              (M + 15) / 16, p.ksplit, p.ksplit, workspace_need(p));
+  else if (p.kernel == QUICK_KERNEL_XW)
+    snprintf(text, text_bytes, "xw tokens=128 channels=256 waves=4 ring=4 queue=4 grid=%d slices=%d xcd_rows=%d workspace=%zu", p.ntiles * p.ksplit, p.ksplit,
+             p.xcd_gm, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_XK)
     snprintf(text, text_bytes, "xk tokens=%d channels=128 waves=%d ring=%d queue=%d grid=%d slices=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
              p.xk_loader ? 12 : (p.xk_kq == 4 ? 16 : 8), p.xk_loader ? 3 : p.xk_nbuf, p.xk_loader ? 5 : p.xk_wd, p.ntiles * p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));

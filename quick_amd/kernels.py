@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 
-KERNEL_AUTO, KERNEL_SKINNY, KERNEL_TILED, KERNEL_WIDE, KERNEL_XK = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_SKINNY, KERNEL_TILED, KERNEL_WIDE, KERNEL_XK, KERNEL_XW = 0, 1, 2, 3, 4, 5
 _OK, _INVALID, _WORKSPACE, _LAUNCH, _UNSUPPORTED = 0, 1, 2, 3, 4
 
 

@@ -1,0 +1,125 @@
+// r04 microbenchmark: what ONE filler instruction of a given kind costs beside v_mfma_f32_32x32x16_f16 with one wave per SIMD.
+// Each workgroup = 4 waves; a wave runs REP x { 8 MFMAs on 8 different accumulators, each followed by N fillers of kind K }, all asm,
+// fillers on rotating independent registers (no dependent pairs closer than 8 instructions).  Prints shader clocks per MFMA.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/bin/mfma_filler_cost tools/mfma_filler_cost.hip && tools/bin/mfma_filler_cost
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <string>
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#define MF(i) "v_mfma_f32_32x32x16_f16 %" #i ", %[a], %[b], %" #i "\n\t"
+
+// filler strings: operate on v[200:215] (clobbered), constants in s40, s41 (set by the asm), LDS address v216
+#define F_NONE ""
+#define F_ANDOR(r) "v_and_or_b32 v" #r ", v" #r ", s40, v217\n\t"
+#define F_LSHR(r) "v_lshrrev_b32 v" #r ", 8, v" #r "\n\t"
+#define F_PKADD(r) "v_pk_add_f16 v" #r ", v" #r ", v217\n\t"
+#define F_PKMUL(r) "v_pk_mul_f16 v" #r ", v" #r ", v217\n\t"
+#define F_PKFMA(r) "v_pk_fma_f16 v" #r ", v" #r ", s41, v217\n\t"
+#define F_ADD16(r) "v_add_f16 v" #r ", v" #r ", v217\n\t"
+#define F_MIXLO(r) "v_fma_mixlo_f16 v" #r ", v" #r ", v217, 0 op_sel_hi:[1,1,0]\n\t"
+#define F_FMA32(r) "v_fma_f32 v" #r ", v" #r ", v217, v217\n\t"
+#define F_MOV(r) "v_mov_b32 v" #r ", v217\n\t"
+#define F_DSRD(r) "ds_read_b128 v[" #r ":" #r "+3], v216\n\t"
+#define F_SALU(r) "s_add_u32 s42, s42, 1\n\t"
+#define F_PKADD32(r) "v_pk_add_f32 v[" #r ":" #r "+1], v[" #r ":" #r "+1], v[218:219]\n\t"
+
+// N fillers behind MFMA i, on registers 200 + 2 * ((i * N + j) % 8)
+#define FILL0(F, i)
+#define FILL1(F, i) F(200)
+#define FILL2(F, i) F(200) F(202)
+#define FILL3(F, i) F(200) F(202) F(204)
+#define FILL4(F, i) F(200) F(202) F(204) F(206)
+#define FILL5(F, i) F(200) F(202) F(204) F(206) F(208)
+#define FILL6(F, i) F(200) F(202) F(204) F(206) F(208) F(210)
+#define FILL4B(F, i) F(208) F(210) F(212) F(214)
+#define FILL3B(F, i) F(208) F(210) F(212)
+#define FILL2B(F, i) F(208) F(210)
+#define FILL1B(F, i) F(208)
+#define FILL5B(F, i) F(208) F(210) F(212) F(214) F(200)
+#define FILL6B(F, i) F(208) F(210) F(212) F(214) F(200) F(202)
+#define FILL0B(F, i)
+
+#define BODY(F, N) MF(0) FILL##N(F, 0) MF(1) FILL##N##B(F, 1) MF(2) FILL##N(F, 2) MF(3) FILL##N##B(F, 3) MF(4) FILL##N(F, 4) MF(5) FILL##N##B(F, 5) MF(6) FILL##N(F, 6) MF(7) FILL##N##B(F, 7)
+
+template <int KIND, int N>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void bench(unsigned long long* out, int rep) {
+  extern __shared__ char smem[];
+  floatx16 c[8];
+  for (int i = 0; i < 8; ++i)
+    for (int r = 0; r < 16; ++r) c[i][r] = 0.f;
+  half8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f); b[i] = (_Float16)(i * 0.01f); }
+  const unsigned lds = (threadIdx.x & 63) * 16;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#define RUN(F, NN)                                                                                                                  \
+  asm volatile("s_mov_b32 s40, 0x000f000f\n\ts_mov_b32 s41, 0x2c002c00\n\ts_mov_b32 s42, 0\n\tv_mov_b32 v217, 0x3c003c00\n\tv_mov_b32 v216, %[l]\n\t" \
+               "v_mov_b32 v218, 1.0\n\tv_mov_b32 v219, 1.0\n\t"                                                                     \
+               "v_mov_b32 v200, 0\n\tv_mov_b32 v201, 0\n\tv_mov_b32 v202, 0\n\tv_mov_b32 v203, 0\n\tv_mov_b32 v204, 0\n\tv_mov_b32 v205, 0\n\tv_mov_b32 v206, 0\n\tv_mov_b32 v207, 0\n\t" \
+               "v_mov_b32 v208, 0\n\tv_mov_b32 v209, 0\n\tv_mov_b32 v210, 0\n\tv_mov_b32 v211, 0\n\tv_mov_b32 v212, 0\n\tv_mov_b32 v213, 0\n\tv_mov_b32 v214, 0\n\tv_mov_b32 v215, 0\n\t" \
+               "s_mov_b32 s43, %[rep]\n\t"                                                                                          \
+               ".Lloop_%=:\n\t" BODY(F, NN) "s_waitcnt lgkmcnt(0)\n\ts_sub_u32 s43, s43, 1\n\ts_cmp_lg_u32 s43, 0\n\ts_cbranch_scc1 .Lloop_%=\n\ts_nop 15\n\t"  \
+               : "+a"(c[0]), "+a"(c[1]), "+a"(c[2]), "+a"(c[3]), "+a"(c[4]), "+a"(c[5]), "+a"(c[6]), "+a"(c[7])                     \
+               : [a] "v"(a), [b] "v"(b), [l] "v"(lds), [rep] "s"(rep)                                                               \
+               : "memory", "scc", "s40", "s41", "s42", "s43", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", \
+                 "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219")
+#define RUNK(NN)                                                        \
+  if constexpr (KIND == 0) RUN(F_MOV, NN);                              \
+  else if constexpr (KIND == 1) RUN(F_ANDOR, NN);                       \
+  else if constexpr (KIND == 2) RUN(F_LSHR, NN);                        \
+  else if constexpr (KIND == 3) RUN(F_PKADD, NN);                       \
+  else if constexpr (KIND == 4) RUN(F_PKMUL, NN);                       \
+  else if constexpr (KIND == 5) RUN(F_PKFMA, NN);                       \
+  else if constexpr (KIND == 6) RUN(F_ADD16, NN);                       \
+  else if constexpr (KIND == 7) RUN(F_MIXLO, NN);                       \
+  else if constexpr (KIND == 8) RUN(F_FMA32, NN);                       \
+  else if constexpr (KIND == 9) RUN(F_DSRD, NN);                        \
+  else if constexpr (KIND == 10) RUN(F_SALU, NN);                       \
+  else RUN(F_PKADD32, NN);
+  if constexpr (N == 0) { RUNK(0) }
+  else if constexpr (N == 1) { RUNK(1) }
+  else if constexpr (N == 2) { RUNK(2) }
+  else if constexpr (N == 3) { RUNK(3) }
+  else if constexpr (N == 4) { RUNK(4) }
+  else if constexpr (N == 5) { RUNK(5) }
+  else { RUNK(6) }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) s += c[i][0];
+  if (threadIdx.x % 64 == 0) out[(blockIdx.x * 4 + threadIdx.x / 64) * 2] = t1 - t0;
+  if (s == 123.456f) out[1] = 1;
+}
+
+static const char* names[] = {"v_mov_b32", "v_and_or_b32", "v_lshrrev_b32", "v_pk_add_f16", "v_pk_mul_f16", "v_pk_fma_f16(sgpr)", "v_add_f16", "v_fma_mixlo_f16",
+                              "v_fma_f32", "ds_read_b128", "s_add_u32", "v_pk_add_f32"};
+
+template <int KIND, int N>
+void run(unsigned long long* d, int blocks) {
+  const int rep = 256;
+  std::vector<unsigned long long> h(blocks * 8);
+  for (int it = 0; it < 3; ++it) {
+    hipLaunchKernelGGL((bench<KIND, N>), dim3(blocks), dim3(256), 1024 * 16, 0, d, rep);
+    hipDeviceSynchronize();
+  }
+  hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+  double sum = 0;
+  for (int i = 0; i < blocks * 4; ++i) sum += (double)h[i * 2];
+  printf("  %-20s N=%d: %6.2f clocks per MFMA\n", names[KIND], N, sum / (blocks * 4) / (rep * 8.0));
+}
+template <int KIND>
+void run_all(unsigned long long* d, int blocks) {
+  run<KIND, 0>(d, blocks); run<KIND, 1>(d, blocks); run<KIND, 2>(d, blocks); run<KIND, 3>(d, blocks); run<KIND, 4>(d, blocks); run<KIND, 5>(d, blocks); run<KIND, 6>(d, blocks);
+}
+
+int main(int argc, char** argv) {
+  const int blocks = argc > 1 ? atoi(argv[1]) : 256;
+  unsigned long long* d;
+  hipMalloc(&d, 4096 * 8 * 8);
+  printf("blocks = %d (4 waves each, one per SIMD)\n", blocks);
+  run_all<0>(d, blocks); run_all<1>(d, blocks); run_all<2>(d, blocks); run_all<3>(d, blocks); run_all<4>(d, blocks); run_all<5>(d, blocks);
+  run_all<6>(d, blocks); run_all<7>(d, blocks); run_all<8>(d, blocks); run_all<9>(d, blocks); run_all<10>(d, blocks); run_all<11>(d, blocks);
+  return 0;
+}

@@ -54,6 +54,7 @@ for spec in (args or ["512x4096x4096"]):
         print(f"   {n:40s} mean {v[0]:7.2f} us   min {v[1]:7.2f}   max {v[2]:7.2f}")
     kl = np.mean([(d[:, 2] - d[:, 1]).mean() for d in acc])
     kc = np.mean([c.mean() for c in cycs])
+    kl = max(kl, 1e-9)
     print(f"   K loop: {kc:.0f} shader clocks per wave in {kl:.2f} us = {kc / kl / 1000:.3f} GHz")
     sw = np.mean([(g >> np.uint64(32)).astype(np.float64).mean() for g in segs])
     sb = np.mean([(g & np.uint64(0xffffffff)).astype(np.float64).mean() for g in segs])
