@@ -312,6 +312,7 @@ def main():
         lib.quick_w4a16_plan_describe(M, K, N, G, args.kernel, args.split_k, pbuf, 256)
         roof["plan"] = pbuf.value.decode()
         roof["traffic"], roof["traffic_source"] = pmc_traffic(M, K, N, G, args.kernel, roof["plan"])
+        roof["traffic_measured_in_this_run"] = False   # counters need their own rocprofv3 --pmc passes: read back from the committed profiles/ file named in traffic_source
         roof.update({"kernel_us": k_us, "kernel_us_event_pairs": k_us_events, "kernel_us_cache_resident": k_us_hot,
                      "algorithmic_bytes": nbytes, "flops": flops})
         roof.update(pmc_issue_mix(M, K, N, G, args.kernel, roof["traffic_source"]))
@@ -459,12 +460,26 @@ def main():
             times.append(dt1)
         reps, total = len(times), sum(times)
         dt = float(np.median(times))
+        # where the time goes (one more call, split): the per-call dequantisation vs the fp16 matmul -- hosts without a native fp16 GEMM
+        # path read hundreds of times slower than BASELINE.md's 73 ms for the full layer (5.8 s per 1024 channels)
+        qw_g, qz_g = cpu_path.pack_gemm_format(iw[:, :n_cpu], z[:, :n_cpu])
+        t0 = time.perf_counter()
+        w_cpu = cpu_path.dequantize_gemm(torch.from_numpy(qw_g), torch.from_numpy(qz_g), torch.from_numpy(np.ascontiguousarray(s[:, :n_cpu])), G)
+        t_deq = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        torch.matmul(x_t, w_cpu)
+        t_mm = time.perf_counter() - t0
+        full_layer_ms = dt * 1e3 * N / n_cpu
         out["cpu_baseline"] = {
             "value": algorithmic_flops(args.M, K, n_cpu) / dt / 1e12, "unit": "TFLOP/s", "cores": cores,
             "kind": "port", "ms_per_call": dt * 1e3, "calls": reps, "ms_per_call_min_max": [min(times) * 1e3, max(times) * 1e3],
             "sample": f"{reps} call(s) of the reference CPU path (dequantize_gemm + torch.matmul, dequant redone per call, "
                       f"oracle/cpu_path.py) on output channels 0..{n_cpu - 1} of the M={args.M} K={K} N={N} g={G} layer, "
                       f"{total:.1f} s on {cores} torch threads",
+            "split_ms": {"dequantize": t_deq * 1e3, "matmul_fp16": t_mm * 1e3},
+            "full_layer_ms_extrapolated": full_layer_ms, "baseline_md_full_layer_ms": 73.3,
+            "deviates_over_10x_from_baseline_md": bool(full_layer_ms > 733.0 or full_layer_ms < 7.33),
+            "torch_parallel_info": torch.__config__.parallel_info().strip().splitlines()[:6],
         }
         # the GPU result of the headline step's set 0 against the CPU baseline's output (same inputs)
         qw, sc, qz = sets[0]

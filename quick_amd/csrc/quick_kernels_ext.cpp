@@ -42,7 +42,10 @@ void check(const torch::Tensor& t, c10::ScalarType dtype, const char* name) {
 [[noreturn]] void raise(int rc) {
   const std::string msg = quick_amd_last_error();
   if (rc == QUICK_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);  // -> ValueError, as the reference's host function
-  if (rc == QUICK_ERR_UNSUPPORTED) throw py::value_error("unsupported on MI355X: " + msg);
+  if (rc == QUICK_ERR_UNSUPPORTED) {   // NotImplementedError, the same type the ctypes shim raises (quick_amd/kernels.py:_raise)
+    PyErr_SetString(PyExc_NotImplementedError, ("unsupported on MI355X: " + msg).c_str());
+    throw py::error_already_set();
+  }
   TORCH_CHECK(false, msg);
 }
 

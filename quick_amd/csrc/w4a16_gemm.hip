@@ -1503,36 +1503,38 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   // tiled kernel (64-bit pointers) runs instead
   if ((p.kernel == QUICK_KERNEL_WIDE || p.kernel == QUICK_KERNEL_XK) && (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32)) p.kernel = QUICK_KERNEL_TILED;
   if (p.kernel == QUICK_KERNEL_XK && (size_t)M * (size_t)N * 2 >= ((size_t)1 << 32)) p.kernel = QUICK_KERNEL_TILED;  // (y through a buffer descriptor as well)
-  if (p.kernel == QUICK_KERNEL_XW && (G % 128 != 0 || ((G / 128) & (G / 128 - 1)) != 0 || N % 256 != 0 || (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32) ||
+  if (p.kernel == QUICK_KERNEL_XW && (G % 128 != 0 || ((G / 128) & (G / 128 - 1)) != 0 || (N % 256 != 0 && mt_req != 2 && !no_xlds) || (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32) ||
                                       (size_t)M * (size_t)N * 2 >= ((size_t)1 << 32)))
     p.kernel = QUICK_KERNEL_TILED;  // (the loop shifts the k tile by log2(G / 128); 256-channel tiles; 32-bit buffer offsets)
   if (p.kernel == QUICK_KERNEL_XW) {
-    // 128 x 256 tiles, four waves, hand-placed K loop (w4a16_xw.hpp); S = 1, 2, 4 K slices per tile on S compute units.  Nobody has to be
-    // co-resident (a wave that waits too long gives its block up, the last partner finishes it), but the exchange zone holds S * S boxes
-    // of a tile's fp16 image / S per tile: tiles * S <= 256.  bits 8-11: S (0 = as many as fit the CUs); bits 22-26: log2 of the poll
-    // limit in ticks of 10 ns (tests: 1 = every wave gives up at once).
-    const int MBk = (M + 127) / 128, NBk = N / 256;
-    p.wide_mb = 4;
-    p.wide_pairs = 2;
-    p.tch = 256;
+    // Four waves, one per SIMD, hand-placed K loops (w4a16_xw.hpp): tiles of 128 x 256, 128 x 128 or 64 x 128; S = 1, 2, 4 K slices per
+    // tile on S compute units.  Nobody has to be co-resident (a wave that waits too long gives its block up, the last partner finishes it),
+    // but the exchange zone holds S * S boxes of (a tile's fp16 image / S) per tile: workgroups <= 256 with S > 1.
+    // bits 4-7: 32-token blocks per tile (2, 4; 0 = 4); bit 12: 128-channel tiles (implied by 2 blocks); bits 8-11: S (0 = as many as fit
+    // the CUs); bits 22-26: log2 of the poll limit in ticks of 10 ns (tests: 1 = every wave gives up at once).
+    const int mb = mt_req == 2 ? 2 : 4, pairs = (mb == 2 || no_xlds) ? 1 : 2;
+    const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / (pairs * 128);
+    p.wide_mb = mb;
+    p.wide_pairs = pairs;
+    p.tch = pairs * 128;
     p.waves = 4;
     p.ntiles = MBk * NBk;
     const int s_req = grid_split_k > 0 ? grid_split_k : (kernel >> 8) & 15;
     int s = 1;
-    if (s_req == 1 || s_req == 2 || s_req == 4) s = s_req;
+    if (s_req == 1 || s_req == 2 || (s_req == 4 && mb == 4)) s = s_req;
     else
-      while (s < 4 && (long)p.ntiles * s * 2 <= cu_count() && KT / (s * 2) >= 4) s *= 2;
+      while (s < mb && s < 4 && (long)p.ntiles * s * 2 <= cu_count() && KT / (s * 2) >= 4) s *= 2;
     while (s > 1 && ((long)p.ntiles * s > 256 || (KT + (KT + s - 1) / s - 1) / ((KT + s - 1) / s) != s)) s /= 2;
     p.ksplit = s;
     p.kt_per_split = (KT + s - 1) / s;
     p.poll_log2 = (kernel >> 22) & 31;
     if (const char* e = getenv("QUICK_AMD_EXCHANGE_POLL_LOG2")) p.poll_log2 = std::max(0, std::min(31, atoi(e)));
-    const int groups = 8 / s;
+    const int groups = 8 / s;  // XCDs per K slice: they form a gm x gn grid over the (token, channel) tiles
     long best = -1;
     if (!((kernel >> 14) & 1) && ((long)p.ntiles * s) % 8 == 0)
       for (int gm = 1; gm <= groups; gm *= 2) {
         if (MBk % gm != 0 || NBk % (groups / gm) != 0) continue;
-        const long cost = (long)(MBk / gm) * 256 + (long)(NBk * gm / groups) * 128;  // bytes per k and XCD: x rows (2 B) + weight columns (1/2 B)
+        const long cost = (long)(MBk / gm) * 64 * mb + (long)(NBk * gm / groups) * 64 * pairs;  // bytes per k and XCD: x rows (2 B) + weight columns (1/2 B)
         if (best < 0 || cost < best) {
           best = cost;
           p.xcd_gm = gm;
@@ -2141,14 +2143,17 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
     int abl = a.span ? 32 : 0;
 #ifdef QUICK_AMD_TOOLS
-    if (p.ablate == 16) abl = 64;       // phase stamps
+    if (p.ablate == 16) {               // phase stamps (QUICK_XW_EXP: + a loop experiment, tools/gen_xw_loop.py)
+      abl = 64;
+      if (const char* e = getenv("QUICK_XW_EXP")) abl += 256 * atoi(e);
+    }
     else if (p.ablate == 20) abl = 68;  // ... and no exchange (wrong results)
     else if (p.ablate) return fail(QUICK_ERR_INVALID_ARGUMENT, "XW: timing-experiment bits 16 (stamps) and 20 (no exchange) only");
 #endif
     a.xcd_gm |= p.poll_log2 << 8;  // (the kernel reads the tile-order rows from the low byte)
-    if (!xw_launch(p.ksplit, abl, a, p.ntiles * p.ksplit, L.st, L.start, L.stop)) {
+    if (!xw_launch(p.wide_mb, p.wide_pairs, p.ksplit, abl, a, p.ntiles * p.ksplit, L.st, L.start, L.stop)) {
       if (abl == 32) g_span_unsupported = true;
-      return fail(QUICK_ERR_UNSUPPORTED, "no 128 x 256 four-wave build for slices=%d abl=%d", p.ksplit, abl);
+      return fail(QUICK_ERR_UNSUPPORTED, "no four-wave build for tokens=%d channels=%d slices=%d abl=%d", p.wide_mb * 32, p.tch, p.ksplit, abl);
     }
   } else if (p.kernel == QUICK_KERNEL_XK) {
     if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
@@ -2267,8 +2272,8 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
              p.xlds ? "lds" : "l2", p.dz ? (p.xlds ? "deferred-zero-table" : "deferred-zero-fragment") : "exact", p.grid_x,
              (M + 15) / 16, p.ksplit, p.ksplit, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_XW)
-    snprintf(text, text_bytes, "xw tokens=128 channels=256 waves=4 ring=4 queue=4 grid=%d slices=%d xcd_rows=%d workspace=%zu", p.ntiles * p.ksplit, p.ksplit,
-             p.xcd_gm, workspace_need(p));
+    snprintf(text, text_bytes, "xw tokens=%d channels=%d waves=4 ring=%d queue=%d grid=%d slices=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32, p.tch,
+             p.wide_mb == 2 ? 8 : 4, p.wide_mb == 2 ? 8 : 4, p.ntiles * p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_XK)
     snprintf(text, text_bytes, "xk tokens=%d channels=128 waves=%d ring=%d queue=%d grid=%d slices=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
              p.xk_loader ? 12 : (p.xk_kq == 4 ? 16 : 8), p.xk_loader ? 3 : p.xk_nbuf, p.xk_loader ? 5 : p.xk_wd, p.ntiles * p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));

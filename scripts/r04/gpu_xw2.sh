@@ -14,6 +14,7 @@ export QUICK_AMD_LIB_OVERRIDE=$PWD/quick_amd/lib/libquick_amd_tools.so
 echo "== phases"
 timeout 200 python tools/xk_phases.py --kernel 0x405 512x4096x4096
 timeout 200 python tools/xk_phases.py --kernel 0x405 --abl 20 512x4096x4096
+timeout 200 python tools/xk_phases.py --kernel 0x405 --abl 21 512x4096x4096
 timeout 200 python tools/xk_phases.py --kernel 0x205 1024x4096x4096
 } > gpurun_out/r04/xw2.txt 2>&1
 grep -v "amdgpu.ids" gpurun_out/r04/xw2.txt | tail -90

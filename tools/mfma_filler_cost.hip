@@ -43,6 +43,17 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define FILL6B(F, i) F(208) F(210) F(212) F(214) F(200) F(202)
 #define FILL0B(F, i)
 
+// realistic mixes per 8 MFMAs: A = 26 VALU + 4 reads (128 x 64 per wave), B = 26 VALU + 8 reads (128 x 32), C = 52 VALU + 8 reads (64 x 32)
+#define V3 F_PKMUL(200) F_ANDOR(202) F_PKADD(204)
+#define V4 F_PKMUL(200) F_ANDOR(202) F_PKADD(204) F_LSHR(206)
+#define V6 F_PKMUL(200) F_ANDOR(202) F_PKADD(204) F_LSHR(206) F_PKFMA(208) F_ANDOR(210)
+#define V7 F_PKMUL(200) F_ANDOR(202) F_PKADD(204) F_LSHR(206) F_PKFMA(208) F_ANDOR(210) F_PKMUL(212)
+#define RD(r) "ds_read_b128 v[" #r ":" #r "+3], v216\n\t"
+#define RDA(r) "ds_read_b128 a[" #r ":" #r "+3], v216\n\t"
+#define MIXA MF(0) RD(220) V3 MF(1) RD(224) V3 MF(2) RD(228) V3 MF(3) RD(232) V3 MF(4) V3 MF(5) V4 MF(6) V3 MF(7) V4
+#define MIXB MF(0) RD(220) V3 MF(1) RD(224) V3 MF(2) RD(228) V3 MF(3) RD(232) V3 MF(4) RD(236) V3 MF(5) RD(240) V4 MF(6) RD(244) V3 MF(7) RD(220) V4
+#define MIXC MF(0) RD(220) V6 MF(1) RD(224) V7 MF(2) RD(228) V6 MF(3) RD(232) V7 MF(4) RD(236) V6 MF(5) RD(240) V7 MF(6) RD(244) V6 MF(7) RD(220) V7
+#define MIXBA MF(0) RDA(128) V3 MF(1) RDA(132) V3 MF(2) RDA(136) V3 MF(3) RDA(140) V3 MF(4) RDA(144) V3 MF(5) RDA(148) V4 MF(6) RDA(152) V3 MF(7) RDA(156) V4
 #define BODY(F, N) MF(0) FILL##N(F, 0) MF(1) FILL##N##B(F, 1) MF(2) FILL##N(F, 2) MF(3) FILL##N##B(F, 3) MF(4) FILL##N(F, 4) MF(5) FILL##N##B(F, 5) MF(6) FILL##N(F, 6) MF(7) FILL##N##B(F, 7)
 
 template <int KIND, int N>
@@ -79,7 +90,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   else if constexpr (KIND == 9) RUN(F_DSRD, NN);                        \
   else if constexpr (KIND == 10) RUN(F_SALU, NN);                       \
   else RUN(F_PKADD32, NN);
-  if constexpr (N == 0) { RUNK(0) }
+#define RUNMIX(MIX)                                                                                                                 \
+  asm volatile("s_mov_b32 s40, 0x000f000f\n\ts_mov_b32 s41, 0x2c002c00\n\ts_mov_b32 s42, 0\n\tv_mov_b32 v217, 0x3c003c00\n\tv_mov_b32 v216, %[l]\n\t" \
+               "v_mov_b32 v200, 0\n\tv_mov_b32 v202, 0\n\tv_mov_b32 v204, 0\n\tv_mov_b32 v206, 0\n\tv_mov_b32 v208, 0\n\tv_mov_b32 v210, 0\n\tv_mov_b32 v212, 0\n\t" \
+               "s_mov_b32 s43, %[rep]\n\t"                                                                                          \
+               ".Lloop_%=:\n\t" MIX "s_waitcnt lgkmcnt(0)\n\ts_sub_u32 s43, s43, 1\n\ts_cmp_lg_u32 s43, 0\n\ts_cbranch_scc1 .Lloop_%=\n\ts_nop 15\n\t"  \
+               : "+a"(c[0]), "+a"(c[1]), "+a"(c[2]), "+a"(c[3]), "+a"(c[4]), "+a"(c[5]), "+a"(c[6]), "+a"(c[7])                     \
+               : [a] "v"(a), [b] "v"(b), [l] "v"(lds), [rep] "s"(rep)                                                               \
+               : "memory", "scc", "s40", "s41", "s42", "s43", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", \
+                 "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", \
+                 "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", \
+                 "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", \
+                 "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159")
+  if constexpr (KIND == 20) { RUNMIX(MIXA); }
+  else if constexpr (KIND == 21) { RUNMIX(MIXB); }
+  else if constexpr (KIND == 22) { RUNMIX(MIXC); }
+  else if constexpr (KIND == 23) { RUNMIX(MIXBA); }
+  else if constexpr (N == 0) { RUNK(0) }
   else if constexpr (N == 1) { RUNK(1) }
   else if constexpr (N == 2) { RUNK(2) }
   else if constexpr (N == 3) { RUNK(3) }
@@ -107,7 +134,8 @@ void run(unsigned long long* d, int blocks) {
   hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
   double sum = 0;
   for (int i = 0; i < blocks * 4; ++i) sum += (double)h[i * 2];
-  printf("  %-20s N=%d: %6.2f clocks per MFMA\n", names[KIND], N, sum / (blocks * 4) / (rep * 8.0));
+  static const char* mixes[] = {"mix A: 26 VALU + 4 ds_read_b128 / 8 MFMA", "mix B: 26 VALU + 8 reads", "mix C: 52 VALU + 8 reads", "mix B, reads into AGPRs"};
+  printf("  %-20s N=%d: %6.2f clocks per MFMA\n", KIND >= 20 ? mixes[KIND - 20] : names[KIND], N, sum / (blocks * 4) / (rep * 8.0));
 }
 template <int KIND>
 void run_all(unsigned long long* d, int blocks) {
@@ -119,6 +147,8 @@ int main(int argc, char** argv) {
   unsigned long long* d;
   hipMalloc(&d, 4096 * 8 * 8);
   printf("blocks = %d (4 waves each, one per SIMD)\n", blocks);
+  run<20, 0>(d, blocks); run<21, 0>(d, blocks); run<22, 0>(d, blocks); run<23, 0>(d, blocks);
+  if (argc > 2) return 0;
   run_all<0>(d, blocks); run_all<1>(d, blocks); run_all<2>(d, blocks); run_all<3>(d, blocks); run_all<4>(d, blocks); run_all<5>(d, blocks);
   run_all<6>(d, blocks); run_all<7>(d, blocks); run_all<8>(d, blocks); run_all<9>(d, blocks); run_all<10>(d, blocks); run_all<11>(d, blocks);
   return 0;

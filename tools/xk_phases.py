@@ -56,6 +56,8 @@ for spec in (args or ["512x4096x4096"]):
     kc = np.mean([c.mean() for c in cycs])
     kl = max(kl, 1e-9)
     print(f"   K loop: {kc:.0f} shader clocks per wave in {kl:.2f} us = {kc / kl / 1000:.3f} GHz")
+    loc = np.mean([g.astype(np.float64).mean() for g in segs])
+    print(f"   word 7 (XW: share of waves whose tile sat behind one L2): {loc:.3f}")
     sw = np.mean([(g >> np.uint64(32)).astype(np.float64).mean() for g in segs])
     sb = np.mean([(g & np.uint64(0xffffffff)).astype(np.float64).mean() for g in segs])
     if sw + sb > 0:

@@ -21,18 +21,21 @@ for spec in shapes:
     assert rc == 0
     ref = x.float() @ w.float()
     scale = ref.abs().max().item()
-    wide = kernels.gemm_forward(x, qw, sc, qz, kernel_id=3 | (4 << 4) | (2 << 8) | (1 << 12), grid_split_k=1)
-    for s in (1, 2, 4):
-        kid = XW | (s << 8)
+    for mb, pairs in ((4, 2), (4, 1), (2, 1)):
+      if N % (pairs * 128):
+        continue
+      wide = kernels.gemm_forward(x, qw, sc, qz, kernel_id=3 | (mb << 4) | (pairs << 8) | (1 << 12), grid_split_k=1)
+      for s in (1, 2, 4):
+        kid = XW | (s << 8) | ((mb << 4) if mb == 2 else 0) | ((1 << 12) if pairs == 1 else 0)
         plan = kernels.plan_describe(M, K, N, G, kid)
-        if f"slices={s}" not in plan:
+        if f"slices={s}" not in plan or not plan.startswith("xw"):
             continue
         y = kernels.gemm_forward(x, qw, sc, qz, kernel_id=kid)
         y2 = kernels.gemm_forward(x, qw, sc, qz, kernel_id=kid)
         torch.cuda.synchronize()
         err = (y.float() - ref).abs().max().item() / scale
         same = bool((y == y2).all())
-        eqw = bool((y == wide).all()) if s == 1 else None
+        eqw = bool((y == wide).all()) if (s == 1 and mb == 4) else None
         nanc = int(torch.isnan(y.float()).sum())
         okk = err <= 2e-3 and same and nanc == 0 and (eqw is not False)
         bad += not okk
