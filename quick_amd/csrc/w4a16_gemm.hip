@@ -1360,6 +1360,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   // 64 x 4096 x 12288 and 8192 x 4096 x 22016, never behind by more than 3 % [r02 probes, profiles/r02_planner_probe*.jsonl].
   // The tile (mb x 32 tokens, pairs x 128 channels) minimises a fitted launch-time model, see below.
   int wide_mb = 0, wide_pairs = 0, xk_auto_mb = 0;
+  int xw_auto_mb = 0, xw_auto_pairs = 0, xw_auto_s = 0;   // [r04] the planner's own four-wave pick (w4a16_xw.hpp)
   bool wide_ring = false;
   // K slices of a wide launch: as many as keep the workgroups within one round of 256 and the slices >= 4 stages -- any count,
   // not only powers of two (80 tiles run 3 slices = 240 workgroups; Llama-2-13B's N = 5120 is 40 / 80 tiles wide)
@@ -1478,7 +1479,40 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         }
       }
     }
-    if (xk_auto_mb) p.kernel = QUICK_KERNEL_XK;
+    // [r04] the four-wave kernels with generated hand-placed loops (w4a16_xw.hpp) -- 128 x 256, 128 x 128 and 64 x 128 tiles, 1 / 2 / 4 K
+    // slices per tile.  Their own launch-time model (same form as above; fitted, relative least squares, to scripts/r04/gpu_xw_sweep.sh:
+    // 9 layer shapes x 12 token counts x 6 forced variants, 4.3 / 4.7 / 1.7 % rms) picks the tile and the slice count; WHETHER one of them
+    // runs is decided on the sweep's own rows, against the pick of the rules above (profiles/r04_xw_sweep.jsonl, tools/xw_sweep_report.py):
+    // they replace the 64- / 128-token wide tiles, the tiled kernel and the exchange-K tiles (6 % faster on the geometric mean of the 108
+    // shapes, 13-24 % where the r02 128-token wide tile ran), not the 256 x 256 tile (level within 5 %, behind at 8192 tokens), and below
+    // 160 tokens only from 96 tokens on wide layers (N >= 10240: 96 / 128 x 4096 x 11008 20.7 / 21.0 -> 17.8 / 18.6 us; at N = 4096 the 64-token
+    // exchange-K tile stays 5-7 % ahead).
+    if (best > 0 && allow_xk && wide_mb != 8 && (G / 128 & (G / 128 - 1)) == 0 && (M >= 160 || (M >= 96 && N >= 10240)) &&
+        (size_t)M * (size_t)K * 2 < ((size_t)1 << 32) && (size_t)M * (size_t)N * 2 < ((size_t)1 << 32)) {
+      struct XwCand { int mb, pairs; double c, a, b_ceil, b_frac, s0, s1, d; };
+      static const XwCand xwc[3] = {{4, 2, -2.8632, 5.8843, 0.8799, 0.6018, -0.6402, 1.2461, 5.8244},
+                                    {4, 1, -0.3015, 1.9468, 0.5116, 0.3473, -0.0715, 1.0316, 4.3280},
+                                    {2, 1, 1.8009, 3.7953, 0.3277, 0.2559, 0.1770, 0.3541, 0.0325}};
+      double xbest = 0;
+      for (int c = 0; c < 3; ++c) {
+        const int mb = xwc[c].mb, pairs = xwc[c].pairs;
+        if (N % (pairs * 128) != 0) continue;
+        const long T = (long)((M + mb * 32 - 1) / (mb * 32)) * (N / (pairs * 128));
+        for (int sx = 1; sx <= mb && sx <= 4; sx *= 2) {
+          if (sx > 1 && (T * sx > 256 || KT / sx < 4 || (KT + (KT + sx - 1) / sx - 1) / ((KT + sx - 1) / sx) != sx)) continue;
+          const double f = (double)(T * sx) / 256.0, n = (double)((T * sx + 255) / 256), stages = (double)((KT + sx - 1) / sx);
+          const double cost = xwc[c].c + xwc[c].a * n + stages * (xwc[c].b_ceil * n + xwc[c].b_frac * f) + (sx > 1 ? xwc[c].s0 + xwc[c].s1 * sx : 0.0) + xwc[c].d * f;
+          if (xw_auto_mb == 0 || cost < xbest) {
+            xbest = cost;
+            xw_auto_mb = mb;
+            xw_auto_pairs = pairs;
+            xw_auto_s = sx;
+          }
+        }
+      }
+    }
+    if (xw_auto_mb) p.kernel = QUICK_KERNEL_XW;
+    else if (xk_auto_mb) p.kernel = QUICK_KERNEL_XK;
     else if (wide_mb) p.kernel = QUICK_KERNEL_WIDE;
     else if (model_tiled_mt) p.kernel = QUICK_KERNEL_TILED;
   }
@@ -1503,7 +1537,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   // tiled kernel (64-bit pointers) runs instead
   if ((p.kernel == QUICK_KERNEL_WIDE || p.kernel == QUICK_KERNEL_XK) && (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32)) p.kernel = QUICK_KERNEL_TILED;
   if (p.kernel == QUICK_KERNEL_XK && (size_t)M * (size_t)N * 2 >= ((size_t)1 << 32)) p.kernel = QUICK_KERNEL_TILED;  // (y through a buffer descriptor as well)
-  if (p.kernel == QUICK_KERNEL_XW && (G % 128 != 0 || ((G / 128) & (G / 128 - 1)) != 0 || (N % 256 != 0 && mt_req != 2 && !no_xlds) || (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32) ||
+  if (p.kernel == QUICK_KERNEL_XW && (G % 128 != 0 || ((G / 128) & (G / 128 - 1)) != 0 || (N % 256 != 0 && !xw_auto_mb && mt_req != 2 && !no_xlds) || (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32) ||
                                       (size_t)M * (size_t)N * 2 >= ((size_t)1 << 32)))
     p.kernel = QUICK_KERNEL_TILED;  // (the loop shifts the k tile by log2(G / 128); 256-channel tiles; 32-bit buffer offsets)
   if (p.kernel == QUICK_KERNEL_XW) {
@@ -1512,14 +1546,14 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // but the exchange zone holds S * S boxes of (a tile's fp16 image / S) per tile: workgroups <= 256 with S > 1.
     // bits 4-7: 32-token blocks per tile (2, 4; 0 = 4); bit 12: 128-channel tiles (implied by 2 blocks); bits 8-11: S (0 = as many as fit
     // the CUs); bits 22-26: log2 of the poll limit in ticks of 10 ns (tests: 1 = every wave gives up at once).
-    const int mb = mt_req == 2 ? 2 : 4, pairs = (mb == 2 || no_xlds) ? 1 : 2;
+    const int mb = xw_auto_mb ? xw_auto_mb : (mt_req == 2 ? 2 : 4), pairs = xw_auto_mb ? xw_auto_pairs : ((mb == 2 || no_xlds) ? 1 : 2);
     const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / (pairs * 128);
     p.wide_mb = mb;
     p.wide_pairs = pairs;
     p.tch = pairs * 128;
     p.waves = 4;
     p.ntiles = MBk * NBk;
-    const int s_req = grid_split_k > 0 ? grid_split_k : (kernel >> 8) & 15;
+    const int s_req = xw_auto_s ? xw_auto_s : (grid_split_k > 0 ? grid_split_k : (kernel >> 8) & 15);
     int s = 1;
     if (s_req == 1 || s_req == 2 || (s_req == 4 && mb == 4)) s = s_req;
     else

@@ -217,15 +217,23 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(512, 4096, 4096, kernel_id=kernels.KERNEL_WIDE | (2 << 4) | (1 << 8) | (1 << 15) | (4 << 22)).startswith(
         "wide tokens=64 channels=128 waves=8 ring=4 grid=256x1")                                       # r02's pick there: the LDS-DMA ring, eight waves
     # r03: the exchange-K tiles (weights in an AGPR queue, five x slots, K slices on different CUs) wherever their workgroups fit one round
-    assert plan(512, 4096, 4096).startswith("xk tokens=64 channels=128 waves=8 ring=5 queue=4 grid=256 slices=1")      # the bench line: one 64 x 128 tile per CU
-    assert "xk tokens=64" in plan(256, 4096, 4096) and "slices=2" in plan(256, 4096, 4096)
-    assert plan(160, 4096, 6144).startswith("xk tokens=64") and "slices=1" in plan(160, 4096, 6144)
-    assert plan(64, 4096, 22016).startswith("xk tokens=64") and "slices=2" in plan(64, 4096, 12288)   # 172 / 96 tiles of 64 x 128
-    assert plan(1024, 4096, 4096).startswith("xk tokens=128 channels=128 waves=8 ring=5 queue=4 grid=256 slices=1")   # 256 tiles of 128 x 128: one round
-    assert "slices=2" in plan(512, 11008, 4096) and "tokens=128" in plan(512, 11008, 4096)             # 128 tiles x 2 slices of 43 stages
-    assert plan(2048, 3584, 18944).startswith("wide")                                                  # several rounds: the wide family's larger tiles
-    assert "tokens=128 channels=256" in plan(2048, 4096, 4096) and "tokens=256 channels=256" in plan(8192, 4096, 22016)
-    assert "tokens=128 channels=256 waves=4 ring=0 grid=144x1" in plan(384, 4096, 12288)  # fitted launch-time model: 45.2 us against 49.4-64 for the others
+    X = kernels.KERNEL_XK
+    assert plan(512, 4096, 4096, kernel_id=X).startswith("xk tokens=128") and plan(512, 4096, 4096, kernel_id=X | (2 << 4)).startswith(
+        "xk tokens=64 channels=128 waves=8 ring=5 queue=4 grid=256 slices=1")                            # r03's bench line: one 64 x 128 tile per CU
+    assert plan(64, 4096, 22016).startswith("xk tokens=64") and "slices=2" in plan(64, 4096, 12288)   # 172 / 96 tiles of 64 x 128 (below 96 tokens: r03's picks)
+    assert "xk tokens=64" in plan(128, 4096, 4096) and "slices=4" in plan(128, 4096, 4096)            # ... and below 160 on the narrow layers
+    # r04: the four-wave kernels with generated loops (w4a16_xw.hpp) from 160 tokens (96 on wide layers), picked by their own launch-time model
+    assert plan(512, 4096, 4096).startswith("xw tokens=128 channels=128 waves=4 ring=4 queue=4 grid=256 slices=2")    # the bench line: 128 x 128 tiles, two K slices
+    assert plan(256, 4096, 4096).startswith("xw tokens=64 channels=128 waves=4 ring=8 queue=8 grid=256 slices=2")
+    assert plan(160, 4096, 6144).startswith("xw tokens=128 channels=128") and "slices=2" in plan(160, 4096, 6144)
+    assert plan(1024, 4096, 4096).startswith("xw tokens=128 channels=128 waves=4 ring=4 queue=4 grid=256 slices=1")   # 256 tiles of 128 x 128: one round, nothing to exchange
+    assert "slices=2" in plan(512, 11008, 4096) and "xw tokens=128 channels=128" in plan(512, 11008, 4096)            # 128 tiles x 2 slices of 43 stages
+    assert plan(96, 4096, 22016).startswith("xw tokens=128 channels=128") and plan(96, 4096, 4096).startswith("xk")   # below 160 tokens only on wide layers
+    assert plan(2048, 3584, 18944).startswith("wide")                                                  # several rounds: the 256 x 256 tile of the wide family
+    assert plan(2048, 4096, 4096).startswith("xw tokens=128 channels=256") and "wide tokens=256 channels=256" in plan(8192, 4096, 22016)
+    assert plan(384, 4096, 12288).startswith("xw tokens=128 channels=256 waves=4 ring=4 queue=4 grid=144 slices=1")   # 41.6 us (r03's 128 x 256 wide tile: 51.2)
+    assert plan(512, 4096, 4096, kernel_id=kernels.KERNEL_XW).startswith("xw tokens=128 channels=256") and "slices=4" in plan(512, 4096, 4096, kernel_id=kernels.KERNEL_XW)
+    assert not plan(512, 4608, 4096, G=384).startswith("xw") and not plan(512, 4608, 4096, G=384, kernel_id=kernels.KERNEL_XW).startswith("xw")  # G / 128 must be a power of two
     W = kernels.KERNEL_WIDE
     assert "tokens=256 channels=256" in plan(4096, 8192, 8192, kernel_id=W | (8 << 4) | (2 << 8))      # explicit tile
     assert "waves=8 ring=6" in plan(512, 4096, 4096, kernel_id=W | (2 << 4) | (1 << 8) | (1 << 15))   # eight-wave ring
