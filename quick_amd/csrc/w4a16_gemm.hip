@@ -2201,6 +2201,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     if (p.ablate)  // (experiments whose bits do not fit the kernel id: the ABL value itself, tools/xk_phases.py --env-abl)
       if (const char* e = getenv("QUICK_XK_ABL")) abl = atoi(e) == 0 && a.span ? 32 : atoi(e);
 #endif
+    if (const char* e = getenv("QUICK_AMD_EXCHANGE_POLL_LOG2")) a.xcd_gm |= std::max(0, std::min(31, atoi(e))) << 8;   // (tests: 1 = every wave gives its part up at once)
     if (!xk_launch(XkConfig{p.wide_mb, p.ksplit, p.xk_nbuf, p.xk_wd, abl, p.xk_kq, p.xk_loader ? 1 : 0}, a, p.ntiles * p.ksplit, L.st, L.start, L.stop)) {
       if (abl == 32) {
         g_span_unsupported = true;

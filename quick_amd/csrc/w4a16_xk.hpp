@@ -209,11 +209,12 @@ __device__ __forceinline__ XkTile xk_tile(const GemmArgs& a) {
   XkTile t;
   const int NB = a.N >> 7, MBk = (a.M + MB * 32 - 1) / (MB * 32);
   const int b = blockIdx.x;
-  if (a.xcd_gm > 0) {
+  const int gmrows = a.xcd_gm & 255;   // (bits 8..: log2 of the exchange poll limit)
+  if (gmrows > 0) {
     const int xcd = b & 7, idx = b >> 3;
     t.ks = xcd % S;
-    const int g = xcd / S, gn = (8 / S) / a.xcd_gm;
-    const int mcnt = MBk / a.xcd_gm, ncnt = NB / gn;
+    const int g = xcd / S, gn = (8 / S) / gmrows;
+    const int mcnt = MBk / gmrows, ncnt = NB / gn;
     t.mb = (g / gn) * mcnt + idx / ncnt;
     t.nb = (g % gn) * ncnt + idx % ncnt;
   } else {
@@ -231,7 +232,6 @@ __device__ __forceinline__ XkTile xk_tile(const GemmArgs& a) {
 }
 
 constexpr unsigned kXkZoneBytes = 16u << 20;   // exchange zone of the workspace (all-zero between launches), see workspace_need()
-constexpr unsigned kXkPollLimit = 1u << 22;    // polls of ~1 us before a wave gives up and traps (a slice that never came)
 
 // The way out shared by the exchange-K kernels: K parities swapped through LDS, slices exchanged through the mailboxes, finished rows
 // stored (see the header comment).  `acc`: this wave's partial sums over its K parity and its workgroup's K slice.
@@ -272,53 +272,119 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
   if constexpr (ABL & 64) ph[3] = __builtin_amdgcn_s_memrealtime();
 
   // ---- 2. the S slices of the tile swap parts through the mailboxes ----
+  // [r04] Nobody has to be co-resident any more (the r03 poll spun for ~4 s and trapped).  A wave that has
+  // polled `limit` ticks for a partner GIVES ITS PART UP: own part to its self box [dst][dst], then bit 0 of the part's state word; it
+  // stores nothing and leaves.  Every sender counts itself in the receiver's state word (+2, returning atomic) once its stores are
+  // acknowledged; the sender that finds bit 0 set and is the last of the S - 1 finishes the part from the boxes (all S of them, slice
+  // order: the same sums whoever finishes) and stores it straight from its registers.  No spinning without bound, no trap, no dependence on
+  // dispatch order; the fast path pays S - 1 atomics per wave whose answers are read after the rows have left.
   constexpr int H = HB * 16, P = H / S;       // registers a wave holds / finishes
   constexpr int GR = P >= 4 ? 4 : 2;          // registers per mailbox granule
   constexpr int NGR = P / GR;                 // granules per part
   static_assert(P >= 2 && P % GR == 0, "part size");
   float fin[P];
+  bool mine = true;
   auto flat = [&](int f) { return part[f / 16][f % 16]; };
+  const __amdgpu_buffer_rsrc_t ry_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.Y, 0, (unsigned)((size_t)a.M * (a.silu_mul ? a.N >> 1 : a.N) * 2), 0x00020000);
+  // part `ks_part` of this wave (P registers, flattened register ks_part * P + f = (block j, accumulator register r): token
+  // m0 + ((wk * HB + j) * 32 + rho), channels 128 nb + 32 wn + 8 (r / 4) + 4 h + r % 4) straight from the registers, GR channels per store
+  auto store_direct = [&](int ks_part, const float (&v)[P]) __attribute__((always_inline)) {
+    if (a.silu_mul) {   // (only where a part is whole 32-token blocks: make_plan / run_gemm)
+      if constexpr (P % 16 == 0) {
+#pragma unroll
+        for (int jj = 0; jj < P / 16; ++jj) {
+          const int m = t.m0 + ((wk * HB + (ks_part * P) / 16 + jj) * 32 + rho);
+          if (m >= a.M) continue;
+#pragma unroll
+          for (int c = 0; c < 4; c += 2) {
+            half4_t o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = silu_mul_f16((half_t)v[jj * 16 + 4 * c + r], (half_t)v[jj * 16 + 4 * c + 4 + r]);
+            const unsigned yoff = (unsigned)(((size_t)m * (a.N >> 1) + (t.nb * 64 + wn * 16 + (c >> 1) * 8 + 4 * h)) * 2);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ry_d, yoff, 0, /*sc1*/ 16);
+          }
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int g = 0; g < NGR; ++g) {
+      const int f0 = ks_part * P + g * GR;       // flattened register of v[g * GR]
+      const int j = f0 / 16, r0 = f0 % 16;
+      const int m = t.m0 + ((wk * HB + j) * 32 + rho);
+      const int n = t.nb * 128 + wn * 32 + 8 * (r0 / 4) + 4 * h + (r0 % 4);
+      if (m < a.M) {
+        half_t o[GR];
+#pragma unroll
+        for (int r = 0; r < GR; ++r) o[r] = (half_t)(v[g * GR + r] + (a.bias ? (float)a.bias[n + r] : 0.f));
+        if (a.residual) {
+#pragma unroll
+          for (int r = 0; r < GR; ++r) o[r] = (half_t)((float)o[r] + (float)a.residual[(size_t)m * a.N + n + r]);
+        }
+        const unsigned yoff = (unsigned)(((size_t)m * a.N + n) * 2);
+        if constexpr (GR == 4) {  // write-through, as the image path
+          const half4_t ov = {o[0], o[1], o[2], o[3]};
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), ry_d, yoff, 0, /*sc1*/ 16);
+        } else {
+          const half2_t ov = {o[0], o[1]};
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, ov), ry_d, yoff, 0, /*sc1*/ 16);
+        }
+      }
+    }
+  };
+  // what this slice still owes after its own rows have left: boxes and state word back to zero, parts their owners gave up
+  unsigned old_lane = 0u;   // lane q: what partner q's state word held before this slice counted itself
   if constexpr (S == 1) {
 #pragma unroll
     for (int f = 0; f < P; ++f) fin[f] = flat(f);
-  } else {
-    // mailbox [tile][dst][src < dst ? src : src - 1][wave][granule][lane] x GR * 4 bytes
-    constexpr unsigned GBYTES = GR * 4 * 64, WBYTES = NGR * GBYTES, BOX = 8 * WBYTES;
-    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.slabs, 0, kXkZoneBytes, 0x00020000);
-    const unsigned tbase = (unsigned)t.tile * (unsigned)(S * (S - 1)) * BOX + (unsigned)wave * WBYTES + (unsigned)lane * (GR * 4);
+  }
+  // mailbox [tile][dst][src (the self box at src == dst)][wave][granule][lane] x GR * 4 bytes
+  constexpr unsigned GBYTES = GR * 4 * 64, WBYTES = NGR * GBYTES, BOX = 8 * WBYTES;
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.slabs, 0, kXkZoneBytes, 0x00020000);
+  const unsigned tbase = (unsigned)t.tile * (unsigned)(S * S) * BOX + (unsigned)wave * WBYTES + (unsigned)lane * (GR * 4);
+  unsigned* state = S > 1 ? a.counters + ((unsigned)t.tile * S) * 8u + (unsigned)wave : nullptr;   // + dst * 8: state word of (tile, dst, wave)
+  constexpr int TL = S > 1 ? (S - 1) * NGR : 1;
+  unsigned so[TL];
+  bool zero_self = false;
+  int adjust = -2 * (S - 1);
+  typedef float floatx2 __attribute__((ext_vector_type(2)));
+  auto mail_store = [&](unsigned off, const float* v) __attribute__((always_inline)) {
+    if constexpr (GR == 4) xk_mail_store(rz, off, floatx4{v[0], v[1], v[2], v[3]});
+    else xk_mail_store(rz, off, v[0], v[1]);
+  };
+  auto mail_zero = [&](unsigned soff) __attribute__((always_inline)) {
+    if constexpr (GR == 4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rz, tbase, soff, 16);
+    else __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rz, tbase, soff, 16);
+  };
+  if constexpr (S > 1) {
+    const unsigned limit = 1u << (((a.xcd_gm >> 8) & 31) ? ((a.xcd_gm >> 8) & 31) : 12);   // ticks of 10 ns; default 41 us
     auto exchange = [&](auto ksc) __attribute__((always_inline)) {
       constexpr int KS = decltype(ksc)::value;
       // send: part p to slice p, negated and never -0.0 (so never the bit pattern 0): w = v + 0.0 is never -0.0, -0.0 - w is -w exactly
 #pragma unroll
       for (int p = 0; p < S; ++p) {
         if (p == KS) continue;
-        const unsigned box = tbase + (unsigned)(p * (S - 1) + (KS < p ? KS : KS - 1)) * BOX;
+        const unsigned box = tbase + (unsigned)(p * S + KS) * BOX;
 #pragma unroll
         for (int g = 0; g < NGR; ++g) {
           float v[GR];
 #pragma unroll
           for (int r = 0; r < GR; ++r) v[r] = -0.0f - (flat(p * P + g * GR + r) + 0.0f);
-          if constexpr (GR == 4) xk_mail_store(rz, box + g * GBYTES, floatx4{v[0], v[1], v[2], v[3]});
-          else xk_mail_store(rz, box + g * GBYTES, v[0], v[1]);
+          mail_store(box + g * GBYTES, v);
         }
       }
 #pragma unroll
       for (int f = 0; f < P; ++f) fin[f] = flat(KS * P + f);
       if constexpr (!(ABL & 4)) {
         // receive: ONE poll fetches the boxes of all S - 1 sources (a round trip to memory each time: polled one after the other, seven
-        // sources cost seven of them [r03 phase stamps, S = 8: 3.6 us]) and is repeated until no word of any of them is zero
-        constexpr int TL = (S - 1) * NGR;
-        typedef float floatx2 __attribute__((ext_vector_type(2)));
-        unsigned so[TL];
+        // sources cost seven of them [r03 phase stamps, S = 8: 3.6 us]) and is repeated until no word of any of them is zero -- or `limit`
 #pragma unroll
         for (int k = 0; k < TL; ++k) {
-          const int si = k / NGR, src = si < KS ? si : si + 1;   // (si: the source's index among the S - 1 boxes of this slice)
-          so[k] = (unsigned)(KS * (S - 1) + si) * BOX + (unsigned)(k % NGR) * GBYTES;
-          (void)src;
+          const int si = k / NGR, src = si < KS ? si : si + 1;
+          so[k] = (unsigned)(KS * S + src) * BOX + (unsigned)(k % NGR) * GBYTES;
         }
         float got[S - 1][P];
-        unsigned polls = 0;
-        for (;;) {
+        auto poll = [&]() {
           bool ok = true;
           if constexpr (GR == 4) {
             u32x4 q[TL];
@@ -343,28 +409,55 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
               got[k][1] = -fq[1];
             }
           }
-          if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-          if (++polls > kXkPollLimit) __builtin_trap();
+          return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+        };
+        // The first poll's wait also acknowledges the stores above (the shares are in memory); right behind it lane q counts this slice in
+        // partner q's state word -- ONE returning atomic instruction for all S - 1 partners, issued BEFORE the waiting starts so that its
+        // answer (looked at after the rows have left: did a partner give up, am I its last share?) travels while the wave polls.
+        bool ok = poll();
+        if (lane < S && lane != KS) old_lane = __hip_atomic_fetch_add(state + lane * 8, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (!ok && (unsigned)(__builtin_amdgcn_s_memrealtime() - t0) <= limit) {
           __builtin_amdgcn_s_sleep(4);
+          ok = poll();
         }
-        // hand the boxes back zeroed
+        bool finish = ok;
+        if (!ok) {
+          // give the part up: own share (encoded as the ones that travel) to the self box, then the flag bit
+          const unsigned box = tbase + (unsigned)(KS * S + KS) * BOX;
 #pragma unroll
-        for (int k = 0; k < TL; ++k) {
-          if constexpr (GR == 4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rz, tbase, so[k], 16);
-          else __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rz, tbase, so[k], 16);
-        }
-        // sum in slice order, the own part at position KS
-        float sum[P];
+          for (int g = 0; g < NGR; ++g) {
+            float v[GR];
 #pragma unroll
-        for (int src = 0; src < S; ++src) {
-#pragma unroll
-          for (int f = 0; f < P; ++f) {
-            const float v = src == KS ? fin[f] : got[src < KS ? src : src - 1][f];
-            sum[f] = src == 0 ? v : sum[f] + v;
+            for (int r = 0; r < GR; ++r) v[r] = -0.0f - (fin[g * GR + r] + 0.0f);
+            mail_store(box + g * GBYTES, v);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          unsigned o = 0u;
+          if (lane == 0) o = __hip_atomic_fetch_or(state + KS * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          o = (unsigned)__builtin_amdgcn_readfirstlane((int)o);
+          if ((int)o >> 1 == S - 1) {   // every partner counted itself meanwhile: its share was acknowledged before, it is readable now
+            (void)poll();
+            finish = true;
+            zero_self = true;
+            adjust = -2 * (S - 1) - 1;
           }
         }
+        mine = finish;
+        if (finish) {
+          // sum in slice order, the own part at position KS
+          float sum[P];
 #pragma unroll
-        for (int f = 0; f < P; ++f) fin[f] = sum[f];
+          for (int src = 0; src < S; ++src) {
+#pragma unroll
+            for (int f = 0; f < P; ++f) {
+              const float v = src == KS ? fin[f] : got[src < KS ? src : src - 1][f];
+              sum[f] = src == 0 ? v : sum[f] + v;
+            }
+          }
+#pragma unroll
+          for (int f = 0; f < P; ++f) fin[f] = sum[f];
+        }
       }
     };
     if constexpr (S == 2) {
@@ -391,37 +484,41 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
   // ---- 3. the way out.  fin[f], f = 0 .. P - 1, is flattened register ks * P + f = (block j, accumulator register r):
   //         token m0 + ((wk * HB + j) * 32 + rho), channels 128 nb + 32 wn + 8 (r / 4) + 4 h + r % 4 ----
   if constexpr (P % 16 == 0) {
-    // whole blocks: f16 image of the finished rows in LDS (row lr, 16-byte chunk q at (lr * CPR + (q ^ lr % 8)) * 16), whole rows out
+    // whole blocks: f16 image of the finished rows in LDS (row lr, 16-byte chunk q at (lr * CPR + (q ^ lr % 8)) * 16), whole rows out.
+    // A wave that gave its part up writes nothing, and its 32 channels of its blocks' rows are left to whoever finishes the part.
     constexpr int NBL = P / 16;               // blocks a wave finishes; local row block index = wk * NBL + jj
     constexpr int ROWS = 2 * NBL * 32;        // rows this workgroup finishes
     const int jb0 = (t.ks * P) / 16;          // first finished block among the wave's HB
     __syncthreads();                          // (the K-parity inboxes have been read)
+    unsigned* flags = (unsigned*)(smem + 64 * 1024);   // [wave]: this wave finished its part (the image is at most 32 KiB)
+    if (lane == 0) flags[wave] = mine ? 1u : 0u;
     auto image = [&](auto siluc) __attribute__((always_inline)) {
       constexpr bool SILU = decltype(siluc)::value != 0;
       constexpr int CPR = SILU ? 8 : 16;
       const unsigned r7 = (unsigned)rho & 7u;
+      if (mine) {
 #pragma unroll
-      for (int jj = 0; jj < NBL; ++jj) {
-        char* wrow = smem + ((wk * NBL + jj) * 32 + rho) * (CPR * 16) + h * 8;
+        for (int jj = 0; jj < NBL; ++jj) {
+          char* wrow = smem + ((wk * NBL + jj) * 32 + rho) * (CPR * 16) + h * 8;
 #pragma unroll
-        for (int c = 0; c < 4; c += SILU ? 2 : 1) {
-          const unsigned q = (unsigned)wn * (SILU ? 2 : 4) + (SILU ? c / 2 : c);
-          half4_t bv = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-          if constexpr (!SILU)
-            if (a.bias) bv = *(const half4_t*)(a.bias + t.nb * 128 + wn * 32 + 8 * c + 4 * h);
-          half4_t o;
+          for (int c = 0; c < 4; c += SILU ? 2 : 1) {
+            const unsigned q = (unsigned)wn * (SILU ? 2 : 4) + (SILU ? c / 2 : c);
+            half4_t bv = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+            if constexpr (!SILU)
+              if (a.bias) bv = *(const half4_t*)(a.bias + t.nb * 128 + wn * 32 + 8 * c + 4 * h);
+            half4_t o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if constexpr (SILU) o[r] = silu_mul_f16((half_t)fin[jj * 16 + 4 * c + r], (half_t)fin[jj * 16 + 4 * c + 4 + r]);
-            else o[r] = (half_t)(fin[jj * 16 + 4 * c + r] + (float)bv[r]);
+            for (int r = 0; r < 4; ++r) {
+              if constexpr (SILU) o[r] = silu_mul_f16((half_t)fin[jj * 16 + 4 * c + r], (half_t)fin[jj * 16 + 4 * c + 4 + r]);
+              else o[r] = (half_t)(fin[jj * 16 + 4 * c + r] + (float)bv[r]);
+            }
+            *(half4_t*)(wrow + ((q ^ r7) << 4)) = o;
           }
-          *(half4_t*)(wrow + ((q ^ r7) << 4)) = o;
         }
       }
       __syncthreads();
       const int ldy = SILU ? a.N >> 1 : a.N;
       const int q = (int)threadIdx.x % CPR;
-      half_t* ycol = a.Y + (SILU ? t.nb * 64 : t.nb * 128) + q * 8;
       const unsigned ycol0 = (unsigned)((SILU ? t.nb * 64 : t.nb * 128) + q * 8);
       const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.Y, 0, (unsigned)((size_t)a.M * ldy * 2), 0x00020000);
       const half_t* rcol = (!SILU && a.residual) ? a.residual + t.nb * 128 + q * 8 : nullptr;
@@ -432,7 +529,8 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
         half8_t v = *(const half8_t*)(smem + (lr * CPR + (q ^ (lr & 7))) * 16);
         const int blk = lr >> 5, wkk = blk / NBL, jj = blk % NBL;
         const int m = t.m0 + ((wkk * HB + jb0 + jj) * 32 + (lr & 31));
-        if (m < a.M) {
+        const bool owner_ok = flags[(q / (CPR / 4)) + 4 * wkk] != 0u;   // wave (wn = chunk's channel quarter, wk = wkk) finished these rows
+        if (m < a.M && owner_ok) {
           if (rcol) {
             const half8_t res = *(const half8_t*)(rcol + (size_t)m * a.N);
 #pragma unroll
@@ -444,7 +542,7 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
           if constexpr (!(ABL & 32768)) {  // (a buffer store the compiler knows: an asm store leaves its data registers unprotected)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, (unsigned)(((size_t)m * ldy + ycol0) * 2), 0, /*sc1*/ 16);
           } else {
-            *(half8_t*)(ycol + (size_t)m * ldy) = v;
+            *(half8_t*)(a.Y + (size_t)m * ldy + ycol0) = v;
           }
         }
       }
@@ -454,35 +552,49 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
   } else {
     // part of a block: straight from the registers, GR channels (8 or 4 bytes) per store.  (No SiLU * mul here: make_plan does not
     // route such launches to these shapes.)
+    if (mine) store_direct(t.ks, fin);
+  }
+
+  // ---- 4. after the rows: boxes and state word back to zero; parts whose owners gave up and whose last share was this slice's ----
+  if constexpr (S > 1 && !(ABL & 4)) {
+    if (mine) {
 #pragma unroll
-    for (int g = 0; g < NGR; ++g) {
-      const int f0 = t.ks * P + g * GR;       // flattened register of fin[g * GR]
-      const int j = f0 / 16, r0 = f0 % 16;
-      const int m = t.m0 + ((wk * HB + j) * 32 + rho);
-      const int n = t.nb * 128 + wn * 32 + 8 * (r0 / 4) + 4 * h + (r0 % 4);
-      if (m < a.M) {
-        float v[GR];
+      for (int k = 0; k < TL; ++k) mail_zero(so[k]);
+      if (zero_self) {
 #pragma unroll
-        for (int r = 0; r < GR; ++r) v[r] = fin[g * GR + r] + (a.bias ? (float)a.bias[n + r] : 0.f);
-        half_t o[GR];
+        for (int g = 0; g < NGR; ++g) mail_zero((unsigned)(t.ks * S + t.ks) * BOX + (unsigned)g * GBYTES);
+      }
+      if (lane == 0) (void)__hip_atomic_fetch_add(state + t.ks * 8, (unsigned)adjust, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int q = 0; q < S; ++q) {
+      if (q == t.ks) continue;
+      const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)old_lane, q);
+      if (!((o & 1u) && (int)(o >> 1) + 1 == S - 1)) continue;
+      float sum[P];
+      for (int src = 0; src < S; ++src) {   // slice order; every box is complete (its sender counted itself after its stores were acknowledged)
+        const unsigned boff = (unsigned)(q * S + src) * BOX;
 #pragma unroll
-        for (int r = 0; r < GR; ++r) o[r] = (half_t)v[r];
-        if (a.residual) {
+        for (int g = 0; g < NGR; ++g) {
+          if constexpr (GR == 4) {
+            u32x4 v[1];
+            const unsigned o1[1] = {boff + (unsigned)g * GBYTES};
+            xk_mail_load16<1>(rz, tbase, o1, v);
+            const floatx4 fq = __builtin_bit_cast(floatx4, v[0]);
 #pragma unroll
-          for (int r = 0; r < GR; ++r) o[r] = (half_t)((float)o[r] + (float)a.residual[(size_t)m * a.N + n + r]);
-        }
-        half_t* yp = a.Y + (size_t)m * a.N + n;
-        (void)yp;
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.Y, 0, (unsigned)((size_t)a.M * a.N * 2), 0x00020000);
-        const unsigned yoff = (unsigned)(((size_t)m * a.N + n) * 2);
-        if constexpr (GR == 4) {  // write-through, as the image path
-          const half4_t ov = {o[0], o[1], o[2], o[3]};
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ov), ry, yoff, 0, /*sc1*/ 16);
-        } else {
-          const half2_t ov = {o[0], o[1]};
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, ov), ry, yoff, 0, /*sc1*/ 16);
+            for (int r = 0; r < 4; ++r) sum[g * 4 + r] = src == 0 ? -fq[r] : sum[g * 4 + r] - fq[r];
+          } else {
+            u32x2 v[1];
+            const unsigned o1[1] = {boff + (unsigned)g * GBYTES};
+            xk_mail_load8<1>(rz, tbase, o1, v);
+            const floatx2 fq = __builtin_bit_cast(floatx2, v[0]);
+            sum[g * 2] = src == 0 ? -fq[0] : sum[g * 2] - fq[0];
+            sum[g * 2 + 1] = src == 0 ? -fq[1] : sum[g * 2 + 1] - fq[1];
+          }
+          mail_zero(boff + (unsigned)g * GBYTES);
         }
       }
+      if (lane == 0) __hip_atomic_store(state + q * 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      store_direct(q, sum);
     }
   }
 }

@@ -445,3 +445,26 @@ def test_gemm_forward_validates_optional_tensors():
     with pytest.raises(RuntimeError, match="GPU tensor"):
         kernels.gemm_forward(x, torch.zeros(32, 64, dtype=torch.int32), torch.zeros(1, 256, dtype=torch.float16),
                              torch.zeros(1, 32, dtype=torch.int32))
+
+
+def test_no_kernel_of_the_library_traps(tmp_path):
+    """r03's exchange-K kernels ended a wave that had polled ~4 s for a partner slice with s_trap -- a dead GPU context when a second
+    process or another stream kept the partner off the chip.  Since r04 a waiting wave gives its part up and
+    leaves, and the last slice to arrive finishes it (w4a16_xk.hpp, w4a16_xw.hpp): the shipped gfx950 code objects contain no trap."""
+    import shutil
+    import subprocess
+    from quick_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump here")
+    lib = tmp_path / "lib.so"
+    shutil.copy(_lib.LIB, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], capture_output=True, text=True, check=True)
+    objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
+    assert objs, list(tmp_path.iterdir())
+    mfma = 0
+    for o in objs:
+        text = subprocess.run([objdump, "-d", str(o)], capture_output=True, text=True, check=True).stdout
+        assert "s_trap" not in text, o.name
+        mfma += text.count("v_mfma_f32_32x32x16_f16")
+    assert mfma > 1000     # (the disassembly really is the GEMM kernels)
