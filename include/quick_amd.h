@@ -82,8 +82,12 @@ const char* quick_amd_last_error(void);
  * zone: the mailboxes through which the K slices of an exchange-K tile swap partial sums; every consumer
  * zeroes what it has read][fp32 partial tiles of the last-arriver kernels, overwritten before they are read]
  * -- so one zeroed buffer can be reused by every later call on the same stream, whatever its shape.  Do
- * not share it between streams that run concurrently.  (A launch that is aborted -- device reset, trap --
+ * not share it between streams that run concurrently.  (A launch that is aborted -- device reset --
  * may leave the first two regions dirty: zero the buffer again before reusing it.)
+ * The K slices of a tile that meet through the exchange zone (QUICK_KERNEL_XK / QUICK_KERNEL_XW launches with more than
+ * one slice) need NOT be co-resident since r04: a wave that has polled for a partner longer than the poll limit (41 us)
+ * gives its part up -- own share to its self box, a flag bit in the part's state word in the counter region -- and leaves;
+ * the last partner to arrive finishes the part from the boxes.  No kernel of the library spins without bound or traps.
  */
 int quick_w4a16_gemm_f16(const void* x, const void* qweight, const void* scales, const void* qzeros,
                          void* y, void* workspace, size_t workspace_bytes,
@@ -99,23 +103,25 @@ size_t quick_w4a16_workspace_bytes(int M, int K, int N, int group_size, int spli
  * bit field -- every field 0 = "planner's choice within the family":
  *   bits 0-3    family, QUICK_KERNEL_*
  *   bits 4-7    SKINNY: channel tiles of 16 per workgroup (1, 2, 4); TILED: token tiles of 16 per workgroup (2, 4, 8);
- *               WIDE / XK: token tiles of 32 per workgroup (WIDE 2, 4, 8; XK 2, 4)
- *   bits 8-11   SKINNY / TILED: waves per workgroup / 4; WIDE: 32-channel pairs per wave (1, 2); XK: K slices per tile (1, 2, 4, 8; 15 = half the planner's count)
- *   bit 12      SKINNY: no LDS copy of x; WIDE: the double-buffered kernel at every tile size (no ring)
+ *               WIDE / XK / XW: token tiles of 32 per workgroup (WIDE 2, 4, 8; XK 2, 4; XW 2, 4 -- 0 = 4)
+ *   bits 8-11   SKINNY / TILED: waves per workgroup / 4; WIDE: 32-channel pairs per wave (1, 2); XK: K slices per tile (1, 2, 4, 8; 15 = half
+ *               the planner's count); XW: K slices per tile (1, 2, 4 <= token tiles)
+ *   bit 12      SKINNY: no LDS copy of x; WIDE: the double-buffered kernel at every tile size (no ring); XW: 128-channel tiles (implied by 2 token tiles)
  *   bit 13      TILED: 32x32x16 MFMA flavour         bit 14  TILED / WIDE / XK: plain (not XCD-aware) tile order
  *   bit 15      TILED: 2 x 4 wave grid; WIDE: eight waves per workgroup (ring kernel)
  *   bits 16-20  timing experiments (wrong results on purpose, phase stamps): only in a QUICK_AMD_TOOLS build of the library
  *               (`python -m quick_amd.build --tools`); the product library answers QUICK_ERR_INVALID_ARGUMENT
  *   bit 21      SKINNY: flip the persistence default
- *   bits 22-24  SKINNY: persistent slots per CU; WIDE: LDS ring slots; XK: x ring slots
+ *   bits 22-24  SKINNY: persistent slots per CU; WIDE: LDS ring slots; XK: x ring slots; XW (bits 22-26): log2 of the exchange poll limit in
+ *               ticks of 10 ns (0 = default 2^12; tests pass 1: every wave gives its part up at once)
  *   bit 25      SKINNY: exact per-weight dequantisation (no deferred zero point)
  *   bits 26-28  SKINNY: 26 force the table deferred-zero path, 28 no fragment deferred-zero path; TILED: 27 force 128 x 256
  *               four-wave tiles; XK: weight queue depth in stages (3..6)
  *   bits 29-30  TILED: force / forbid 256-channel tiles
- * Environment: QUICK_AMD_EXCHANGE_CUS=<n> -- the K slices of an XK launch run on different compute units AT THE SAME TIME and poll each
- * other's mailboxes, so tiles x slices workgroups must be co-resident; the planner counts on the device's CU count.  A process whose
- * queues see fewer CUs (a CU mask) sets this to that number (0: never split K this way); otherwise such a launch would spin until
- * its poll limit traps.
+ * Environment: QUICK_AMD_EXCHANGE_CUS=<n> -- a SPEED hint since r04: the K slices of an XK launch exchange fastest when tiles x slices
+ * workgroups are co-resident, and the planner sizes the slice count for the device's CU count; a process whose queues see fewer CUs (a
+ * CU mask) may say so (0: never split K this way).  Correctness does not depend on it: slices that are not there in time are given up
+ * on and finished by the last arriver (see "workspace").  QUICK_AMD_EXCHANGE_POLL_LOG2=<n> overrides the poll limit (2^n ticks of 10 ns).
  * A combination the library has no build for returns QUICK_ERR_UNSUPPORTED; results never depend on the field
  * beyond fp32 summation order (and bit 25's rounding). */
 int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scales, const void* qzeros,
@@ -220,10 +226,12 @@ int quick_lm_head_argmax_f16(const void* x, const void* norm_weight, float eps, 
                              void* next_token, void* workspace, size_t workspace_bytes, int batch, int vocab, int hidden,
                              void* hip_stream);
 
+#ifdef QUICK_AMD_TOOLS /* only in `python -m quick_amd.build --tools` libraries (libquick_amd_tools.so) */
 /* Measurement aid (tools/prefetch_probe.py): pull [ptr, ptr + bytes) through HBM into the memory-side cache -- one
  * dword read per 128-byte line, results unused -- with `workgroups` (low 16 bits; 0 = 64) workgroups of 256 threads; bits 16..
  * choose the touch density (0 / 1: one dword per line, 2, 4, 32 = every byte).  No library path calls it. */
 int quick_prefetch(const void* ptr, size_t bytes, int workgroups, void* hip_stream);
+#endif
 
 /*
  * Format bridge.  "cuda order" is byte-for-byte what the reference's WQLinear_QUICK.from_linear

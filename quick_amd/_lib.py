@@ -32,7 +32,6 @@ _SIGNATURES = {
     "quick_decode_attention_f16": (_I, [_P] * 5 + [_I] * 5 + [ctypes.c_float, _P]),
     "quick_decode_rope_attention_f16": (_I, [_P] * 7 + [_I] * 5 + [ctypes.c_float, _P]),
     "quick_silu_mul_f16": (_I, [_P, _P, _I, _I, _P]),
-    "quick_prefetch": (_I, [_P, _Z, _I, _P]),
     "quick_lm_head_workspace_bytes": (_Z, [_I]),
     "quick_lm_head_argmax_f16": (_I, [_P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P]),
     "quick_amd_dispatch_floor": (_I, [_I, _P, _P]),
@@ -43,6 +42,7 @@ _SIGNATURES = {
     "quick_dequantize_mi355x_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
+_TOOLS_ONLY = {"quick_prefetch": (_I, [_P, _Z, _I, _P])}   # measurement aids of libquick_amd_tools.so (-DQUICK_AMD_TOOLS), absent from the product library
 
 _lib = None
 
@@ -60,6 +60,10 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
+        for name, (res, args) in _TOOLS_ONLY.items():
+            if hasattr(lib, name):
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
         if lib.quick_amd_abi_version() != 1:
             raise ImportError("libquick_amd.so ABI version mismatch; rebuild with `python -m quick_amd.build --force`")
         _lib = lib

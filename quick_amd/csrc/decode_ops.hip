@@ -793,6 +793,7 @@ int quick_lm_head_argmax_f16(const void* x, const void* norm_weight, float eps, 
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
 }
 
+#ifdef QUICK_AMD_TOOLS   // (a measurement aid of tools/prefetch_probe.py: not in the product library)
 int quick_prefetch(const void* ptr, size_t bytes, int workgroups, void* hip_stream) {
   if (!ptr || bytes < 128) return QUICK_OK;
   const int dw = workgroups >> 16;  // (probe builds: bits 16.. choose the touch density; 0 = one dword per line)
@@ -805,5 +806,6 @@ int quick_prefetch(const void* ptr, size_t bytes, int workgroups, void* hip_stre
   hipLaunchKernelGGL(k, dim3(g), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned*)ptr, lines, sink);
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
 }
+#endif
 
 }  // extern "C"

@@ -362,7 +362,7 @@ def lm_head_argmax(x, weight, norm_weight=None, eps=1e-5, want_hidden=False, wan
     B, H = x.shape
     V = weight.shape[0]
     lib = _lib.load()
-    key = (x.device.index, B)
+    key = (x.device.index, _stream(), B)   # per stream: two streams must not share the partial-key buffer
     if key not in _LM_WS:
         _LM_WS[key] = torch.empty(lib.quick_lm_head_workspace_bytes(B), dtype=torch.uint8, device=x.device)
     ws = _LM_WS[key]
