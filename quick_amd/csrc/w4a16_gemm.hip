@@ -1256,6 +1256,7 @@ struct Plan {
   bool xk_loader;      // exchange-K: the twelve-wave flavour (four loader waves; kernel bit 12)
   int xk_kq;           // exchange-K: K groups of waves per workgroup, 2 (eight waves) or 4 (sixteen; kernel bit 13)
   int poll_log2;       // XW: log2 of the ticks (10 ns) a wave waits for a partner slice before it gives its block up (0 = the kernel's default)
+  double est_us, est_xw_us;  // launch-time model: the r02 / r03 candidates' minimum, the four-wave kernels' minimum (0 = not evaluated)
 };
 
 // Where the main kernel goes: the stream, plus an optional event pair bound to that one dispatch
@@ -1504,6 +1505,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
           const double cost = xwc[c].c + xwc[c].a * n + stages * (xwc[c].b_ceil * n + xwc[c].b_frac * f) + (sx > 1 ? xwc[c].s0 + xwc[c].s1 * sx : 0.0) + xwc[c].d * f;
           if (xw_auto_mb == 0 || cost < xbest) {
             xbest = cost;
+            p.est_xw_us = cost;
             xw_auto_mb = mb;
             xw_auto_pairs = pairs;
             xw_auto_s = sx;
@@ -1511,6 +1513,12 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         }
       }
     }
+    p.est_us = best;
+    // ... unless the models say the r02 / r03 candidate is clearly ahead: on the audit's 133 four-wave picks (scripts/r04/gpu_audit_vs_r03.sh, this
+    // tree against r03's library in one session) the r03 model reads 0.95x and the four-wave model 1.03x the measured time, and "four-wave
+    // iff its estimate < 1.10 x the other" is the best threshold (geometric mean 0.904 against 0.905 for always; it returns 320 x 4096 x 12288 /
+    // 22016 -- 430 tiles of 64 x 256 against 516 of 128 x 128, a nearly empty third round -- to the r02 ring kernel: 43.5 -> 39.6 us, 82.9 -> 75.0)
+    if (xw_auto_mb && p.est_xw_us >= 1.10 * best) xw_auto_mb = 0;
     if (xw_auto_mb) p.kernel = QUICK_KERNEL_XW;
     else if (xk_auto_mb) p.kernel = QUICK_KERNEL_XK;
     else if (wide_mb) p.kernel = QUICK_KERNEL_WIDE;
@@ -2318,6 +2326,10 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
   else
     snprintf(text, text_bytes, "tiled tokens=%d channels=%d waves=%d grid=%dx%d ksplit=%d xcd_rows=%d workspace=%zu", p.mt * 16,
              p.tch, p.wn2 ? 8 : p.waves, p.ntiles, p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
+  if ((p.est_us > 0 || p.est_xw_us > 0) && getenv("QUICK_AMD_PLAN_ESTIMATES")) {   // (the launch-time models' estimates, for planner audits)
+    const size_t n = strlen(text);
+    if (n + 40 < text_bytes) snprintf(text + n, text_bytes - n, " est=%.1f est_xw=%.1f", p.est_us, p.est_xw_us);
+  }
   return QUICK_OK;
 }
 
