@@ -3,7 +3,7 @@ import json, sys, collections, glob, os, math
 d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r04")
 t = collections.defaultdict(lambda: collections.defaultdict(list))
 plan = {}
-for f in glob.glob(os.path.join(d, "audit_*_*.jsonl")):
+for f in glob.glob(os.path.join(d, "audit_*_*.jsonl")) + glob.glob(os.path.join(d, "r04_audit_r0*_lib.jsonl")):   # (gpurun_out/r04 or profiles)
     which = "r03" if "audit_r03" in f else "new"
     for l in open(f):
         if l.startswith("{"):
