@@ -59,17 +59,23 @@ def even(n): return n + (n & 1)
 
 
 class Cfg:
-    def __init__(self, MB, PAIRS, NS, KP, exp=0):
-        self.MB, self.PAIRS, self.NS, self.KP = MB, PAIRS, NS, KP
+    def __init__(self, MB, PAIRS, NS, KP, exp=0, KW=1, bar=0):
+        self.MB, self.PAIRS, self.NS, self.KP, self.KW = MB, PAIRS, NS, KP, KW
+        # bar = 1: the barrier of a stage sits in FRONT of the last super-step (whose fillers are the first reads of the next stage), so
+        # the only counted wait of a stage is "W(s + 1) has landed" (behind X(s + 1)): a load has a whole stage longer to arrive
+        self.bar = bar
         self.exp = exp   # timing experiments (tools builds, wrong results): 1 no barrier, 2 no vector memory in the loop, 4 no dequantisation, 8 no B reads
         self.MPS = MB * PAIRS
         assert self.MPS in (2, 4, 8) and NS % 2 == 0 and (KP == 1 or PAIRS == 1)
         self.SS = 8 // self.MPS            # k16 steps per super-step
-        self.NSU = 8 // self.SS            # super-steps per stage
+        self.KST = 8 // KW                 # k16 steps of a stage that are this wave's (KW = 2: those of its parity)
+        assert KW in (1, 2) and self.KST % self.SS == 0
+        self.NSU = self.KST // self.SS     # super-steps per stage
         self.NCH, self.NRD = PAIRS * self.SS, MB * self.SS
-        self.NX, self.LW = 2 * MB, 3 * PAIRS
+        self.NX, self.LW = 2 * MB, (3 if KW == 1 else 2) * PAIRS
         self.L = self.NX + self.LW
-        self.QS = even(9 * PAIRS)
+        self.QW = 8 // KW                  # packed dwords per pair and stage
+        self.QS = even((self.QW + 1) * PAIRS)
         self.SLOTB = MB * 8192
         self.G = 8 * self.NSU              # MFMAs (= gaps) per stage
         self.NACC = KP * PAIRS * MB
@@ -86,14 +92,14 @@ class Cfg:
         self.VEND = b
         assert self.VEND <= 253, self.VEND
         assert NS * self.SLOTB <= 128 * 1024
-        self.name = "%d%d" % (MB, PAIRS)
+        self.name = "%d%d%s" % (MB, PAIRS, "k" if KW == 2 else "")
 
     # registers
     def Q(self, j, what, p=0, t=0):
         base = self.VQ + self.QS * j
-        if what == "lo": return base + 8 * p + t
-        if what == "hi": return base + 8 * p + 4 + t
-        if what == "sz": return base + 8 * self.PAIRS + p
+        if what == "lo": return base + self.QW * p + t
+        if what == "hi" and self.KW == 1: return base + 8 * p + 4 + t
+        if what == "sz": return base + self.QW * self.PAIRS + p
         raise ValueError(what)
     def BF(self, b, rd): return self.VBF + (b * self.NRD + rd) * 4
     def AF(self, b, ch): return self.VAF + (b * self.NCH + ch) * 4
@@ -152,8 +158,9 @@ class Cfg:
     def w_loads(self, j):
         out = []
         for p in range(self.PAIRS):
-            out += [I(f"buffer_load_dwordx4 {v(self.Q(j, 'lo', p), 4)}, {WV}, {RSW}, {s(S_WSO[p])} offen", "vmem"),
-                    I(f"buffer_load_dwordx4 {v(self.Q(j, 'hi', p), 4)}, {WV}, {RSW}, {s(S_WSO[p])} offen offset:512", "vmem")]
+            out += [I(f"buffer_load_dwordx4 {v(self.Q(j, 'lo', p), 4)}, {WV}, {RSW}, {s(S_WSO[p])} offen", "vmem")]
+            if self.KW == 1:
+                out += [I(f"buffer_load_dwordx4 {v(self.Q(j, 'hi', p), 4)}, {WV}, {RSW}, {s(S_WSO[p])} offen offset:512", "vmem")]
         for p in range(self.PAIRS):
             out += [I(f"buffer_load_dword {v(self.Q(j, 'sz', p))}, {SV}, {RSS}, {s(S_SSO[p])} offen", "vmem")]
         return out
@@ -174,6 +181,7 @@ class Cfg:
         return out
 
     def weight_dword(self, j, p, kk):
+        if self.KW == 2: return self.Q(j, "lo", p, kk)   # (the wave's own half of the 32 bytes: wv points at it)
         return self.Q(j, "lo" if kk % 2 == 0 else "hi", p, kk >> 1)
 
     def prep(self, J, u):
@@ -238,13 +246,21 @@ class Cfg:
             for i, op in enumerate(ops):
                 extras[at(gc0) + (i * 4) // len(ops)] += [op]
         # "X(s + 2) has landed" + the barrier, then the stage counter and the next stage's load offsets
-        gb = G - 5
-        if at(gb) is not None:
-            assert issued_before(gb) == self.L
-            extras[at(gb)] += [I(f"s_waitcnt vmcnt({self.LW + (NS - 3) * self.L})", "wait"), I("s_barrier", "wait")]
-            sal = [I(f"s_add_u32 {s(S_S)}, {s(S_S)}, 1", "salu")] + self.offsets(NS - 1)
+        sal = [I(f"s_add_u32 {s(S_S)}, {s(S_S)}, 1", "salu")] + self.offsets(NS - 1)
+        if self.bar:
+            gb = G - 9
+            if at(gb) is not None:
+                extras[at(gb)] += [I("s_waitcnt lgkmcnt(0)", "wait"), I("s_barrier", "wait")]   # (nobody still reads the slot the next stage's X goes to)
             for i, op in enumerate(sal):
-                extras[at(gb) + 1 + (i * 4) // len(sal)] += [op]
+                gs = G - 8 + (i * 4) // len(sal)
+                if at(gs) is not None: extras[at(gs)] += [op]
+        else:
+            gb = G - 5
+            if at(gb) is not None:
+                assert issued_before(gb) == self.L
+                extras[at(gb)] += [I(f"s_waitcnt vmcnt({self.LW + (NS - 3) * self.L})", "wait"), I("s_barrier", "wait")]
+                for i, op in enumerate(sal):
+                    extras[at(gb) + 1 + (i * 4) // len(sal)] += [op]
         # dequantisation ops per gap
         nd = len(dq)
         if self.NRD == 4: per_gap = [2, 2, 2, 2, 4, 4, 5, 5]
@@ -277,6 +293,7 @@ class Cfg:
                 if (self.exp & 2) and (i.kind == "vmem" or t.startswith("s_waitcnt vmcnt") or t.startswith("s_add_u32 m0")): return False
                 if (self.exp & 4) and i.kind == "valu": return False
                 if (self.exp & 8) and (i.kind == "lds" or t.startswith("s_waitcnt lgkmcnt")): return False
+                if (self.exp & 16) and t.startswith("s_waitcnt vmcnt"): return False
                 return True
             out = [i for i in out if keep(i)]
         return pad_deps(out)
@@ -331,12 +348,12 @@ def build(c, stamped):
         pro += c.w_loads(q)
     pro += c.offsets(c.NS - 1)   # what stage 0 itself issues
     pro += [I(f"v_mov_b32 {v(c.VMAGIC)}, 0x64006400", "valu", [c.VMAGIC])]
-    for kk in range(8):
-        pro += [I(f"v_xor_b32 {v(c.VRA + kk)}, {kk << 5}, {XRD}", "valu", [c.VRA + kk])]
-    for kk in range(8):
+    for kk in range(c.KST):   # (KW = 2: the wave's j-th step is k16 step 2 j + parity of the stage; xrd carries the parity)
+        pro += [I(f"v_xor_b32 {v(c.VRA + kk)}, {(kk * c.KW) << 5}, {XRD}", "valu", [c.VRA + kk])]
+    for kk in range(c.KST):
         pro += [I(f"v_add_u32 {v(c.VRA2 + kk)}, 0x10000, {v(c.VRA + kk)}", "valu", [c.VRA2 + kk], [c.VRA + kk])]
     # X(0), W(0), X(1) have landed, in every wave: behind them W(1) and NS - 3 whole stages
-    pro += [I(f"s_waitcnt vmcnt({c.LW + (c.NS - 3) * c.L})", "wait"), I("s_barrier", "wait")]
+    pro += [I(f"s_waitcnt vmcnt({(c.NS - 2) * c.L if c.bar else c.LW + (c.NS - 3) * c.L})", "wait"), I("s_barrier", "wait")]
     if stamped:
         pro += [I(f"s_memrealtime s[{STAMP0}:{STAMP0 + 1}]", "salu"), I(f"s_memtime s[{CLK0}:{CLK0 + 1}]", "salu"), I("s_waitcnt lgkmcnt(0)", "wait")]
     per = [c.group_consts(c.Q(0, "sz", p), 0, p) for p in range(c.PAIRS)]
@@ -393,6 +410,12 @@ def run_macro(c):
 
 
 CONFIGS = [Cfg(4, 2, 4, 1), Cfg(4, 1, 4, 1), Cfg(2, 1, 8, 2)]
+# Tried and not kept [r04, profiles/r04_loop_variants.txt] -- the options stay in the generator for the record:
+#   Cfg(4, 2, 4, 1, KW=2)   128 x 128 tile of (4, 2)-shaped waves, the two wave pairs splitting the k16 steps of a stage by parity (half the
+#                           B reads per MFMA of (4, 1)): 40.6-41.3 clocks per MFMA, the same as (4, 1)'s 41.3-41.6 -- what the 128 x 128
+#                           tile pays for is its x traffic per MFMA (twice that of 128 x 256), not its LDS reads;
+#   bar=1                   the stage's barrier in front of the last super-step, one counted wait per stage: same time (+-0.5 %);
+#   exp=16                  no counted vector-memory waits at all (wrong results): same time -- the loops do not wait for memory.
 EXPERIMENTS = [(2, 1, 8, 2, e) for e in (1, 2, 4, 8, 15)] + [(4, 1, 4, 1, e) for e in (1, 2, 4, 8)]
 
 
@@ -408,7 +431,7 @@ def main():
         print("config (%d, %d): %d instructions, VGPRs v48..v%d, ring / queue of %d, LDS %d KiB" % (c.MB, c.PAIRS, n, c.VEND - 1, c.NS, c.NS * c.SLOTB // 1024))
     body += "#ifdef QUICK_AMD_TOOLS\n"
     for (mb, pairs, ns, kp, e) in EXPERIMENTS:
-        c = Cfg(mb, pairs, ns, kp, e)
+        c = Cfg(mb, pairs, ns, kp, e & ~64, bar=1 if e & 64 else 0)   # (64: not an omission -- the early barrier, right results)
         text, n = build(c, True)
         nm = "%s_E%d" % (c.name, e)
         body += "#define QA_XW_ASM_STAMPED_%s \\\n" % nm
