@@ -54,6 +54,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define MIXB MF(0) RD(220) V3 MF(1) RD(224) V3 MF(2) RD(228) V3 MF(3) RD(232) V3 MF(4) RD(236) V3 MF(5) RD(240) V4 MF(6) RD(244) V3 MF(7) RD(220) V4
 #define MIXC MF(0) RD(220) V6 MF(1) RD(224) V7 MF(2) RD(228) V6 MF(3) RD(232) V7 MF(4) RD(236) V6 MF(5) RD(240) V7 MF(6) RD(244) V6 MF(7) RD(220) V7
 #define MIXBA MF(0) RDA(128) V3 MF(1) RDA(132) V3 MF(2) RDA(136) V3 MF(3) RDA(140) V3 MF(4) RDA(144) V3 MF(5) RDA(148) V4 MF(6) RDA(152) V3 MF(7) RDA(156) V4
+#define V1 F_PKMUL(200)
+#define V2 F_ANDOR(202) F_PKADD(204)
+// D = 13 VALU + 4 reads per 8 MFMAs (256 x 64 per wave: a k16 step is 16 MFMAs, 26 VALU, 8 reads)
+#define MIXD MF(0) RD(220) V2 MF(1) RD(224) V1 MF(2) RD(228) V2 MF(3) RD(232) V1 MF(4) V2 MF(5) V2 MF(6) V1 MF(7) V2
 #define BODY(F, N) MF(0) FILL##N(F, 0) MF(1) FILL##N##B(F, 1) MF(2) FILL##N(F, 2) MF(3) FILL##N##B(F, 3) MF(4) FILL##N(F, 4) MF(5) FILL##N##B(F, 5) MF(6) FILL##N(F, 6) MF(7) FILL##N##B(F, 7)
 
 template <int KIND, int N>
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   half8 a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f); b[i] = (_Float16)(i * 0.01f); }
   const unsigned lds = (threadIdx.x & 63) * 16;
+  unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #define RUN(F, NN)                                                                                                                  \
   asm volatile("s_mov_b32 s40, 0x000f000f\n\ts_mov_b32 s41, 0x2c002c00\n\ts_mov_b32 s42, 0\n\tv_mov_b32 v217, 0x3c003c00\n\tv_mov_b32 v216, %[l]\n\t" \
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   else if constexpr (KIND == 21) { RUNMIX(MIXB); }
   else if constexpr (KIND == 22) { RUNMIX(MIXC); }
   else if constexpr (KIND == 23) { RUNMIX(MIXBA); }
+  else if constexpr (KIND == 24) { RUNMIX(MIXD); }
   else if constexpr (N == 0) { RUNK(0) }
   else if constexpr (N == 1) { RUNK(1) }
   else if constexpr (N == 2) { RUNK(2) }
@@ -114,10 +120,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   else if constexpr (N == 5) { RUNK(5) }
   else { RUNK(6) }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   float s = 0.f;
   for (int i = 0; i < 8; ++i) s += c[i][0];
-  if (threadIdx.x % 64 == 0) out[(blockIdx.x * 4 + threadIdx.x / 64) * 2] = t1 - t0;
-  if (s == 123.456f) out[1] = 1;
+  if (threadIdx.x % 64 == 0) {
+    out[(blockIdx.x * 4 + threadIdx.x / 64) * 2] = t1 - t0;
+    out[(blockIdx.x * 4 + threadIdx.x / 64) * 2 + 1] = r1 - r0;   // 100 MHz ticks
+  }
+  if (s == 123.456f) out[0] = 1;
 }
 
 static const char* names[] = {"v_mov_b32", "v_and_or_b32", "v_lshrrev_b32", "v_pk_add_f16", "v_pk_mul_f16", "v_pk_fma_f16(sgpr)", "v_add_f16", "v_fma_mixlo_f16",
@@ -125,17 +135,19 @@ static const char* names[] = {"v_mov_b32", "v_and_or_b32", "v_lshrrev_b32", "v_p
 
 template <int KIND, int N>
 void run(unsigned long long* d, int blocks) {
-  const int rep = 256;
+  const int rep = 512;
   std::vector<unsigned long long> h(blocks * 8);
   for (int it = 0; it < 3; ++it) {
     hipLaunchKernelGGL((bench<KIND, N>), dim3(blocks), dim3(256), 1024 * 16, 0, d, rep);
     hipDeviceSynchronize();
   }
   hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
-  double sum = 0;
-  for (int i = 0; i < blocks * 4; ++i) sum += (double)h[i * 2];
-  static const char* mixes[] = {"mix A: 26 VALU + 4 ds_read_b128 / 8 MFMA", "mix B: 26 VALU + 8 reads", "mix C: 52 VALU + 8 reads", "mix B, reads into AGPRs"};
-  printf("  %-20s N=%d: %6.2f clocks per MFMA\n", KIND >= 20 ? mixes[KIND - 20] : names[KIND], N, sum / (blocks * 4) / (rep * 8.0));
+  double sum = 0, rsum = 0;
+  for (int i = 0; i < blocks * 4; ++i) { sum += (double)h[i * 2]; rsum += (double)h[i * 2 + 1]; }
+  static const char* mixes[] = {"mix A: 26 VALU + 4 ds_read_b128 / 8 MFMA", "mix B: 26 VALU + 8 reads", "mix C: 52 VALU + 8 reads", "mix B, reads into AGPRs",
+                                "mix D: 13 VALU + 4 reads"};
+  const double clk = sum / (blocks * 4) / (rep * 8.0), ns = rsum * 10.0 / (blocks * 4) / (rep * 8.0);
+  printf("  %-20s N=%d: %6.2f clocks per MFMA  %6.2f ns per MFMA (%.3f GHz)\n", KIND >= 20 ? mixes[KIND - 20] : names[KIND], N, clk, ns, clk / ns);
 }
 template <int KIND>
 void run_all(unsigned long long* d, int blocks) {
@@ -147,7 +159,7 @@ int main(int argc, char** argv) {
   unsigned long long* d;
   hipMalloc(&d, 4096 * 8 * 8);
   printf("blocks = %d (4 waves each, one per SIMD)\n", blocks);
-  run<20, 0>(d, blocks); run<21, 0>(d, blocks); run<22, 0>(d, blocks); run<23, 0>(d, blocks);
+  run<20, 0>(d, blocks); run<21, 0>(d, blocks); run<22, 0>(d, blocks); run<23, 0>(d, blocks); run<24, 0>(d, blocks); run<0, 0>(d, blocks);
   if (argc > 2) return 0;
   run_all<0>(d, blocks); run_all<1>(d, blocks); run_all<2>(d, blocks); run_all<3>(d, blocks); run_all<4>(d, blocks); run_all<5>(d, blocks);
   run_all<6>(d, blocks); run_all<7>(d, blocks); run_all<8>(d, blocks); run_all<9>(d, blocks); run_all<10>(d, blocks); run_all<11>(d, blocks);
