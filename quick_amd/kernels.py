@@ -141,7 +141,7 @@ def _tensor_version(t):
 
 
 class _Repacked:
-    __slots__ = ("refs", "versions", "packed", "stream", "event")
+    __slots__ = ("refs", "versions", "packed", "stream", "event", "done", "seen")
 
 
 _REPACK_CACHE = {}     # (data_ptr of qweight, scales, qzeros) -> _Repacked; entries die with the tensors they mirror
@@ -164,13 +164,24 @@ def reference_to_mi355x_cached(kernel, scaling_factors, zeros):
     if ent is not None and ent.versions == versions and all(r() is t for r, t in zip(ent.refs, tensors)):
         if kernel.is_cuda:
             cur = torch.cuda.current_stream(kernel.device)
-            if cur != ent.stream:      # made on another stream: wait for the repack, and tell the allocator who else reads the copy
-                cur.wait_event(ent.event)
-                for t in ent.packed:
-                    t.record_stream(cur)
+            if cur != ent.stream and cur.cuda_stream not in ent.seen:
+                # Made on another stream.  Outside a capture: wait for the repack ONCE on the host -- from then on the copy is visible to
+                # every stream -- and tell the allocator once per stream who else reads it; later hits cost nothing.
+                # Inside a capture nothing may block: the capturing stream waits for the event, every time, until a call outside one.
+                if torch.cuda.is_current_stream_capturing():
+                    if not ent.done:
+                        cur.wait_event(ent.event)
+                else:
+                    if not ent.done:
+                        ent.event.synchronize()
+                        ent.done = True
+                    for t in ent.packed:
+                        t.record_stream(cur)
+                    ent.seen.add(cur.cuda_stream)
         return ent.packed
     ent = _Repacked()
     ent.stream = ent.event = None
+    ent.done, ent.seen = False, set()
     if kernel.shape[0] * 4 % 128 == 0:
         ent.packed = repack_cuda_to_mi355x(kernel, scaling_factors, zeros)
     else:

@@ -319,6 +319,21 @@ def test_e2e_layer_shapes_sampled_channels_against_oracle(qa, device, K, N, M):
     assert float(np.abs(got - want).max()) <= TOL * float(np.abs(want).max())
 
 
+@pytest.mark.parametrize("K,N", E2E_SHAPES[:8] + [(8192, 8192), (8192, 10240)])
+@pytest.mark.parametrize("M", [100, 192, 320, 512, 1000])
+def test_mid_token_counts_on_layer_shapes_against_oracle(qa, device, K, N, M):
+    """96..1024 tokens on the model layers: the four-wave kernels' territory since r04 (whatever the planner picks is checked; the test
+    also insists that the family it was written for still runs on at least the bench shape)."""
+    from quick_amd import kernels as K_
+    packed, x, cols, want = _random_layer_and_sampled_oracle(qa, device, M, K, N, 128, seed=K + N + M, ncols=64)
+    y = qa.gemm_forward(x, *packed)
+    got = y[:, torch.from_numpy(cols).to(device)].float().cpu().numpy()
+    assert float(np.abs(got - want).max()) <= TOL * float(np.abs(want).max())
+    assert torch.equal(y, qa.gemm_forward(x, *packed))                     # bit-identical run to run, exchange or not
+    if (M, K, N) == (512, 4096, 4096):
+        assert K_.plan_describe(M, K, N, 128, 0).startswith("xw ")
+
+
 @pytest.mark.parametrize("kernel_id", [0, TILED, WIDE, wide(4, 2), wide(8, 2)], ids=["auto", "tiled", "wide", "wide128x256", "wide256x256"])
 @pytest.mark.parametrize("M,K,N", [(128, 4096, 12288), (2048, 4096, 12288), (8192, 4096, 6144), (2048, 8192, 10240), (1024, 11008, 4096)])
 def test_prefill_shapes_sampled_channels_against_oracle(qa, device, M, K, N, kernel_id):
@@ -448,6 +463,43 @@ def test_function_level_drop_in_takes_reference_order_tensors(qa, device, path):
     import gc
     gc.collect()
     assert key not in K_._REPACK_CACHE
+
+
+def test_function_level_drop_in_cache_hits_from_other_streams(qa, device):
+    """The cached MI355X-order copy is made on one stream and hit from others: the first eager hit from another stream waits
+    for the repack once, on the host, and later hits from that stream neither wait nor record anything; a hit inside a graph capture on a
+    third stream must be capturable and replay to the same numbers."""
+    import quick_kernels
+    from quick_amd import kernels as K_
+    M, K, N, G = 5, 1024, 512, 128
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=41)
+    ref = [_dev(a, device) for a in oracle.pack_cuda_order(iw, s, z)]
+    xd = _dev(x, device)
+    want = oracle.w4a16_forward(x, iw, s, z, G)
+    maker, other, third = (torch.cuda.Stream(device) for _ in range(3))
+    with torch.cuda.stream(maker):
+        y0 = quick_kernels.gemm_forward_cuda_quick(xd, *ref, 8)
+    ent = K_._REPACK_CACHE[tuple(t.data_ptr() for t in ref)]
+    assert ent.stream == maker and not ent.done
+    with torch.cuda.stream(other):
+        y1 = quick_kernels.gemm_forward_cuda_quick(xd, *ref, 8)
+        assert ent.done and other.cuda_stream in ent.seen
+        seen = set(ent.seen)
+        y2 = quick_kernels.gemm_forward_cuda_quick(xd, *ref, 8)
+        assert ent.seen == seen
+    torch.cuda.synchronize()
+    for y in (y0, y1, y2):
+        assert rel_err(y.cpu().numpy(), want) <= TOL
+    assert torch.equal(y0, y1) and torch.equal(y1, y2)
+    g = torch.cuda.CUDAGraph()
+    static_x = xd.clone()
+    with torch.cuda.stream(third):
+        with torch.cuda.graph(g, stream=third):
+            static_y = quick_kernels.gemm_forward_cuda_quick(static_x, *ref, 8)
+    static_x.copy_(xd * 2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert rel_err(static_y.cpu().numpy(), want.astype(np.float32) * 2) <= TOL
 
 
 @pytest.mark.parametrize("M,K,N,G", [(1, 96, 128, 32), (7, 320, 256, 64), (40, 192, 128, 96), (130, 1056, 384, 32), (16, 4160, 512, 64)])
