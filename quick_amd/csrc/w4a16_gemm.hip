@@ -1513,6 +1513,21 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         }
       }
     }
+    // [r04] where the r02 model's pick is the 256 x 256 tile with ONE K slice, the four-wave kernel with the generated 256 x 256 loop runs it
+    // instead: 0.935-0.965 of the hipcc-scheduled kernel's time on 28 prefill shapes of 1024..8192 tokens in one session, bit-identical
+    // results (scripts/r04/gpu_xw82.sh, profiles/r04_xw256_sweep.jsonl; 4096^3 117.3 -> 111.6 us, 8192 x 4096 x 22016 1232 -> 1170).
+    // QUICK_AMD_XW256=0 keeps r02's kernel (the A/B switch).
+    if (best > 0 && wide_mb == 8 && !xw_auto_mb && !xk_auto_mb && N % 256 == 0 && (G / 128 & (G / 128 - 1)) == 0 && KT >= 2 &&
+        wide_split((long)((M + 255) / 256) * (N / 256)) == 1 &&
+        (size_t)M * (size_t)K * 2 < ((size_t)1 << 32) && (size_t)M * (size_t)N * 2 < ((size_t)1 << 32)) {
+      const char* e = getenv("QUICK_AMD_XW256");
+      if (!e || atoi(e) != 0) {
+        xw_auto_mb = 8;
+        xw_auto_pairs = 2;
+        xw_auto_s = 1;
+        p.est_xw_us = 0.95 * best;
+      }
+    }
     p.est_us = best;
     // ... unless the models say the r02 / r03 candidate is clearly ahead: on the audit's 133 four-wave picks (scripts/r04/gpu_audit_vs_r03.sh, this
     // tree against r03's library in one session) the r03 model reads 0.95x and the four-wave model 1.03x the measured time, and "four-wave
@@ -1554,7 +1569,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // but the exchange zone holds S * S boxes of (a tile's fp16 image / S) per tile: workgroups <= 256 with S > 1.
     // bits 4-7: 32-token blocks per tile (2, 4; 0 = 4); bit 12: 128-channel tiles (implied by 2 blocks); bits 8-11: S (0 = as many as fit
     // the CUs); bits 22-26: log2 of the poll limit in ticks of 10 ns (tests: 1 = every wave gives up at once).
-    const int mb = xw_auto_mb ? xw_auto_mb : (mt_req == 2 ? 2 : 4), pairs = xw_auto_mb ? xw_auto_pairs : ((mb == 2 || no_xlds) ? 1 : 2);
+    // (bits 4-7 = 8: the 256 x 256 tile -- waves of 256 tokens x 64 channels, a ring of two 64 KiB slots, one slice only)
+    const int mb = xw_auto_mb ? xw_auto_mb : (mt_req == 2 ? 2 : (mt_req == 8 ? 8 : 4)), pairs = xw_auto_mb ? xw_auto_pairs : (mb == 8 ? 2 : ((mb == 2 || no_xlds) ? 1 : 2));
     const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / (pairs * 128);
     p.wide_mb = mb;
     p.wide_pairs = pairs;
@@ -1563,7 +1579,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     p.ntiles = MBk * NBk;
     const int s_req = xw_auto_s ? xw_auto_s : (grid_split_k > 0 ? grid_split_k : (kernel >> 8) & 15);
     int s = 1;
-    if (s_req == 1 || s_req == 2 || (s_req == 4 && mb == 4)) s = s_req;
+    if (mb == 8) s = 1;
+    else if (s_req == 1 || s_req == 2 || (s_req == 4 && mb == 4)) s = s_req;
     else
       while (s < mb && s < 4 && (long)p.ntiles * s * 2 <= cu_count() && KT / (s * 2) >= 4) s *= 2;
     while (s > 1 && ((long)p.ntiles * s > 256 || (KT + (KT + s - 1) / s - 1) / ((KT + s - 1) / s) != s)) s /= 2;
@@ -2316,7 +2333,7 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
              (M + 15) / 16, p.ksplit, p.ksplit, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_XW)
     snprintf(text, text_bytes, "xw tokens=%d channels=%d waves=4 ring=%d queue=%d grid=%d slices=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32, p.tch,
-             p.wide_mb == 2 ? 8 : 4, p.wide_mb == 2 ? 8 : 4, p.ntiles * p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
+             p.wide_mb == 2 ? 8 : (p.wide_mb == 8 ? 2 : 4), p.wide_mb == 2 ? 8 : (p.wide_mb == 8 ? 2 : 4), p.ntiles * p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));
   else if (p.kernel == QUICK_KERNEL_XK)
     snprintf(text, text_bytes, "xk tokens=%d channels=128 waves=%d ring=%d queue=%d grid=%d slices=%d xcd_rows=%d workspace=%zu", p.wide_mb * 32,
              p.xk_loader ? 12 : (p.xk_kq == 4 ? 16 : 8), p.xk_loader ? 3 : p.xk_nbuf, p.xk_loader ? 5 : p.xk_wd, p.ntiles * p.ksplit, p.ksplit, p.xcd_gm, workspace_need(p));

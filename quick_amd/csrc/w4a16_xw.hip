@@ -40,6 +40,7 @@ static bool xw_go_s(int s, const GemmArgs& a, int workgroups, hipStream_t st, hi
 
 template <int ABL>
 static bool xw_go_t(int mb, int pairs, int s, const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+  if (mb == 8 && pairs == 2) return s == 1 ? xw_go<8, 2, 1, ABL>(a, workgroups, st, start, stop) : false;
   if (mb == 4 && pairs == 2) return xw_go_s<4, 2, ABL>(s, a, workgroups, st, start, stop);
   if (mb == 4 && pairs == 1) return xw_go_s<4, 1, ABL>(s, a, workgroups, st, start, stop);
   if (mb == 2 && pairs == 1) return xw_go_s<2, 1, ABL>(s, a, workgroups, st, start, stop);

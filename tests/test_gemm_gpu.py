@@ -1167,14 +1167,15 @@ XW = 5
 
 
 def xw(mb, pairs, s=0, poll_log2=0):
-    return XW | ((mb << 4) if mb == 2 else 0) | ((1 << 12) if pairs == 1 else 0) | (s << 8) | (poll_log2 << 22)
+    return XW | ((mb << 4) if mb != 4 else 0) | ((1 << 12) if pairs == 1 else 0) | (s << 8) | (poll_log2 << 22)
 
 
-XW_TILES = [(4, 2), (4, 1), (2, 1)]
+XW_TILES = [(4, 2), (4, 1), (2, 1), (8, 2)]
+XW_IDS = ["128x256", "128x128", "64x128", "256x256"]
 
 
 @pytest.mark.parametrize("S", [1, 2, 4])
-@pytest.mark.parametrize("mb,pairs", XW_TILES, ids=["128x256", "128x128", "64x128"])
+@pytest.mark.parametrize("mb,pairs", XW_TILES, ids=XW_IDS)
 @pytest.mark.parametrize("M,K,N,G", [(300, 512, 512, 128), (77, 1152, 768, 128), (1, 1024, 1024, 128), (513, 1024, 256, 128),
                                      (64, 2048, 512, 128), (130, 4096, 256, 256), (40, 1536, 256, 512), (128, 128, 256, 128)])
 def test_xw_family_against_oracle(qa, device, M, K, N, G, mb, pairs, S):
@@ -1183,8 +1184,8 @@ def test_xw_family_against_oracle(qa, device, M, K, N, G, mb, pairs, S):
     taken in slice order over the same fp16-rounded parts: no dependence on timing) -- and once more with a poll limit of two ticks, where
     every wave gives its block up at once and the LAST partner to arrive finishes it from the boxes: bit for bit the same result."""
     from quick_amd import kernels as K_
-    if S > mb:
-        pytest.skip("whole 32-token blocks per slice")
+    if S > mb or (mb == 8 and S > 1):
+        pytest.skip("whole 32-token blocks per slice; the 256 x 256 tile runs one slice")
     kid = xw(mb, pairs, S)
     plan = K_.plan_describe(M, K, N, G, kid)
     assert plan.startswith("xw"), plan
@@ -1209,7 +1210,7 @@ def test_xw_family_against_oracle(qa, device, M, K, N, G, mb, pairs, S):
     assert torch.equal(y_act, qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=xw(mb, pairs, S, poll_log2=1))), plan
 
 
-@pytest.mark.parametrize("mb,pairs", XW_TILES, ids=["128x256", "128x128", "64x128"])
+@pytest.mark.parametrize("mb,pairs", XW_TILES, ids=XW_IDS)
 def test_xw_golden_fixtures_and_reference_pin(qa, device, pin, mb, pairs):
     """The reference-made fixtures end to end (reference-format checkpoint -> HIP repack -> the four-wave kernels), and the 4096 x 4096 pin
     of the reference packer / CPU path at the bench's token counts (the fixture's 16 rows repeated), one slice and as many as fit."""
@@ -1231,6 +1232,29 @@ def test_xw_golden_fixtures_and_reference_pin(qa, device, pin, mb, pairs):
             for rep in (0, M // 16 - 1):
                 assert float(np.abs(y[g["y_rows"] + 16 * rep, g["y_cols"]] - ref).max()) <= TOL * float(np.abs(ref).max())
             assert float(np.abs(np.abs(y).sum(0) - g["col_abs_sum"] * (M // 16)).max()) <= TOL * float(g["col_abs_sum"].max()) * (M // 16)
+
+
+@pytest.mark.parametrize("M,K,N,G", [(256, 256, 256, 128), (129, 384, 512, 128), (1000, 1024, 768, 128), (2049, 384, 512, 128), (4100, 1280, 1024, 256),
+                                     (300, 128, 256, 128)])
+def test_xw_256x256_tile_equals_the_r02_kernel_bit_for_bit(qa, device, M, K, N, G):
+    """The generated 256 x 256 loop (waves of 256 tokens x 64 channels, ring of two slots) sums every output in the same k order as r02's
+    hipcc-scheduled 256 x 256 kernel: equal bits, whatever the token count does to the two 128-row halves of the way out (rows past M in
+    the first half only, in the second, a whole half missing), several tiles per XCD, one- to nine-stage K (the r02 kernel pinned to one K slice: its split launches add fp32 slabs); and against the oracle."""
+    from quick_amd import kernels as K_
+    kid = xw(8, 2, 1)
+    assert K_.plan_describe(M, K, N, G, kid).startswith("xw tokens=256 channels=256")
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + K + N + G)
+    want = oracle.w4a16_forward(x, iw, s, z, G).astype(np.float32)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device)
+    y = qa.gemm_forward(xd, *packed, kernel_id=kid)
+    assert rel_err(y.cpu().numpy(), want) <= TOL
+    assert torch.equal(y, qa.gemm_forward(xd, *packed, kernel_id=wide(8, 2) | WIDE_NORING, grid_split_k=1))
+    bias = torch.linspace(-1, 1, N, device=device).half()
+    res = torch.randn(M, N, device=device).half()
+    assert torch.equal(qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=kid),
+                       qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=wide(8, 2) | WIDE_NORING, grid_split_k=1))
+    assert torch.equal(qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kid), qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=wide(8, 2) | WIDE_NORING, grid_split_k=1))
 
 
 def test_xw_exchange_when_partners_are_not_there(qa, device):

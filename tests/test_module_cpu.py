@@ -231,8 +231,15 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(1024, 4096, 4096).startswith("xw tokens=128 channels=128 waves=4 ring=4 queue=4 grid=256 slices=1")   # 256 tiles of 128 x 128: one round, nothing to exchange
     assert "slices=2" in plan(512, 11008, 4096) and "xw tokens=128 channels=128" in plan(512, 11008, 4096)            # 128 tiles x 2 slices of 43 stages
     assert plan(96, 4096, 22016).startswith("xw tokens=128 channels=128") and plan(96, 4096, 4096).startswith("xk")   # below 160 tokens only on wide layers
-    assert plan(2048, 3584, 18944).startswith("wide")                                                  # several rounds: the 256 x 256 tile of the wide family
-    assert plan(2048, 4096, 4096).startswith("xw tokens=128 channels=256") and "wide tokens=256 channels=256" in plan(8192, 4096, 22016)
+    assert plan(2048, 3584, 18944).startswith("xw tokens=256 channels=256")                            # several rounds: the 256 x 256 tile, since r04 with the generated loop
+    assert plan(2048, 4096, 4096).startswith("xw tokens=128 channels=256") and "xw tokens=256 channels=256 waves=4 ring=2 queue=2 grid=2752 slices=1" in plan(8192, 4096, 22016)
+    assert plan(1024, 28672, 8192).startswith("wide tokens=256 channels=256") and "ksplit=2" in plan(1024, 28672, 8192)   # 128 tiles x 2 K slices: r02's kernel keeps the split launches
+    os.environ["QUICK_AMD_XW256"] = "0"
+    try:
+        assert plan(4096, 4096, 4096).startswith("wide tokens=256 channels=256")                       # (the A/B switch)
+    finally:
+        del os.environ["QUICK_AMD_XW256"]
+    assert plan(4096, 4096, 4096).startswith("xw tokens=256 channels=256 waves=4 ring=2 queue=2 grid=256 slices=1")
     assert plan(384, 4096, 12288).startswith("xw tokens=128 channels=256 waves=4 ring=4 queue=4 grid=144 slices=1")   # 41.6 us (r03's 128 x 256 wide tile: 51.2)
     assert plan(512, 4096, 4096, kernel_id=kernels.KERNEL_XW).startswith("xw tokens=128 channels=256") and "slices=4" in plan(512, 4096, 4096, kernel_id=kernels.KERNEL_XW)
     assert not plan(512, 4608, 4096, G=384).startswith("xw") and not plan(512, 4608, 4096, G=384, kernel_id=kernels.KERNEL_XW).startswith("xw")  # G / 128 must be a power of two

@@ -42,6 +42,7 @@ S_S, S_N, S_KT, S_XSO, S_KTMAX, S_G, S_KTLO = 57, 58, 59, 60, 65, 66, 67
 S_WSO = [61, 62]
 S_SSO = [63, 64]
 STAMP0, STAMP1, S_TPG, CLK0, CLK1 = 68, 70, 72, 74, 76
+S_KTHI, S_WPS, S_SPS, S_K2 = 78, 79, 80, 81     # (256-token tiles: end k tile, pair strides and the row pitch of x, derived from the k tile count)
 RSX, RSW, RSS = "%[rsx]", "%[rsw]", "%[rss]"
 WV, SV, XRD, XDST, KTLO, KTHI, WPS, SPS = "%[wv]", "%[sv]", "%[xrd]", "%[xdst]", "%[ktlo]", "%[kthi]", "%[wps]", "%[sps]"
 
@@ -66,8 +67,11 @@ class Cfg:
         self.bar = bar
         self.exp = exp   # timing experiments (tools builds, wrong results): 1 no barrier, 2 no vector memory in the loop, 4 no dequantisation, 8 no B reads
         self.MPS = MB * PAIRS
-        assert self.MPS in (2, 4, 8) and NS % 2 == 0 and (KP == 1 or PAIRS == 1)
-        self.SS = 8 // self.MPS            # k16 steps per super-step
+        assert self.MPS in (2, 4, 8, 16) and NS % 2 == 0 and (KP == 1 or PAIRS == 1)
+        self.SSM = max(8, self.MPS)        # MFMAs per super-step
+        self.SS = self.SSM // self.MPS     # k16 steps per super-step
+        self.big = MB == 8                 # 256-token tiles: ring of TWO 64 KiB slots (needs bar = 1), x piece offsets in registers
+        assert not self.big or (NS == 2 and bar == 1 and KW == 1)
         self.KST = 8 // KW                 # k16 steps of a stage that are this wave's (KW = 2: those of its parity)
         assert KW in (1, 2) and self.KST % self.SS == 0
         self.NSU = self.KST // self.SS     # super-steps per stage
@@ -77,7 +81,7 @@ class Cfg:
         self.QW = 8 // KW                  # packed dwords per pair and stage
         self.QS = even((self.QW + 1) * PAIRS)
         self.SLOTB = MB * 8192
-        self.G = 8 * self.NSU              # MFMAs (= gaps) per stage
+        self.G = self.SSM * self.NSU       # MFMAs (= gaps) per stage
         self.NACC = KP * PAIRS * MB
         b = 48
         self.VQ = b; b += NS * self.QS
@@ -89,6 +93,7 @@ class Cfg:
         self.VRA = b; b += 8
         self.VRA2 = b; b += 8
         self.VMAGIC = b; b += 1
+        self.VX = b; b += (self.NX + 1 if self.big else 0)   # byte offsets of the x pieces (rows clamped to M - 1) + a temporary
         self.VEND = b
         assert self.VEND <= 253, self.VEND
         assert NS * self.SLOTB <= 128 * 1024
@@ -153,7 +158,7 @@ class Cfg:
     def x_piece(self, i, slot, pad=False):
         """M0 <- LDS destination of piece i in `slot`, then the LDS-DMA (1 KiB: 4 token rows x 256 B); one wait state between the two"""
         return ([I(f"s_add_u32 m0, {XDST}, {slot * self.SLOTB + i * 4096}", "salu", ["m0"], [])] + ([I("s_nop 0", "salu")] if pad else []) +
-                [I(f"buffer_load_dwordx4 {self.XV(i)}, {RSX}, {s(S_XSO)} offen lds", "vmem", [], ["m0"])])
+                [I(f"buffer_load_dwordx4 {v(self.VX + i) if self.big else self.XV(i)}, {RSX}, {s(S_XSO)} offen lds", "vmem", [], ["m0"])])
 
     def w_loads(self, j):
         out = []
@@ -177,7 +182,8 @@ class Cfg:
             I(f"s_lshl_b32 {s(S_SSO[0])}, {s(S_G)}, 6", "salu"),
         ]
         if self.PAIRS == 2:
-            out += [I(f"s_add_u32 {s(S_WSO[1])}, {s(S_WSO[0])}, {WPS}", "salu"), I(f"s_add_u32 {s(S_SSO[1])}, {s(S_SSO[0])}, {SPS}", "salu")]
+            wps, sps = (s(S_WPS), s(S_SPS)) if self.big else (WPS, SPS)
+            out += [I(f"s_add_u32 {s(S_WSO[1])}, {s(S_WSO[0])}, {wps}", "salu"), I(f"s_add_u32 {s(S_SSO[1])}, {s(S_SSO[0])}, {sps}", "salu")]
         return out
 
     def weight_dword(self, j, p, kk):
@@ -201,17 +207,17 @@ class Cfg:
         return reads, dq
 
     def superstep(self, J, u, peel=False):
-        """the 8 MFMAs of super-step u of stage J, each followed by its fillers"""
-        G, NS = self.G, self.NS
+        """the SSM MFMAs of super-step u of stage J, each followed by its fillers"""
+        G, NS, SSM = self.G, self.NS, self.SSM
         last = u == self.NSU - 1
         nJ, nu = ((J + 1) % NS, 0) if last else (J, u + 1)
         reads, dq = self.prep(nJ, nu)
         buf = u % 2
-        extras = [[] for _ in range(8)]
-        pre = [[] for _ in range(8)]     # placed in front of the gap's dequantisation ops (waits)
-        base = u * 8                     # stage gap index of this super-step's gap 0
+        extras = [[] for _ in range(SSM)]
+        pre = [[] for _ in range(SSM)]   # placed in front of the gap's dequantisation ops (waits)
+        base = u * SSM                   # stage gap index of this super-step's gap 0
         def at(gs):                      # local gap of stage gap gs, or None
-            return gs - base if base <= gs < base + 8 else None
+            return gs - base if base <= gs < base + SSM else None
         # X(s + NS - 1): piece i, M0 at stage gap gx, DMA at gx + 1, into the slot stage s - 1 released
         xs = (J + NS - 1) % NS
         for i in range(self.NX):
@@ -233,7 +239,7 @@ class Cfg:
                 if G // 2 + (j * (G // 4)) // self.LW < g: n += 1
             return n
         # the next stage's group constants in the four gaps before the last super-step, behind "W(s + 1) has landed"
-        gc0 = G - 12
+        gc0 = G - SSM - 4
         if at(gc0) is not None:
             nxt = (J + 1) % NS
             cnt = (NS - 3) * self.L + issued_before(gc0)
@@ -248,11 +254,11 @@ class Cfg:
         # "X(s + 2) has landed" + the barrier, then the stage counter and the next stage's load offsets
         sal = [I(f"s_add_u32 {s(S_S)}, {s(S_S)}, 1", "salu")] + self.offsets(NS - 1)
         if self.bar:
-            gb = G - 9
+            gb = G - SSM - 1
             if at(gb) is not None:
                 extras[at(gb)] += [I("s_waitcnt lgkmcnt(0)", "wait"), I("s_barrier", "wait")]   # (nobody still reads the slot the next stage's X goes to)
             for i, op in enumerate(sal):
-                gs = G - 8 + (i * 4) // len(sal)
+                gs = G - SSM + (i * 4) // len(sal)
                 if at(gs) is not None: extras[at(gs)] += [op]
         else:
             gb = G - 5
@@ -263,12 +269,13 @@ class Cfg:
                     extras[at(gb) + 1 + (i * 4) // len(sal)] += [op]
         # dequantisation ops per gap
         nd = len(dq)
-        if self.NRD == 4: per_gap = [2, 2, 2, 2, 4, 4, 5, 5]
+        if SSM == 16: per_gap = [1] * 8 + [2, 2, 2, 2, 2, 3, 3, 2]
+        elif self.NRD == 4: per_gap = [2, 2, 2, 2, 4, 4, 5, 5]
         elif nd == 26: per_gap = [3, 3, 3, 3, 3, 3, 4, 4]
         else: per_gap = [6, 6, 6, 6, 7, 7, 7, 7]
         assert sum(per_gap) == nd
         out, di, waited, zeroed = [], 0, -1, set()
-        for g in range(8):
+        for g in range(SSM):
             st, gi = g // self.MPS, g % self.MPS
             p, mt = gi // self.MB, gi % self.MB
             kk = u * self.SS + st
@@ -339,8 +346,21 @@ def build(c, stamped):
     pro = [I(f"s_mov_b32 {s(S_MLO)}, 0x000f000f", "salu"), I(f"s_mov_b32 {s(S_MHI)}, 0x00f000f0", "salu"),
            I(f"s_mov_b32 {s(S_SIXT)}, 0x2c002c00", "salu"), I(f"s_mov_b32 {s(S_D400)}, 0xd400d400", "salu"),
            I(f"s_mov_b32 {s(S_PERM)}, 0x01000100", "salu"), I(f"s_mov_b32 {s(S_S)}, 0", "salu"),
-           I(f"s_lshr_b32 {s(S_TPG)}, {KTLO}, 24", "salu"), I(f"s_and_b32 {s(S_KTLO)}, {KTLO}, 0xffffff", "salu"),
-           I(f"s_sub_u32 {s(S_N)}, {KTHI}, {s(S_KTLO)}", "salu"), I(f"s_sub_u32 {s(S_KTMAX)}, {KTHI}, 1", "salu")]
+           I(f"s_lshr_b32 {s(S_TPG)}, {KTLO}, 24", "salu"), I(f"s_and_b32 {s(S_KTLO)}, {KTLO}, 0xffffff", "salu")]
+    kthi = KTHI
+    if c.big:
+        # the operand list is at clang's limit of 30: the k tile count rides in the upper half of kthi, and the pair strides of the weights
+        # and group words and the row pitch of x are derived from it; the x piece offsets (rows clamped to M - 1) are made here, once
+        kthi = s(S_KTHI)
+        pro += [I(f"s_and_b32 {s(S_KTHI)}, {KTHI}, 0xffff", "salu"), I(f"s_lshr_b32 {s(S_K2)}, {KTHI}, 16", "salu"),
+                I(f"s_lshl_b32 {s(S_WPS)}, {s(S_K2)}, 11", "salu"), I(f"s_lshr_b32 {s(S_SPS)}, {s(S_K2)}, {s(S_TPG)}", "salu"),
+                I(f"s_lshl_b32 {s(S_SPS)}, {s(S_SPS)}, 7", "salu"), I(f"s_lshl_b32 {s(S_K2)}, {s(S_K2)}, 8", "salu")]
+        t = c.VX + c.NX
+        for i in range(c.NX):
+            pro += [I(f"v_add_u32 {v(t)}, {16 * i}, %[xr]", "valu", [t]),
+                    I(f"v_min_u32 {v(t)}, %[mlast], {v(t)}", "valu", [t], [t]),
+                    I(f"v_mad_u32_u24 {v(c.VX + i)}, {v(t)}, {s(S_K2)}, %[xc]", "valu", [c.VX + i], [t])]
+    pro += [I(f"s_sub_u32 {s(S_N)}, {kthi}, {s(S_KTLO)}", "salu"), I(f"s_sub_u32 {s(S_KTMAX)}, {kthi}, 1", "salu")]
     # the ring and the queue as NS - 1 stages of the steady state would have left them: X(q) W(q), q = 0 .. NS - 2
     for q in range(c.NS - 1):
         pro += c.offsets(q)
@@ -391,25 +411,32 @@ def build(c, stamped):
     text += '  "s_waitcnt vmcnt(0) lgkmcnt(0)\\n\\t"\n'
     if stamped:
         text += '  "s_mov_b64 %%[t0], s[%d:%d]\\n\\t"\n  "s_mov_b64 %%[t1], s[%d:%d]\\n\\t"\n' % (STAMP0, STAMP0 + 1, STAMP1, STAMP1 + 1)
-        text += '  "s_sub_u32 %%[clk], s%d, s%d\\n\\t"\n' % (CLK1, CLK0)
+        if not c.big:
+            text += '  "s_sub_u32 %%[clk], s%d, s%d\\n\\t"\n' % (CLK1, CLK0)
     text += '  "s_nop 15\\n\\t"\n  "s_nop 7"\n'   # the last MFMAs' results -> whoever reads the accumulators next
     return text, nins
 
 
 def run_macro(c):
-    """the whole asm statement: names of the kernel's variables (accr[], b, xrd, xdst, kt_lo, kt_hi; stamped: t0, t1, clk)"""
+    """the whole asm statement: names of the kernel's variables (accr[], b, xrd, xdst, kt_lo, kt_hi; stamped: t0, t1, clk; 256-token tiles:
+    xr = first row of the lane's piece 0, xc = its swizzled 16-byte chunk, kt_hi carries K / 128 in its upper half, m_last = M - 1)"""
     outs = ", ".join('[a%d] "=&a"(accr[%d])' % (i, i) for i in range(c.NACC))
-    ins = ['[rsx] "s"(b.x)', '[rsw] "s"(b.w)', '[rss] "s"(b.s)'] + ['[xv%d] "v"(b.x_voff[%d])' % (i, i) for i in range(c.NX)]
-    ins += ['[wv] "v"(b.w_voff)', '[sv] "v"(b.s_voff)', '[xrd] "v"(xrd)', '[xdst] "s"(xdst)', '[ktlo] "s"(kt_lo)', '[kthi] "s"(kt_hi)',
-            '[wps] "s"(b.w_pstride)', '[sps] "s"(b.s_pstride)']
-    cl = ['"memory"', '"scc"'] + ['"v%d"' % r for r in range(48, c.VEND)] + ['"s%d"' % r for r in range(52, 78)]
+    ins = ['[rsx] "s"(b.x)', '[rsw] "s"(b.w)', '[rss] "s"(b.s)']
+    if c.big:
+        ins += ['[xr] "v"(xr)', '[xc] "v"(xc)']
+    else:
+        ins += ['[xv%d] "v"(b.x_voff[%d])' % (i, i) for i in range(c.NX)]
+    ins += ['[wv] "v"(b.w_voff)', '[sv] "v"(b.s_voff)', '[xrd] "v"(xrd)', '[xdst] "s"(xdst)', '[ktlo] "s"(kt_lo)', '[kthi] "s"(kt_hi)']
+    ins += ['[mlast] "s"(m_last)'] if c.big else ['[wps] "s"(b.w_pstride)', '[sps] "s"(b.s_pstride)']
+    cl = ['"memory"', '"scc"'] + ['"v%d"' % r for r in range(48, c.VEND)] + ['"s%d"' % r for r in range(52, 82 if c.big else 78)]
+    stamps = '[t0] "=&s"(t0), [t1] "=&s"(t1)' + ('' if c.big else ', [clk] "=&s"(clk)')
     body = "#define QA_XW_RUN_%s() asm volatile(QA_XW_ASM_%s : %s : %s : %s)\n" % (c.name, c.name, outs, ", ".join(ins), ", ".join(cl))
-    body += ("#define QA_XW_RUN_STAMPED_%s() asm volatile(QA_XW_ASM_STAMPED_%s : %s, [t0] \"=&s\"(t0), [t1] \"=&s\"(t1), [clk] \"=&s\"(clk) : %s : %s)\n"
-             % (c.name, c.name, outs, ", ".join(ins), ", ".join(cl)))
+    body += ("#define QA_XW_RUN_STAMPED_%s() asm volatile(QA_XW_ASM_STAMPED_%s : %s, %s : %s : %s)\n"
+             % (c.name, c.name, outs, stamps, ", ".join(ins), ", ".join(cl)))
     return body
 
 
-CONFIGS = [Cfg(4, 2, 4, 1), Cfg(4, 1, 4, 1), Cfg(2, 1, 8, 2)]
+CONFIGS = [Cfg(4, 2, 4, 1), Cfg(4, 1, 4, 1), Cfg(2, 1, 8, 2), Cfg(8, 2, 2, 1, bar=1)]
 # Tried and not kept [r04, profiles/r04_loop_variants.txt] -- the options stay in the generator for the record:
 #   Cfg(4, 2, 4, 1, KW=2)   128 x 128 tile of (4, 2)-shaped waves, the two wave pairs splitting the k16 steps of a stage by parity (half the
 #                           B reads per MFMA of (4, 1)): 40.6-41.3 clocks per MFMA, the same as (4, 1)'s 41.3-41.6 -- what the 128 x 128

@@ -58,6 +58,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define V2 F_ANDOR(202) F_PKADD(204)
 // D = 13 VALU + 4 reads per 8 MFMAs (256 x 64 per wave: a k16 step is 16 MFMAs, 26 VALU, 8 reads)
 #define MIXD MF(0) RD(220) V2 MF(1) RD(224) V1 MF(2) RD(228) V2 MF(3) RD(232) V1 MF(4) V2 MF(5) V2 MF(6) V1 MF(7) V2
+// the same mixes on ROTATING random operands (four A, eight B fragments of N(0, 0.5)-like numbers): what the part's power management makes of
+// real data -- constant operands toggle nothing between consecutive MFMAs and run at a clock no real launch sees
+#define MR(i, x, y) "v_mfma_f32_32x32x16_f16 %" #i ", %[ra" #x "], %[rb" #y "], %" #i "\n\t"
+#define MIXAR MR(0, 0, 0) RD(220) V3 MR(1, 0, 1) RD(224) V3 MR(2, 0, 2) RD(228) V3 MR(3, 0, 3) RD(232) V3 MR(4, 1, 0) V3 MR(5, 1, 1) V4 MR(6, 1, 2) V3 MR(7, 1, 3) V4 \
+              MR(0, 2, 4) RD(220) V3 MR(1, 2, 5) RD(224) V3 MR(2, 2, 6) RD(228) V3 MR(3, 2, 7) RD(232) V3 MR(4, 3, 4) V3 MR(5, 3, 5) V4 MR(6, 3, 6) V3 MR(7, 3, 7) V4
+#define MIXDR MR(0, 0, 0) RD(220) V2 MR(1, 0, 1) RD(224) V1 MR(2, 0, 2) RD(228) V2 MR(3, 0, 3) RD(232) V1 MR(4, 0, 4) RD(236) V2 MR(5, 0, 5) RD(240) V2 MR(6, 0, 6) RD(244) V1 MR(7, 0, 7) RD(220) V2 \
+              MR(0, 1, 0) V2 MR(1, 1, 1) V1 MR(2, 1, 2) V2 MR(3, 1, 3) V1 MR(4, 1, 4) V2 MR(5, 1, 5) V2 MR(6, 1, 6) V1 MR(7, 1, 7) V2
+#define MIXNR MR(0, 0, 0) MR(1, 0, 1) MR(2, 0, 2) MR(3, 0, 3) MR(4, 1, 4) MR(5, 1, 5) MR(6, 1, 6) MR(7, 1, 7) MR(0, 2, 0) MR(1, 2, 1) MR(2, 2, 2) MR(3, 2, 3) MR(4, 3, 4) MR(5, 3, 5) MR(6, 3, 6) MR(7, 3, 7)
 #define BODY(F, N) MF(0) FILL##N(F, 0) MF(1) FILL##N##B(F, 1) MF(2) FILL##N(F, 2) MF(3) FILL##N##B(F, 3) MF(4) FILL##N(F, 4) MF(5) FILL##N##B(F, 5) MF(6) FILL##N(F, 6) MF(7) FILL##N##B(F, 7)
 
 template <int KIND, int N>
@@ -69,6 +77,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   half8 a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f); b[i] = (_Float16)(i * 0.01f); }
   const unsigned lds = (threadIdx.x & 63) * 16;
+  half8 ra[4], rb[8];
+  {
+    unsigned st = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (_Float16)(((int)(st >> 9) % 2001 - 1000) * 0.001f); };   // ~U(-1, 1)
+    for (int j = 0; j < 4; ++j) for (int e = 0; e < 8; ++e) ra[j][e] = rnd();
+    for (int j = 0; j < 8; ++j) for (int e = 0; e < 8; ++e) rb[j][e] = rnd();
+  }
   unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #define RUN(F, NN)                                                                                                                  \
@@ -107,7 +122,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                  "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", \
                  "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", \
                  "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159")
-  if constexpr (KIND == 20) { RUNMIX(MIXA); }
+#define RUNMIXR(MIX)                                                                                                                \
+  asm volatile("s_mov_b32 s40, 0x000f000f\n\ts_mov_b32 s41, 0x2c002c00\n\ts_mov_b32 s42, 0\n\tv_mov_b32 v217, 0x3c003c00\n\tv_mov_b32 v216, %[l]\n\t" \
+               "v_mov_b32 v200, 0\n\tv_mov_b32 v202, 0\n\tv_mov_b32 v204, 0\n\tv_mov_b32 v206, 0\n\tv_mov_b32 v208, 0\n\tv_mov_b32 v210, 0\n\tv_mov_b32 v212, 0\n\t" \
+               "s_mov_b32 s43, %[rep]\n\t"                                                                                          \
+               ".Lloop_%=:\n\t" MIX "s_waitcnt lgkmcnt(0)\n\ts_sub_u32 s43, s43, 1\n\ts_cmp_lg_u32 s43, 0\n\ts_cbranch_scc1 .Lloop_%=\n\ts_nop 15\n\t"  \
+               : "+a"(c[0]), "+a"(c[1]), "+a"(c[2]), "+a"(c[3]), "+a"(c[4]), "+a"(c[5]), "+a"(c[6]), "+a"(c[7])                     \
+               : [ra0] "v"(ra[0]), [ra1] "v"(ra[1]), [ra2] "v"(ra[2]), [ra3] "v"(ra[3]), [rb0] "v"(rb[0]), [rb1] "v"(rb[1]), [rb2] "v"(rb[2]),   \
+                 [rb3] "v"(rb[3]), [rb4] "v"(rb[4]), [rb5] "v"(rb[5]), [rb6] "v"(rb[6]), [rb7] "v"(rb[7]), [l] "v"(lds), [rep] "s"(rep / 2)      \
+               : "memory", "scc", "s40", "s41", "s42", "s43", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", \
+                 "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", \
+                 "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247")
+  if constexpr (KIND == 30) { RUNMIXR(MIXAR); }
+  else if constexpr (KIND == 31) { RUNMIXR(MIXDR); }
+  else if constexpr (KIND == 32) { RUNMIXR(MIXNR); }
+  else if constexpr (KIND == 20) { RUNMIX(MIXA); }
   else if constexpr (KIND == 21) { RUNMIX(MIXB); }
   else if constexpr (KIND == 22) { RUNMIX(MIXC); }
   else if constexpr (KIND == 23) { RUNMIX(MIXBA); }
@@ -146,8 +175,9 @@ void run(unsigned long long* d, int blocks) {
   for (int i = 0; i < blocks * 4; ++i) { sum += (double)h[i * 2]; rsum += (double)h[i * 2 + 1]; }
   static const char* mixes[] = {"mix A: 26 VALU + 4 ds_read_b128 / 8 MFMA", "mix B: 26 VALU + 8 reads", "mix C: 52 VALU + 8 reads", "mix B, reads into AGPRs",
                                 "mix D: 13 VALU + 4 reads"};
+  static const char* rmixes[] = {"random operands, mix A (128 x 64 per wave)", "random operands, mix D (256 x 64 per wave)", "random operands, MFMAs only"};
   const double clk = sum / (blocks * 4) / (rep * 8.0), ns = rsum * 10.0 / (blocks * 4) / (rep * 8.0);
-  printf("  %-20s N=%d: %6.2f clocks per MFMA  %6.2f ns per MFMA (%.3f GHz)\n", KIND >= 20 ? mixes[KIND - 20] : names[KIND], N, clk, ns, clk / ns);
+  printf("  %-20s N=%d: %6.2f clocks per MFMA  %6.2f ns per MFMA (%.3f GHz)\n", KIND >= 30 ? rmixes[KIND - 30] : (KIND >= 20 ? mixes[KIND - 20] : names[KIND]), N, clk, ns, clk / ns);
 }
 template <int KIND>
 void run_all(unsigned long long* d, int blocks) {
@@ -160,6 +190,7 @@ int main(int argc, char** argv) {
   hipMalloc(&d, 4096 * 8 * 8);
   printf("blocks = %d (4 waves each, one per SIMD)\n", blocks);
   run<20, 0>(d, blocks); run<21, 0>(d, blocks); run<22, 0>(d, blocks); run<23, 0>(d, blocks); run<24, 0>(d, blocks); run<0, 0>(d, blocks);
+  run<30, 0>(d, blocks); run<31, 0>(d, blocks); run<32, 0>(d, blocks); run<30, 0>(d, blocks); run<31, 0>(d, blocks); run<32, 0>(d, blocks);
   if (argc > 2) return 0;
   run_all<0>(d, blocks); run_all<1>(d, blocks); run_all<2>(d, blocks); run_all<3>(d, blocks); run_all<4>(d, blocks); run_all<5>(d, blocks);
   run_all<6>(d, blocks); run_all<7>(d, blocks); run_all<8>(d, blocks); run_all<9>(d, blocks); run_all<10>(d, blocks); run_all<11>(d, blocks);

@@ -9,7 +9,7 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 G = int(os.environ.get("G", "128"))
 XW = 5
-shapes = sys.argv[1:] or ["128x512x256", "128x1024x256", "130x1024x512", "300x2048x512", "512x4096x4096", "77x4096x256", "1x512x256"]
+shapes = sys.argv[1:] or ["128x512x256", "128x1024x256", "130x1024x512", "300x2048x512", "512x4096x4096", "77x4096x256", "1x512x256", "1000x1024x768", "256x256x256", "2049x384x512"]
 bad = 0
 for spec in shapes:
     M, K, N = (int(v) for v in spec.split("x"))
@@ -21,12 +21,12 @@ for spec in shapes:
     assert rc == 0
     ref = x.float() @ w.float()
     scale = ref.abs().max().item()
-    for mb, pairs in ((4, 2), (4, 1), (2, 1)):
+    for mb, pairs in ((8, 2), (4, 2), (4, 1), (2, 1)):
       if N % (pairs * 128):
         continue
       wide = kernels.gemm_forward(x, qw, sc, qz, kernel_id=3 | (mb << 4) | (pairs << 8) | (1 << 12), grid_split_k=1)
       for s in (1, 2, 4):
-        kid = XW | (s << 8) | ((mb << 4) if mb == 2 else 0) | ((1 << 12) if pairs == 1 else 0)
+        kid = XW | (s << 8) | ((mb << 4) if mb != 4 else 0) | ((1 << 12) if pairs == 1 else 0)
         plan = kernels.plan_describe(M, K, N, G, kid)
         if f"slices={s}" not in plan or not plan.startswith("xw"):
             continue
@@ -39,7 +39,7 @@ for spec in shapes:
         torch.cuda.synchronize()
         err = (y.float() - ref).abs().max().item() / scale
         same = bool((y == y2).all())
-        eqw = bool((y == wide).all()) if (s == 1 and mb == 4) else None
+        eqw = bool((y == wide).all()) if (s == 1 and mb >= 4) else None
         nanc = int(torch.isnan(y.float()).sum())
         okk = err <= 2e-3 and same and nanc == 0 and (eqw is not False)
         bad += not okk
