@@ -15,6 +15,7 @@ timeout 120 python tools/xk_phases.py --kernel 0x405 512x4096x4096
 timeout 120 python tools/xk_phases.py --kernel 0x125 512x4096x4096
 timeout 120 python tools/xk_phases.py --kernel 0x1105 1024x4096x4096
 timeout 120 python tools/xk_phases.py --kernel 0x105 512x4096x11008
+timeout 120 python tools/xk_phases.py --kernel 0x85 4096x4096x4096
 echo "# loop experiments (wrong results on purpose): 1 no barrier, 2 no vector memory in the loop, 4 no dequantisation, 8 no B reads, 15 all"
 for e in 1 2 4 8; do echo "== 128 x 128, two slices, experiment $e"; QUICK_XW_EXP=$e timeout 100 python tools/xk_phases.py --kernel 0x1205 512x4096x4096 | grep -v "reached\|word 7\|of those"; done
 for e in 1 2 4 8 15; do echo "== 64 x 128, experiment $e"; QUICK_XW_EXP=$e timeout 100 python tools/xk_phases.py --kernel 0x125 512x4096x4096 | grep -v "reached\|word 7\|of those"; done
