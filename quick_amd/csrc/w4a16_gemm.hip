@@ -1488,7 +1488,10 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // shapes, 13-24 % where the r02 128-token wide tile ran), not the 256 x 256 tile (level within 5 %, behind at 8192 tokens), and below
     // 160 tokens only from 96 tokens on wide layers (N >= 10240: 96 / 128 x 4096 x 11008 20.7 / 21.0 -> 17.8 / 18.6 us; at N = 4096 the 64-token
     // exchange-K tile stays 5-7 % ahead).
-    if (best > 0 && allow_xk && wide_mb != 8 && (G / 128 & (G / 128 - 1)) == 0 && (M >= 160 || (M >= 96 && N >= 10240)) &&
+    // (where the 256 x 256 tile is the pick they compete only if it runs with a K split: 1024 x 28672 x 8192, 128 tiles x 2 slices, 419 us
+    // against 379 on 256 tiles of 128 x 256 -- profiles/r04_xw256.txt)
+    if (best > 0 && allow_xk && (wide_mb != 8 || (N % 256 == 0 && wide_split((long)((M + 255) / 256) * (N / 256)) > 1)) && (G / 128 & (G / 128 - 1)) == 0 &&
+        (M >= 160 || (M >= 96 && N >= 10240)) &&
         (size_t)M * (size_t)K * 2 < ((size_t)1 << 32) && (size_t)M * (size_t)N * 2 < ((size_t)1 << 32)) {
       struct XwCand { int mb, pairs; double c, a, b_ceil, b_frac, s0, s1, d; };
       static const XwCand xwc[3] = {{4, 2, -2.8632, 5.8843, 0.8799, 0.6018, -0.6402, 1.2461, 5.8244},

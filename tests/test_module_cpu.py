@@ -233,7 +233,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(96, 4096, 22016).startswith("xw tokens=128 channels=128") and plan(96, 4096, 4096).startswith("xk")   # below 160 tokens only on wide layers
     assert plan(2048, 3584, 18944).startswith("xw tokens=256 channels=256")                            # several rounds: the 256 x 256 tile, since r04 with the generated loop
     assert plan(2048, 4096, 4096).startswith("xw tokens=128 channels=256") and "xw tokens=256 channels=256 waves=4 ring=2 queue=2 grid=2752 slices=1" in plan(8192, 4096, 22016)
-    assert plan(1024, 28672, 8192).startswith("wide tokens=256 channels=256") and "ksplit=2" in plan(1024, 28672, 8192)   # 128 tiles x 2 K slices: r02's kernel keeps the split launches
+    assert plan(1024, 28672, 8192).startswith("xw tokens=128 channels=256 waves=4 ring=4 queue=4 grid=256 slices=1")   # (r02: 128 tiles of 256 x 256 x 2 K slices; 256 one-slice tiles of 128 x 256 are 10 % ahead)
     os.environ["QUICK_AMD_XW256"] = "0"
     try:
         assert plan(4096, 4096, 4096).startswith("wide tokens=256 channels=256")                       # (the A/B switch)
