@@ -46,9 +46,10 @@ extern "C" {
 #define QUICK_KERNEL_WIDE 3   /* large M: 32x32x16 MFMA, one wave per SIMD, operands by LDS-DMA (G % 128 == 0; else TILED runs) */
 #define QUICK_KERNEL_XK 4     /* 64- / 128-token tiles, eight waves, the K slices of a tile on different CUs exchange partial tiles
                                  (G % 128 == 0; else TILED runs) */
-#define QUICK_KERNEL_XW 5     /* 128 x 256 tiles, four waves of 128 tokens x 64 channels (one per SIMD), hand-placed K loop; 1 / 2 / 4 K slices
-                                 of a tile on different CUs exchange fp16 parts and give up on partners that are not there
-                                 (G / 128 a power of two, N % 256 == 0; else TILED runs) */
+#define QUICK_KERNEL_XW 5     /* 256 x 256 / 128 x 256 / 128 x 128 / 64 x 128 tiles, four waves (one per SIMD) each owning all tokens and a quarter
+                                 of the channels, generated hand-placed K loop; 1 / 2 / 4 K slices of a tile on different CUs exchange fp16
+                                 parts and give up on partners that are not there (256 x 256: one slice)
+                                 (G / 128 a power of two, N % 256 == 0 for the 256-channel tiles; else TILED runs) */
 
 int quick_amd_abi_version(void);
 const char* quick_amd_last_error(void);
@@ -103,7 +104,7 @@ size_t quick_w4a16_workspace_bytes(int M, int K, int N, int group_size, int spli
  * bit field -- every field 0 = "planner's choice within the family":
  *   bits 0-3    family, QUICK_KERNEL_*
  *   bits 4-7    SKINNY: channel tiles of 16 per workgroup (1, 2, 4); TILED: token tiles of 16 per workgroup (2, 4, 8);
- *               WIDE / XK / XW: token tiles of 32 per workgroup (WIDE 2, 4, 8; XK 2, 4; XW 2, 4 -- 0 = 4)
+ *               WIDE / XK / XW: token tiles of 32 per workgroup (WIDE 2, 4, 8; XK 2, 4; XW 2, 4, 8 -- 0 = 4; 8 = the 256 x 256 tile)
  *   bits 8-11   SKINNY / TILED: waves per workgroup / 4; WIDE: 32-channel pairs per wave (1, 2); XK: K slices per tile (1, 2, 4, 8; 15 = half
  *               the planner's count); XW: K slices per tile (1, 2, 4 <= token tiles)
  *   bit 12      SKINNY: no LDS copy of x; WIDE: the double-buffered kernel at every tile size (no ring); XW: 128-channel tiles (implied by 2 token tiles)
@@ -122,6 +123,7 @@ size_t quick_w4a16_workspace_bytes(int M, int K, int N, int group_size, int spli
  * workgroups are co-resident, and the planner sizes the slice count for the device's CU count; a process whose queues see fewer CUs (a
  * CU mask) may say so (0: never split K this way).  Correctness does not depend on it: slices that are not there in time are given up
  * on and finished by the last arriver (see "workspace").  QUICK_AMD_EXCHANGE_POLL_LOG2=<n> overrides the poll limit (2^n ticks of 10 ns).
+ * QUICK_AMD_XW256=0 -- the planner keeps r02's hipcc-scheduled kernel for the 256 x 256 tile (bit-identical results; the A/B switch).
  * A combination the library has no build for returns QUICK_ERR_UNSUPPORTED; results never depend on the field
  * beyond fp32 summation order (and bit 25's rounding). */
 int quick_w4a16_gemm_f16_ex(const void* x, const void* qweight, const void* scales, const void* qzeros,

@@ -6,6 +6,7 @@ stages (x ring slot and weight queue set are static per copy).
     python tools/gen_xw_loop.py            # rewrites the .inc (checked in; the build does not run this script)
 
 Configurations (MB 32-token blocks x PAIRS 32-channel pairs per WAVE; the workgroup tile is MB * 32 tokens x PAIRS * 128 channels):
+    (8, 2)  256 x 256   1.6  VALU + 0.5 ds_read_b128 per MFMA    ring / queue of 2 stages (64 KiB slots), super-steps of 16 MFMAs, bar = 1
     (4, 2)  128 x 256   3.25 VALU + 0.5 ds_read_b128 per MFMA    ring / queue of 4 stages
     (4, 1)  128 x 128   3.25 VALU + 1   ds_read_b128 per MFMA    ring / queue of 4 stages
     (2, 1)   64 x 128   6.5  VALU + 1   ds_read_b128 per MFMA    ring / queue of 8 stages, two accumulator sets (even / odd k16 steps: a wave
