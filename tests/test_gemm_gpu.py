@@ -898,8 +898,8 @@ def test_llama70b_shapes_against_dense_dequant(qa, device, K, N, M):
 
 
 def test_random_shapes_against_dequantised_matmul(qa, device):
-    """60 seeded random (M, K, N, G) draws through whatever the planner picks (skinny/tiled, 128/256-channel tiles, K
-    splits that are not powers of two, ragged M, odd stage counts), twice each with the same workspace, against
+    """60 seeded random (M, K, N, G) draws through whatever the planner picks (skinny / tiled / wide / exchange-K / four-wave tiles up to
+    256 x 256, K splits that are not powers of two, ragged M, odd stage counts), twice each with the same workspace, against
     fp32 matmul over the weights dequantised on the GPU (quick_dequantize_mi355x_f16 is bit-exact against the oracle,
     see above).  Not a replacement for the oracle sweeps: a net for planner branches no fixed list thought of."""
     from quick_amd import kernels as K_, packing
@@ -911,7 +911,7 @@ def test_random_shapes_against_dequantised_matmul(qa, device):
         kmax = 28672 if case % 5 == 4 else 8192              # every fifth draw may have a long K (the planner's long-K rules)
         K = int(rng.integers(1, kmax // unit + 1)) * unit
         N = int(rng.integers(1, 97)) * 128
-        M = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 13, 16, 17, 24, 32, 40, 48, 57, 63, 64, 65, 96, 100, 128, 200, 257, 384, 520, 700]))
+        M = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 13, 16, 17, 24, 32, 40, 48, 57, 63, 64, 65, 96, 100, 128, 200, 257, 384, 520, 700, 1100, 2100, 4200]))
         if M * N * K > 2.5e10:
             M = max(1, int(2.5e10 // (N * K)))
         gen.manual_seed(case)
@@ -953,7 +953,7 @@ def test_random_shapes_with_fused_epilogues_and_prologue(qa, device):
         unit = max(G, 128)
         K = int(rng.integers(1, (16384 if case % 4 == 3 else 4096) // unit + 1)) * unit
         N = int(rng.integers(1, 65)) * 256                   # (SiLU*mul pairs gate / up channels: N / 2 must stay a multiple of 128)
-        M = int(rng.choice([1, 2, 4, 6, 8, 12, 16, 24, 48, 64, 96, 130, 300, 520]))
+        M = int(rng.choice([1, 2, 4, 6, 8, 12, 16, 24, 48, 64, 96, 130, 300, 520, 1030, 2500]))
         if M * N * K > 1.2e10:
             M = max(1, int(1.2e10 // (N * K)))
         gen.manual_seed(1000 + case)
