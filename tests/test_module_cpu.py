@@ -477,3 +477,18 @@ def test_no_kernel_of_the_library_traps(tmp_path):
         assert "s_trap" not in text, o.name
         mfma += text.count("v_mfma_f32_32x32x16_f16")
     assert mfma > 1000     # (the disassembly really is the GEMM kernels)
+
+
+def test_generated_k_loops_are_what_the_generator_writes(tmp_path):
+    """quick_amd/csrc/w4a16_xw_loop.inc is checked in (the build does not run the generator): it must be byte for byte what
+    tools/gen_xw_loop.py writes today -- hazard distances, counted waits and register plans are asserted inside the generator."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_xw_loop", os.path.join(root, "tools", "gen_xw_loop.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gen.OUT = str(tmp_path / "loop.inc")
+    gen.main()
+    assert open(gen.OUT).read() == open(os.path.join(root, "quick_amd", "csrc", "w4a16_xw_loop.inc")).read()
+    names = {c.name for c in gen.CONFIGS}
+    assert names == {"82", "42", "41", "21"}
