@@ -415,10 +415,14 @@ def main():
             k_us = min(meds)
             fl = algorithmic_flops(Ml, Kl, Nl)
             ach = fl / (k_us * 1e-6) / 1e12
-            out["prefill_layers"].append({"M": Ml, "K": Kl, "N": Nl, "kernel_us": k_us, "plan": kernels.plan_describe(Ml, Kl, Nl, G, args.kernel),
-                                          "kernel_us_medians": meds,
-                                          "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                       "frac": ach / MFMA_PEAK_TFLOPS, "flops": fl}})
+            lplan = kernels.plan_describe(Ml, Kl, Nl, G, args.kernel)
+            lroof = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "flops": fl}
+            # (north_star: "evidenced by rocprof MFMA-busy %" -- where a committed counter pass is about this shape and this plan's kernel)
+            ltraffic, lsrc = pmc_traffic(Ml, Kl, Nl, G, args.kernel, lplan)
+            if lsrc and "rejected" not in lsrc:
+                lroof.update({"traffic": ltraffic, "traffic_source": lsrc, "traffic_measured_in_this_run": False})
+                lroof.update(pmc_issue_mix(Ml, Kl, Nl, G, args.kernel, lsrc))
+            out["prefill_layers"].append({"M": Ml, "K": Kl, "N": Nl, "kernel_us": k_us, "plan": lplan, "kernel_us_medians": meds, "roofline": lroof})
             log(f"prefill M={Ml} K={Kl} N={Nl}: kernel {k_us:8.2f} us  {ach:7.1f} TFLOP/s = {100 * ach / MFMA_PEAK_TFLOPS:.1f}% of the f16 MFMA peak")
             del lsets, larr
 
