@@ -88,7 +88,8 @@ const char* quick_amd_last_error(void);
  * The K slices of a tile that meet through the exchange zone (QUICK_KERNEL_XK / QUICK_KERNEL_XW launches with more than
  * one slice) need NOT be co-resident since r04: a wave that has polled for a partner longer than the poll limit (41 us)
  * gives its part up -- own share to its self box, a flag bit in the part's state word in the counter region -- and leaves;
- * the last partner to arrive finishes the part from the boxes.  No kernel of the library spins without bound or traps.
+ * the partner whose shares reach memory last finds the flag, claims the part (the protocol's only atomic, a compare-and-swap) and
+ * finishes it from the boxes.  The fast path writes no state word.  No kernel of the library spins without bound or traps.
  */
 int quick_w4a16_gemm_f16(const void* x, const void* qweight, const void* scales, const void* qzeros,
                          void* y, void* workspace, size_t workspace_bytes,

@@ -272,12 +272,16 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
   if constexpr (ABL & 64) ph[3] = __builtin_amdgcn_s_memrealtime();
 
   // ---- 2. the S slices of the tile swap parts through the mailboxes ----
-  // [r04] Nobody has to be co-resident any more (the r03 poll spun for ~4 s and trapped).  A wave that has
-  // polled `limit` ticks for a partner GIVES ITS PART UP: own part to its self box [dst][dst], then bit 0 of the part's state word; it
-  // stores nothing and leaves.  Every sender counts itself in the receiver's state word (+2, returning atomic) once its stores are
-  // acknowledged; the sender that finds bit 0 set and is the last of the S - 1 finishes the part from the boxes (all S of them, slice
-  // order: the same sums whoever finishes) and stores it straight from its registers.  No spinning without bound, no trap, no dependence on
-  // dispatch order; the fast path pays S - 1 atomics per wave whose answers are read after the rows have left.
+  // [r04] Nobody has to be co-resident any more (the r03 poll spun for ~4 s and trapped), and the fast path pays
+  // no atomic for it.  A state word per (tile, owner, wave): bit 0 = the owner GAVE its part UP, bit 1 = somebody CLAIMED it.
+  //   owner:  polls `limit` ticks for its partners' shares.  If they do not come: own share to its self box [dst][dst], then (stores
+  //           acknowledged) bit 0, then (acknowledged) ONE more look at the boxes -- all there after all: claim and finish; else leave.
+  //   sender: once its shares are acknowledged in memory it reads the owners' state words (a plain load, issued behind the polling so that
+  //           no poll waits for it, looked at after its own rows have left).  Bit 0 set, bit 1 not: look at ALL S boxes of that part; all
+  //           full: claim (compare-and-swap 1 -> 3, the only atomic of the protocol) and, having won, finish the part from the boxes --
+  //           slice order, the same sums whoever finishes -- store it straight from the registers, zero the boxes and the word.
+  // Whoever's contribution (shares, or self box + flag) is acknowledged LAST looks afterwards and therefore sees everything: exactly one
+  // party finishes an abandoned part.  No spinning without bound, no trap, no dependence on dispatch order.
   constexpr int H = HB * 16, P = H / S;       // registers a wave holds / finishes
   constexpr int GR = P >= 4 ? 4 : 2;          // registers per mailbox granule
   constexpr int NGR = P / GR;                 // granules per part
@@ -332,8 +336,8 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
       }
     }
   };
-  // what this slice still owes after its own rows have left: boxes and state word back to zero, parts their owners gave up
-  unsigned old_lane = 0u;   // lane q: what partner q's state word held before this slice counted itself
+  // what this slice still owes after its own rows have left: boxes (and, after a give-up, the state word) back to zero, parts their owners gave up
+  unsigned flag_lane = 0u;  // lane q: partner q's state word, read after this slice's shares were acknowledged
   if constexpr (S == 1) {
 #pragma unroll
     for (int f = 0; f < P; ++f) fin[f] = flat(f);
@@ -345,8 +349,7 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
   unsigned* state = S > 1 ? a.counters + ((unsigned)t.tile * S) * 8u + (unsigned)wave : nullptr;   // + dst * 8: state word of (tile, dst, wave)
   constexpr int TL = S > 1 ? (S - 1) * NGR : 1;
   unsigned so[TL];
-  bool zero_self = false;
-  int adjust = -2 * (S - 1);
+  bool zero_self = false;   // (the owner gave up, found everything there after all and won the claim: self box and state word are its to clear)
   typedef float floatx2 __attribute__((ext_vector_type(2)));
   auto mail_store = [&](unsigned off, const float* v) __attribute__((always_inline)) {
     if constexpr (GR == 4) xk_mail_store(rz, off, floatx4{v[0], v[1], v[2], v[3]});
@@ -411,11 +414,11 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
           }
           return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
         };
-        // The first poll's wait also acknowledges the stores above (the shares are in memory); right behind it lane q counts this slice in
-        // partner q's state word -- ONE returning atomic instruction for all S - 1 partners, issued BEFORE the waiting starts so that its
-        // answer (looked at after the rows have left: did a partner give up, am I its last share?) travels while the wave polls.
+        // The first poll's wait also acknowledges the stores above: the shares are in memory.  Right behind it lane q asks whether partner q has
+        // given its part up -- a plain load, as quick as the polls that may follow it, long back when it is looked at (after the rows have left).
+        // Early is enough: an owner that gives up LATER looks at its boxes once more after raising its flag, and finds these shares.
         bool ok = poll();
-        if (lane < S && lane != KS) old_lane = __hip_atomic_fetch_add(state + lane * 8, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < S && lane != KS) flag_lane = __hip_atomic_load(state + lane * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (!ok && (unsigned)(__builtin_amdgcn_s_memrealtime() - t0) <= limit) {
           __builtin_amdgcn_s_sleep(4);
@@ -423,7 +426,7 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
         }
         bool finish = ok;
         if (!ok) {
-          // give the part up: own share (encoded as the ones that travel) to the self box, then the flag bit
+          // give the part up: own share (encoded as the ones that travel) to the self box, then the flag, then one more look
           const unsigned box = tbase + (unsigned)(KS * S + KS) * BOX;
 #pragma unroll
           for (int g = 0; g < NGR; ++g) {
@@ -433,18 +436,24 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
             mail_store(box + g * GBYTES, v);
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          unsigned o = 0u;
-          if (lane == 0) o = __hip_atomic_fetch_or(state + KS * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          o = (unsigned)__builtin_amdgcn_readfirstlane((int)o);
-          if ((int)o >> 1 == S - 1) {   // every partner counted itself meanwhile: its share was acknowledged before, it is readable now
-            (void)poll();
-            finish = true;
-            zero_self = true;
-            adjust = -2 * (S - 1) - 1;
+          if (lane == 0) __hip_atomic_store(state + KS * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (poll()) {   // every share is there after all: whoever of the partners looks now sees the same, so claim
+            unsigned expect = 1u;
+            bool won = false;
+            if (lane == 0) won = __hip_atomic_compare_exchange_strong(state + KS * 8, &expect, 3u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_readfirstlane((int)won)) {
+              finish = true;
+              zero_self = true;
+            }
           }
         }
         mine = finish;
         if (finish) {
+          // the shares are in registers: hand the boxes back zeroed NOW -- these stores are acknowledged under the rows' way out, not behind it
+          // (behind it they cost 0.25 us of every launch, profiles/r04_xk_giveup_phases.txt)
+#pragma unroll
+          for (int k = 0; k < TL; ++k) mail_zero(so[k]);
           // sum in slice order, the own part at position KS
           float sum[P];
 #pragma unroll
@@ -555,23 +564,23 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
     if (mine) store_direct(t.ks, fin);
   }
 
-  // ---- 4. after the rows: boxes and state word back to zero; parts whose owners gave up and whose last share was this slice's ----
+  // ---- 4. after the rows: (after a give-up won back) self box and state word to zero; parts whose owners gave up and which this slice is the one to finish ----
   if constexpr (S > 1 && !(ABL & 4)) {
     if (mine) {
-#pragma unroll
-      for (int k = 0; k < TL; ++k) mail_zero(so[k]);
       if (zero_self) {
 #pragma unroll
         for (int g = 0; g < NGR; ++g) mail_zero((unsigned)(t.ks * S + t.ks) * BOX + (unsigned)g * GBYTES);
+        if (lane == 0) __hip_atomic_store(state + t.ks * 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (lane == 0) (void)__hip_atomic_fetch_add(state + t.ks * 8, (unsigned)adjust, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int q = 0; q < S; ++q) {
       if (q == t.ks) continue;
-      const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)old_lane, q);
-      if (!((o & 1u) && (int)(o >> 1) + 1 == S - 1)) continue;
-      float sum[P];
-      for (int src = 0; src < S; ++src) {   // slice order; every box is complete (its sender counted itself after its stores were acknowledged)
+      if ((unsigned)__builtin_amdgcn_readlane((int)flag_lane, q) != 1u) continue;   // not given up (or claimed already)
+      // all S boxes of the part (the self box at src == q), one look: complete?
+      float val[S][P];
+      bool full = true;
+#pragma unroll
+      for (int src = 0; src < S; ++src) {
         const unsigned boff = (unsigned)(q * S + src) * BOX;
 #pragma unroll
         for (int g = 0; g < NGR; ++g) {
@@ -581,17 +590,36 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
             xk_mail_load16<1>(rz, tbase, o1, v);
             const floatx4 fq = __builtin_bit_cast(floatx4, v[0]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sum[g * 4 + r] = src == 0 ? -fq[r] : sum[g * 4 + r] - fq[r];
+            for (int r = 0; r < 4; ++r) {
+              full = full && v[0][r] != 0u;
+              val[src][g * 4 + r] = -fq[r];
+            }
           } else {
             u32x2 v[1];
             const unsigned o1[1] = {boff + (unsigned)g * GBYTES};
             xk_mail_load8<1>(rz, tbase, o1, v);
             const floatx2 fq = __builtin_bit_cast(floatx2, v[0]);
-            sum[g * 2] = src == 0 ? -fq[0] : sum[g * 2] - fq[0];
-            sum[g * 2 + 1] = src == 0 ? -fq[1] : sum[g * 2 + 1] - fq[1];
+            full = full && v[0][0] != 0u && v[0][1] != 0u;
+            val[src][g * 2] = -fq[0];
+            val[src][g * 2 + 1] = -fq[1];
           }
-          mail_zero(boff + (unsigned)g * GBYTES);
         }
+      }
+      if (__builtin_amdgcn_ballot_w64(!full) != 0ull) continue;   // somebody's share is still on its way: that somebody will look later
+      unsigned expect = 1u;
+      bool won = false;
+      if (lane == 0) won = __hip_atomic_compare_exchange_strong(state + q * 8, &expect, 3u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!__builtin_amdgcn_readfirstlane((int)won)) continue;
+      float sum[P];
+#pragma unroll
+      for (int src = 0; src < S; ++src) {   // slice order
+#pragma unroll
+        for (int f = 0; f < P; ++f) sum[f] = src == 0 ? val[0][f] : sum[f] + val[src][f];
+      }
+#pragma unroll
+      for (int src = 0; src < S; ++src) {
+#pragma unroll
+        for (int g = 0; g < NGR; ++g) mail_zero((unsigned)(q * S + src) * BOX + (unsigned)g * GBYTES);
       }
       if (lane == 0) __hip_atomic_store(state + q * 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       store_direct(q, sum);
