@@ -1505,7 +1505,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         for (int sx = 1; sx <= mb && sx <= 4; sx *= 2) {
           if (sx > 1 && (T * sx > 256 || KT / sx < 4 || (KT + (KT + sx - 1) / sx - 1) / ((KT + sx - 1) / sx) != sx)) continue;
           const double f = (double)(T * sx) / 256.0, n = (double)((T * sx + 255) / 256), stages = (double)((KT + sx - 1) / sx);
-          const double cost = xwc[c].c + xwc[c].a * n + stages * (xwc[c].b_ceil * n + xwc[c].b_frac * f) + (sx > 1 ? xwc[c].s0 + xwc[c].s1 * sx : 0.0) + xwc[c].d * f;
+          // (- 0.5 us with slices: the exchange lost its atomics after the fit -- 512 x 4096 x 4096 22.0 -> 21.5 / 24.2 -> 23.3 us on two / four
+          // slices, profiles/r04_ab_exchange.txt)
+          const double cost = xwc[c].c + xwc[c].a * n + stages * (xwc[c].b_ceil * n + xwc[c].b_frac * f) + (sx > 1 ? xwc[c].s0 + xwc[c].s1 * sx - 0.5 : 0.0) + xwc[c].d * f;
           if (xw_auto_mb == 0 || cost < xbest) {
             xbest = cost;
             p.est_xw_us = cost;

@@ -500,7 +500,8 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
     const int jb0 = (t.ks * P) / 16;          // first finished block among the wave's HB
     __syncthreads();                          // (the K-parity inboxes have been read)
     unsigned* flags = (unsigned*)(smem + 64 * 1024);   // [wave]: this wave finished its part (the image is at most 32 KiB)
-    if (lane == 0) flags[wave] = mine ? 1u : 0u;
+    if constexpr (S > 1)
+      if (lane == 0) flags[wave] = mine ? 1u : 0u;
     auto image = [&](auto siluc) __attribute__((always_inline)) {
       constexpr bool SILU = decltype(siluc)::value != 0;
       constexpr int CPR = SILU ? 8 : 16;
@@ -532,13 +533,20 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
       const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.Y, 0, (unsigned)((size_t)a.M * ldy * 2), 0x00020000);
       const half_t* rcol = (!SILU && a.residual) ? a.residual + t.nb * 128 + q * 8 : nullptr;
       constexpr int RPI = 512 / CPR;          // rows per pass of the workgroup
+      // did the wave that owns this thread's chunk column (wn = the chunk's channel quarter) finish its rows?  One look per K parity, in front
+      // of the loop: read inside it, next to the image reads, the two flag words cost every launch 0.5 us (profiles/r04_ab_exchange.txt)
+      bool fin_ok[2] = {true, true};
+      if constexpr (S > 1) {
+        fin_ok[0] = flags[q / (CPR / 4)] != 0u;
+        fin_ok[1] = flags[q / (CPR / 4) + 4] != 0u;
+      }
 #pragma unroll
       for (int it = 0; it < ROWS / RPI; ++it) {
         const int lr = it * RPI + (int)threadIdx.x / CPR;  // local row: block lr / 32 (= wkk * NBL + jj), token lr % 32
         half8_t v = *(const half8_t*)(smem + (lr * CPR + (q ^ (lr & 7))) * 16);
         const int blk = lr >> 5, wkk = blk / NBL, jj = blk % NBL;
         const int m = t.m0 + ((wkk * HB + jb0 + jj) * 32 + (lr & 31));
-        const bool owner_ok = flags[(q / (CPR / 4)) + 4 * wkk] != 0u;   // wave (wn = chunk's channel quarter, wk = wkk) finished these rows
+        const bool owner_ok = fin_ok[wkk];   // wave (wn, wk = wkk) finished these rows (one slice: nobody can have given anything up)
         if (m < a.M && owner_ok) {
           if (rcol) {
             const half8_t res = *(const half8_t*)(rcol + (size_t)m * a.N);
