@@ -355,9 +355,15 @@ __device__ __forceinline__ void xk_way_out(const GemmArgs& a, const XkTile& t, f
     if constexpr (GR == 4) xk_mail_store(rz, off, floatx4{v[0], v[1], v[2], v[3]});
     else xk_mail_store(rz, off, v[0], v[1]);
   };
+  // (16-byte stores with an SGPR offset carry their own wait states: gfx950 corrupts the store's data when the next VALU instruction
+  // overwrites the data registers, and hipcc pads that hazard only for stores without an SGPR offset -- see xw_mail_store, w4a16_xw.hpp)
   auto mail_zero = [&](unsigned soff) __attribute__((always_inline)) {
-    if constexpr (GR == 4) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rz, tbase, soff, 16);
-    else __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rz, tbase, soff, 16);
+    if constexpr (GR == 4) {
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 3" : : "v"(zero), "v"(tbase), "s"(rz), "s"(soff) : "memory");
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rz, tbase, soff, 16);
+    }
   };
   if constexpr (S > 1) {
     const unsigned limit = 1u << (((a.xcd_gm >> 8) & 31) ? ((a.xcd_gm >> 8) & 31) : 12);   // ticks of 10 ns; default 41 us

@@ -1156,7 +1156,10 @@ def test_xk_exchange_under_uneven_load(qa, device):
                 got = y[:, cols].float().cpu().numpy()
                 assert float(np.abs(got - want).max()) <= TOL * float(np.abs(want).max()), (rep, i)
             assert torch.equal(y, first[i]), (rep, i)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        from quick_amd import kernels as K_
+        for ws in K_._WORKSPACES.values():   # counters and exchange zone: handed back all-zero, every launch
+            assert int(ws[: (64 << 10) + (16 << 20)].count_nonzero()) == 0, rep
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1261,11 +1264,24 @@ def test_xw_exchange_when_partners_are_not_there(qa, device):
     """The slices of a tile need not be co-resident: (a) an S = 4 launch while a long-running kernel on another
     stream holds most of the chip -- partner workgroups are dispatched one kernel-length apart; (b) two S > 1 launches on two streams at
     the same time, each on its own workspace; (c) the same with a poll limit of 2.5 us, so that give-ups and in-time exchanges mix inside
-    one launch.  No trap, no hang, and every word equals the undisturbed launch's."""
+    one launch.  No trap, no hang, every word equals the undisturbed launch's -- written into NaN-poisoned buffers, so that a block nobody
+    finished shows whatever the allocator hands back -- and counters and exchange zone of every workspace are all-zero again after every
+    round (this check found the store hazard described at xw_mail_store; tools/exchange_stress.py is the long form of this test)."""
+    from quick_amd import kernels as K_
+
+    def poisoned(y0):
+        return torch.full_like(y0, float("nan"))
+
+    def workspaces_clean():
+        for ws in K_._WORKSPACES.values():
+            if int(ws[: (64 << 10) + (16 << 20)].count_nonzero()) != 0:
+                return False
+        return True
     cases = []
     for (M, K, N), kid in (((512, 4096, 4096), xw(4, 2, 4)), ((512, 4096, 4096), xw(4, 1, 2)), ((256, 4096, 4096), xw(2, 1, 2)),
                            ((1024, 4096, 4096), xw(4, 2, 2)), ((128, 8192, 2048), xw(4, 1, 4)),
-                           ((128, 4096, 4096), xk(2, 4)), ((64, 11008, 4096), xk(2, 8)), ((512, 4096, 4096), xk(4, 2))):
+                           ((128, 4096, 4096), xk(2, 4)), ((64, 11008, 4096), xk(2, 8)), ((512, 4096, 4096), xk(4, 2)),
+                           ((200, 4096, 2048), xk(4, 4)), ((64, 4096, 6144), xk(2, 4))):
         x, iw, s, z = oracle.make_synthetic(M, K, N, 128, seed=M + N + K)
         cols = np.unique(np.random.default_rng(M + N).integers(0, N, 96))
         want = oracle.w4a16_forward(x, iw[:, cols], s[:, cols], z[:, cols], 128).astype(np.float32)
@@ -1285,21 +1301,23 @@ def test_xw_exchange_when_partners_are_not_there(qa, device):
             for poll in (0, 8):
                 if (kid & 15) == XK:   # (the exchange-K kernel ids use bits 22.. for their ring depth: the limit comes from the environment)
                     os.environ["QUICK_AMD_EXCHANGE_POLL_LOG2"] = str(poll)
-                y = qa.gemm_forward(xd, *packed, kernel_id=kid | ((poll << 22) if (kid & 15) == XW else 0))
+                y = qa.gemm_forward(xd, *packed, kernel_id=kid | ((poll << 22) if (kid & 15) == XW else 0), out=poisoned(y0))
                 os.environ.pop("QUICK_AMD_EXCHANGE_POLL_LOG2", None)
                 assert torch.equal(y, y0), (rep, kid, poll)
         torch.cuda.synchronize()
+        assert workspaces_clean(), rep
         # (b) two exchange launches at once on two streams (the Python face keeps one workspace per stream)
         xa, pa, ka, ya = cases[rep % len(cases)]
         xb, pb, kb, yb = cases[(rep + 1) % len(cases)]
         if rep % 2:
             os.environ["QUICK_AMD_EXCHANGE_POLL_LOG2"] = "8"
         with torch.cuda.stream(side):
-            outs_b = [qa.gemm_forward(xb, *pb, kernel_id=kb) for _ in range(4)]
-        outs_a = [qa.gemm_forward(xa, *pa, kernel_id=ka) for _ in range(4)]
+            outs_b = [qa.gemm_forward(xb, *pb, kernel_id=kb, out=poisoned(yb)) for _ in range(4)]
+        outs_a = [qa.gemm_forward(xa, *pa, kernel_id=ka, out=poisoned(ya)) for _ in range(4)]
         os.environ.pop("QUICK_AMD_EXCHANGE_POLL_LOG2", None)
         torch.cuda.synchronize()
         assert all(torch.equal(o, ya) for o in outs_a) and all(torch.equal(o, yb) for o in outs_b), rep
+        assert workspaces_clean(), rep
 
 
 def test_decode_full_stack_llama2_7b_fused_against_torch_ops(qa, device):
