@@ -51,6 +51,10 @@ extern "C" {
                                  parts and give up on partners that are not there (256 x 256: one slice)
                                  (G / 128 a power of two, N % 256 == 0 for the 256-channel tiles; else TILED runs) */
 
+#define QUICK_KERNEL_LEAN 6   /* [r05] 1..16 tokens: one workgroup per 16 tokens x 16 channels, its waves split K; x by LDS-DMA FIRST in the
+                                 memory queue, every weight tile of a wave requested up front, unit sums computed under the weights'
+                                 flight (G % 128 == 0, K / 128 between waves and 16 * waves; else QUICK_ERR_UNSUPPORTED when forced) */
+
 int quick_amd_abi_version(void);
 const char* quick_amd_last_error(void);
 
@@ -106,7 +110,7 @@ size_t quick_w4a16_workspace_bytes(int M, int K, int N, int group_size, int spli
  *   bits 0-3    family, QUICK_KERNEL_*
  *   bits 4-7    SKINNY: channel tiles of 16 per workgroup (1, 2, 4); TILED: token tiles of 16 per workgroup (2, 4, 8);
  *               WIDE / XK / XW: token tiles of 32 per workgroup (WIDE 2, 4, 8; XK 2, 4; XW 2, 4, 8 -- 0 = 4; 8 = the 256 x 256 tile)
- *   bits 8-11   SKINNY / TILED: waves per workgroup / 4; WIDE: 32-channel pairs per wave (1, 2); XK: K slices per tile (1, 2, 4, 8; 15 = half
+ *   bits 8-11   SKINNY / TILED / LEAN: waves per workgroup / 4; WIDE: 32-channel pairs per wave (1, 2); XK: K slices per tile (1, 2, 4, 8; 15 = half
  *               the planner's count); XW: K slices per tile (1, 2, 4 <= token tiles)
  *   bit 12      SKINNY: no LDS copy of x; WIDE: the double-buffered kernel at every tile size (no ring); XW: 128-channel tiles (implied by 2 token tiles)
  *   bit 13      TILED: 32x32x16 MFMA flavour         bit 14  TILED / WIDE / XK: plain (not XCD-aware) tile order

@@ -22,11 +22,13 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libquick_amd.so")
 TOOLS_LIB = os.path.join(LIBDIR, "libquick_amd_tools.so")
-SOURCES = ["w4a16_gemm.hip", "w4a16_xk.hip", "w4a16_xw.hip", "repack.hip", "decode_ops.hip"]
-HEADERS = ["w4a16_common.hpp", "w4a16_args.hpp", "w4a16_wide.hpp", "w4a16_xk.hpp", "w4a16_xk_host.hpp", "w4a16_xw.hpp", "w4a16_xw_host.hpp", "w4a16_xw_loop.inc",
+SOURCES = ["w4a16_gemm.hip", "w4a16_xk.hip", "w4a16_xw.hip", "w4a16_lean.hip", "repack.hip", "decode_ops.hip"]
+HEADERS = ["w4a16_common.hpp", "w4a16_args.hpp", "w4a16_wide.hpp", "w4a16_xk.hpp", "w4a16_xk_host.hpp", "w4a16_xw.hpp", "w4a16_xw_host.hpp", "w4a16_xw_loop.inc", "w4a16_lean.hpp", "w4a16_lean_host.hpp",
            os.path.join("..", "..", "include", "quick_amd.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"]
+# per-source extras: the lean small-M kernels take their leading arguments preloaded into SGPRs (w4a16_lean.hpp)
+EXTRA_CFLAGS = {"w4a16_lean.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
 FLAGS = CFLAGS + ["-shared"]   # (what the library is built with, for the record)
 
 
@@ -47,11 +49,11 @@ def _sha(paths, extra=""):
 
 
 def _digest(tools=False):
-    return _sha([os.path.join(CSRC, f) for f in SOURCES + HEADERS], " ".join(FLAGS) + (" tools" if tools else ""))
+    return _sha([os.path.join(CSRC, f) for f in SOURCES + HEADERS], " ".join(FLAGS) + repr(sorted(EXTRA_CFLAGS.items())) + (" tools" if tools else ""))
 
 
 def _compile(src, obj, flags, verbose):
-    cmd = [_hipcc()] + flags + ["-c", "-o", obj, os.path.join(CSRC, src)]
+    cmd = [_hipcc()] + flags + EXTRA_CFLAGS.get(src, []) + ["-c", "-o", obj, os.path.join(CSRC, src)]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -74,7 +76,7 @@ def build(force=False, verbose=False, tools=False):
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        want = _sha([os.path.join(CSRC, src)] + hdr, " ".join(flags))
+        want = _sha([os.path.join(CSRC, src)] + hdr, " ".join(flags + EXTRA_CFLAGS.get(src, [])))
         ostamp = obj + ".sha256"
         if force or not os.path.exists(obj) or not os.path.exists(ostamp) or open(ostamp).read().strip() != want:
             jobs.append((src, obj, ostamp, want))

@@ -29,6 +29,7 @@
 #include "w4a16_wide.hpp"
 #include "w4a16_xk_host.hpp"
 #include "w4a16_xw_host.hpp"
+#include "w4a16_lean_host.hpp"
 namespace quick_amd {
 
 // ------------------------------------------------------------------------------------------------
@@ -1256,6 +1257,7 @@ struct Plan {
   bool xk_loader;      // exchange-K: the twelve-wave flavour (four loader waves; kernel bit 12)
   int xk_kq;           // exchange-K: K groups of waves per workgroup, 2 (eight waves) or 4 (sixteen; kernel bit 13)
   int poll_log2;       // XW: log2 of the ticks (10 ns) a wave waits for a partner slice before it gives its block up (0 = the kernel's default)
+  int lean_tmax;       // LEAN: the most k tiles a wave may own (the build's register ring), 0 = no build for this shape
   double est_us, est_xw_us;  // launch-time model: the r02 / r03 candidates' minimum, the four-wave kernels' minimum (0 = not evaluated)
 };
 
@@ -1331,6 +1333,35 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   p.ablate = (kernel >> 16) & 31;
   p.mfma32 = ((kernel >> 13) & 1) && p.ablate == 0;
   p.wn2 = (kernel >> 15) & 1;
+  if (family == QUICK_KERNEL_LEAN) {
+    // [r05] lean small-M kernels (w4a16_lean.hpp): one workgroup per 16 tokens x (ntw x 16) channels, `waves` waves split K and request all
+    // their k tiles up front.  bits 8-11: waves / 4 (1, 2, 4; 0 = choose); bits 4-7: channel tiles per workgroup (1, 2; 0 = 1).
+    p.kernel = QUICK_KERNEL_LEAN;
+    p.ksplit = 1;
+    p.kt_per_split = KT;
+    p.mt = mt_req == 2 ? 2 : 1;
+    p.ntiles = (N / 16) * ((M + 15) / 16);
+    p.grid_x = N / 16 / p.mt;
+    static const int builds[12][3] = {{4, 8, 1}, {4, 16, 1}, {8, 4, 1}, {8, 4, 2}, {8, 8, 1}, {8, 8, 2}, {8, 12, 1}, {16, 2, 1}, {16, 2, 2}, {16, 4, 1}, {16, 4, 2}, {16, 8, 1}};
+    const auto pick = [&](int waves) {
+      if (KT < waves) return 0;
+      const int need = (KT + waves - 1) / waves;
+      int best = 0;
+      for (const auto& b : builds)
+        if (b[0] == waves && b[2] == p.mt && b[1] >= need && (best == 0 || b[1] < best)) best = b[1];
+      return best;
+    };
+    p.waves = waves_req;
+    if (!(p.waves == 4 || p.waves == 8 || p.waves == 16)) {
+      p.waves = 8;
+      while (p.waves < 16 && pick(p.waves) == 0) p.waves *= 2;
+    }
+    p.lean_tmax = pick(p.waves);
+    if (G % 128 != 0 || (size_t)K * N / 2 >= ((size_t)1 << 31) || (size_t)M * K * 2 >= ((size_t)1 << 31) ||
+        lean_lds_need(M, K, p.waves, p.mt, true) > kLdsPerCu)
+      p.lean_tmax = 0;
+    return p;
+  }
   // skinny: one workgroup per 16 tokens x 16..64 channels for all of K (x re-read per channel block, no cross-workgroup
   // reduction); tiled: 32..64 tokens x 128 channels through LDS.  Measured crossover [r01]: the tiled kernel wins from
   // M = 65, and from M = 17 once there are >= 64 tiles of 128 channels (N >= 8192) so that it needs no K split.
@@ -2175,7 +2206,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
                     void* workspace, size_t workspace_bytes, int M, int K, int N, int G, int kernel, int grid_split_k,
                     const Launch& L) {
   if (int rc = check_shapes(M, K, N, G)) return rc;
-  if ((kernel & 15) > QUICK_KERNEL_XW || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+  if ((kernel & 15) > QUICK_KERNEL_LEAN || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
 #ifndef QUICK_AMD_TOOLS
   if ((kernel >> 16) & 31)  // the timing-experiment builds (wrong results on purpose, phase stamps) are not in the product library
     return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: bits 16-20 select timing experiments that only a QUICK_AMD_TOOLS build contains", kernel);
@@ -2186,7 +2217,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   const Plan p = plan_for(M, K, N, G, kernel, grid_split_k, f.silu_mul != 0);
   if (f.silu_mul && (f.bias || f.residual)) return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual");
   if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
-  if (f.ln_w && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8))))
+  if (f.ln_w && p.kernel != QUICK_KERNEL_LEAN && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8))))
     return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
              (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr, (const half_t*)f.ln_w, f.ln_eps};
@@ -2203,7 +2234,17 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     a.counters = (unsigned*)workspace;  // zero on entry (caller's contract), zero again when the launch completes
     a.slabs = (float*)((char*)workspace + ((p.kernel == QUICK_KERNEL_XK || p.kernel == QUICK_KERNEL_XW) ? counters_bytes(p) : slabs_offset(p)));  // (exchange-K / XW: the zone)
   }
-  if (p.kernel == QUICK_KERNEL_XW) {
+  if (p.kernel == QUICK_KERNEL_LEAN) {
+    int abl = a.span ? 32 : 0;
+#ifdef QUICK_AMD_TOOLS
+    if (p.ablate == 16) abl = 64;  // phase stamps into the workspace (tools/lean_phases.py)
+    else if (p.ablate) return fail(QUICK_ERR_INVALID_ARGUMENT, "LEAN: timing-experiment bit 16 (stamps) only");
+#endif
+    if (!p.lean_tmax || !lean_launch(p.waves, p.lean_tmax, p.mt, abl, a, p.grid_x, (M + 15) / 16, L.st, L.start, L.stop)) {
+      if (abl == 32) g_span_unsupported = true;
+      return fail(QUICK_ERR_UNSUPPORTED, "no lean build for K=%d G=%d waves=%d (G %% 128 == 0, waves <= K / 128 <= 16 waves, x + table within 160 KiB of LDS)", K, G, p.waves);
+    }
+  } else if (p.kernel == QUICK_KERNEL_XW) {
     if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
     int abl = a.span ? 32 : 0;
 #ifdef QUICK_AMD_TOOLS
@@ -2332,7 +2373,10 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
   if (rc != QUICK_OK) return rc;
   if (!text || text_bytes == 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "no text buffer");
   const Plan p = make_plan(M, K, N, group_size, kernel, grid_split_k);
-  if (p.kernel == QUICK_KERNEL_SKINNY)
+  if (p.kernel == QUICK_KERNEL_LEAN)
+    snprintf(text, text_bytes, "lean ntw=%d waves=%d tiles_per_wave<=%d grid=%dx%d lds=%u workspace=0", p.mt, p.waves, p.lean_tmax, p.grid_x, (M + 15) / 16,
+             lean_lds_need(M, K, p.waves, p.mt, false));
+  else if (p.kernel == QUICK_KERNEL_SKINNY)
     snprintf(text, text_bytes, "skinny ntw=%d waves=%d x=%s dequant=%s grid=%dx%dx%d ksplit=%d workspace=%zu", p.mt, p.waves,
              p.xlds ? "lds" : "l2", p.dz ? (p.xlds ? "deferred-zero-table" : "deferred-zero-fragment") : "exact", p.grid_x,
              (M + 15) / 16, p.ksplit, p.ksplit, workspace_need(p));
