@@ -1333,34 +1333,57 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   p.ablate = (kernel >> 16) & 31;
   p.mfma32 = ((kernel >> 13) & 1) && p.ablate == 0;
   p.wn2 = (kernel >> 15) & 1;
-  if (family == QUICK_KERNEL_LEAN) {
-    // [r05] lean small-M kernels (w4a16_lean.hpp): one workgroup per 16 tokens x (ntw x 16) channels, `waves` waves split K and request all
-    // their k tiles up front.  bits 8-11: waves / 4 (1, 2, 4; 0 = choose); bits 4-7: channel tiles per workgroup (1, 2; 0 = 1).
-    p.kernel = QUICK_KERNEL_LEAN;
-    p.ksplit = 1;
-    p.kt_per_split = KT;
-    p.mt = mt_req == 2 ? 2 : 1;
-    p.ntiles = (N / 16) * ((M + 15) / 16);
-    p.grid_x = N / 16 / p.mt;
-    static const int builds[12][3] = {{4, 8, 1}, {4, 16, 1}, {8, 4, 1}, {8, 4, 2}, {8, 8, 1}, {8, 8, 2}, {8, 12, 1}, {16, 2, 1}, {16, 2, 2}, {16, 4, 1}, {16, 4, 2}, {16, 8, 1}};
-    const auto pick = [&](int waves) {
-      if (KT < waves) return 0;
-      const int need = (KT + waves - 1) / waves;
-      int best = 0;
-      for (const auto& b : builds)
-        if (b[0] == waves && b[2] == p.mt && b[1] >= need && (best == 0 || b[1] < best)) best = b[1];
-      return best;
-    };
-    p.waves = waves_req;
-    if (!(p.waves == 4 || p.waves == 8 || p.waves == 16)) {
-      p.waves = 8;
-      while (p.waves < 16 && pick(p.waves) == 0) p.waves *= 2;
+  // [r05] lean small-M kernels (w4a16_lean.hpp): one workgroup per 16 tokens x (ntw x 16) channels, `waves` waves split K and request all
+  // their k tiles up front.  Forced: family LEAN, bits 8-11 waves / 4 (1, 2, 4; 0 = choose), bits 4-7 channel tiles per workgroup (1, 2;
+  // 0 = choose).  AUTO takes them for 1..4 tokens wherever a build exists, and up to 16 tokens on layers of <= 512 channel blocks -- each
+  // workgroup fetches its own copy of x, which at 8..16 tokens on a wide layer is more L2 -> LDS traffic than the weights
+  // [profiles/r05_lean_sweep.txt: in-kernel spans against the r01-r04 skinny kernels, one session: 1 x 4096 x 4096 4.81 -> 3.65 us, 8 x: 5.28 ->
+  // 4.08, 16 x: 6.48 -> 4.58; 1 x 4096 x 12288 7.83 -> 6.77, 1 x 4096 x 22016 11.56 -> 10.64, 1 x 11008 x 4096 8.13 -> 7.00, 1 x 8192 x 8192 9.65 -> 8.36;
+  // 8 x 4096 x 22016 13.6 -> 15.1 and 16 x 4096 x 12288 9.9 -> 10.7 stay with the old kernels].  QUICK_AMD_LEAN=0 switches the AUTO rule off (A/B).
+  {
+    static const int builds[7][3] = {{8, 4, 1}, {8, 4, 2}, {8, 8, 1}, {8, 12, 1}, {16, 4, 1}, {16, 4, 2}, {16, 8, 1}};
+    const int mblocks = (M + 15) / 16;
+    const bool forced = family == QUICK_KERNEL_LEAN;
+    static const bool lean_on = [] {
+      const char* e = getenv("QUICK_AMD_LEAN");
+      return !(e && *e && atoi(e) == 0);
+    }();
+    const bool envelope = G % 128 == 0 && (size_t)K * N / 2 < ((size_t)1 << 31) && (size_t)M * K * 2 < ((size_t)1 << 31);
+    if (forced || (family == QUICK_KERNEL_AUTO && lean_on && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M <= 16 &&
+                   (M <= 4 || N / 16 <= 512))) {
+      int bw = 0, bt = 0, bn = 0;
+      double bcost = 0;
+      for (const auto& b : builds) {
+        const int waves = b[0], tmax = b[1], ntw = b[2];
+        if (forced && ((waves_req && waves != waves_req) || (mt_req && ntw != mt_req))) continue;
+        if (KT < waves || (KT + waves - 1) / waves > tmax || (N / 16) % ntw != 0) continue;
+        if (lean_lds_need(M, K, waves, ntw, true) > kLdsPerCu) continue;
+        // what the fullest CU streams: rounds of workgroups x bytes per workgroup; two tiles per workgroup share the head (0.85, measured);
+        // sixteen waves with <= 4 tiles each and twelve tiles per wave cost
+        const long wgs = (long)(N / 16 / ntw) * mblocks;
+        double cost = (double)((wgs + 255) / 256) * ntw * (ntw == 2 ? 0.85 : 1.0);
+        if (waves == 16 && tmax <= 4) cost *= 1.13;
+        if (tmax >= 12) cost *= 1.12;
+        cost *= 1.0 + 0.001 * tmax;  // (ties: the smallest register ring)
+        if (bw == 0 || cost < bcost) {
+          bcost = cost;
+          bw = waves;
+          bt = tmax;
+          bn = ntw;
+        }
+      }
+      if (forced || bw) {
+        p.kernel = QUICK_KERNEL_LEAN;
+        p.ksplit = 1;
+        p.kt_per_split = KT;
+        p.mt = bn ? bn : (mt_req == 2 ? 2 : 1);
+        p.waves = bw ? bw : (waves_req ? waves_req : 8);
+        p.lean_tmax = envelope ? bt : 0;
+        p.ntiles = (N / 16) * mblocks;
+        p.grid_x = N / 16 / p.mt;
+        return p;
+      }
     }
-    p.lean_tmax = pick(p.waves);
-    if (G % 128 != 0 || (size_t)K * N / 2 >= ((size_t)1 << 31) || (size_t)M * K * 2 >= ((size_t)1 << 31) ||
-        lean_lds_need(M, K, p.waves, p.mt, true) > kLdsPerCu)
-      p.lean_tmax = 0;
-    return p;
   }
   // skinny: one workgroup per 16 tokens x 16..64 channels for all of K (x re-read per channel block, no cross-workgroup
   // reduction); tiled: 32..64 tokens x 128 channels through LDS.  Measured crossover [r01]: the tiled kernel wins from
@@ -2365,6 +2388,7 @@ int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size) {
   // the deferred-zero skinny kernel copies (and tabulates) x per workgroup anyway: normalising on the way costs a
   // second pass over LDS, not a launch
   const Plan p = make_plan(M, K, N, group_size, QUICK_KERNEL_AUTO, 0);
+  if (p.kernel == QUICK_KERNEL_LEAN) return p.lean_tmax > 0;   // x * weight in LDS on the way in, 1 / rms on the fp32 result
   return p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8));
 }
 

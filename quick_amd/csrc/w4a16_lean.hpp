@@ -60,7 +60,7 @@ __device__ __forceinline__ void lean_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned
 // unit sums between two tiles and halves the workgroup count: on wide layers all of them are resident at once and the whole weight
 // matrix is in flight after the first microsecond.  Straight-line code: hipcc's s_waitcnt placement is
 // exact there (one counted wait per tile), while any loop carrying requests around its back edge made it drain the queue at the loop head.
-template <int WAVES, int TMAX, int NTW, int GM, int ABL>
+template <int WAVES, int TMAX, int NTW, int GM, int ABL, bool LN, int MR>
 __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __restrict__ aX, const u32x4* __restrict__ aQW, const half_t* __restrict__ aS,
                                                                 const half_t* __restrict__ a_lnw, int aK, int aN, int aM, unsigned groups, int gx, unsigned tpg,
                                                                 const LeanRest rest) {
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
   const int n16 = lane & 15, q = lane >> 4;
   const int KT = aK >> 7;
   const int row0 = blockIdx.y * 16, rows = min(16, aM - row0);
-  const bool ln = a_lnw != nullptr;
+  constexpr bool ln = LN;  // (a_lnw != nullptr: the launcher picks the instantiation)
   // XCD-aware block order (workgroups are dealt to the XCDs round-robin: a contiguous run of channel blocks per XCD shares the
   // 128-byte lines of their group words)
   const int nb = (gx & 7) == 0 ? ((int)blockIdx.x & 7) * (gx >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
@@ -147,36 +147,86 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
   // so lane (n16, q) ends up with A (even n16) or C (odd n16) of its tokens 4q .. 4q+3
   const u32x4 bc_bits = (lane & 1) ? u32x4{0x64006400u, 0x54005400u, 0x64006400u, 0x54005400u} : u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
   const half8_t bconst = __builtin_bit_cast(half8_t, bc_bits);
-  char* xl = smem + x_off + (unsigned)min(n16, rows - 1) * pitch + (unsigned)q * 16u;  // A fragment rows: token n16 (rows past M replay the last)
+  const char* xl = smem + x_off + (unsigned)min(n16, rows - 1) * pitch + (unsigned)q * 16u;  // A fragment rows: token n16 (rows past M replay the last)
   const char* gl = smem + lnw_off + (unsigned)q * 16u;
-  floatx4 sm[TMAX];
+  // MR = 16: the unit sums from the matrix core (sm: lane holds A or C of its four tokens); MR = 1, 4 (that many tokens at most): the unit
+  // sums as wave-uniform scalars -- computed on the compact copy (lane L = 8 consecutive k of one token), summed over the sixteen lanes of a
+  // k tile and read into SGPRs.  Half the MFMAs and LDS fragment reads per tile of the MR = 16 form, which at 1..4 tokens on a wide layer
+  // are what the launch runs out of first (both pipes ~50 % busy at the weights' HBM rate; with the RMSNorm prologue on fragments, over it).
+  constexpr int SMR = MR == 16 ? 1 : MR;
+  floatx4 sm[MR == 16 ? TMAX : 1];
+  float sA[MR == 16 ? 1 : TMAX][SMR], sC[MR == 16 ? 1 : TMAX][SMR];
   floatx4 sq = floatx4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (MR == 16) {
 #pragma unroll
-  for (int j = 0; j < TMAX; ++j) {
-    sm[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    if (j < T) {  // wave-uniform
-      const unsigned ko = (unsigned)(kb + j) * 256u;
-      half8_t xf[4];
+    for (int j = 0; j < TMAX; ++j) {
+      sm[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+      if (j < T) {  // wave-uniform
+        const unsigned ko = (unsigned)(kb + j) * 256u;
+        half8_t xf[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) xf[t] = *(const half8_t*)(xl + ko + 64 * t);
-      if (ln) {
-        // RMSNorm: x * weight in fp16 back into LDS (rows past M: the same bytes again), sum of squares of the raw x as the diagonal of x x^T
+        for (int t = 0; t < 4; ++t) xf[t] = *(const half8_t*)(xl + ko + 64 * t);
+        if constexpr (LN) {
+          // RMSNorm: sum of squares of the raw x as the diagonal of x x^T; x * weight in fp16 (nothing is written back: the tile loop below
+          // multiplies again -- an in-place update chains every tile's reads behind the previous tile's writes)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const half8_t gf = *(const half8_t*)(gl + ko + 64 * t);
-          sq = mfma16(xf[t], xf[t], sq);
-          xf[t] = xf[t] * gf;
-          *(half8_t*)(xl + ko + 64 * t) = xf[t];
+          for (int t = 0; t < 4; ++t) {
+            const half8_t gf = *(const half8_t*)(gl + ko + 64 * t);
+            sq = mfma16(xf[t], xf[t], sq);
+            xf[t] = xf[t] * gf;
+          }
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sm[j] = mfma16(xf[t], bconst, sm[j]);
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) sm[j] = mfma16(xf[t], bconst, sm[j]);
     }
-  }
-  if (ln) {
+    if constexpr (LN) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (n16 == 4 * q + r) ((float*)(smem + ssq_off))[wave * 16 + n16] = sq[r];
+      for (int r = 0; r < 4; ++r)
+        if (n16 == 4 * q + r) ((float*)(smem + ssq_off))[wave * 16 + n16] = sq[r];
+    }
+  } else {
+    float ss[SMR];
+#pragma unroll
+    for (int tk = 0; tk < SMR; ++tk) ss[tk] = 0.f;
+#pragma unroll
+    for (int sg = 0; sg < NSZ; ++sg) {
+      const bool mine = lane < 16 * (T - 4 * sg);
+      const unsigned cb = (unsigned)(kb * 128 + 512 * sg) * 2u + (unsigned)lane * 16u;
+      u32x4 gv = u32x4{0u, 0u, 0u, 0u};
+      if constexpr (LN) gv = mine ? *(const u32x4*)(smem + lnw_off + cb) : gv;
+#pragma unroll
+      for (int tk = 0; tk < SMR; ++tk) {
+        char* xp = smem + x_off + (unsigned)min(tk, rows - 1) * pitch + cb;  // (tokens past M: the last one again, never stored)
+        u32x4 v = mine ? *(const u32x4*)xp : u32x4{0u, 0u, 0u, 0u};
+        if constexpr (LN) {
+          // RMSNorm: x * weight in fp16 back into the compact copy (lane-linear, before any fragment of it is read), squares summed per lane
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ss[tk] = __builtin_amdgcn_fdot2(as_h2(v[i]), as_h2(v[i]), ss[tk], false);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = as_u32(as_h2(v[i]) * as_h2(gv[i]));
+          if (mine && tk < rows) *(u32x4*)xp = v;
+        }
+        const half2_t one2 = {(half_t)1.f, (half_t)1.f};
+        const float lo = __builtin_amdgcn_fdot2(as_h2(v[0]), one2, __builtin_amdgcn_fdot2(as_h2(v[2]), one2, 0.f, false), false);
+        const float hi = __builtin_amdgcn_fdot2(as_h2(v[1]), one2, __builtin_amdgcn_fdot2(as_h2(v[3]), one2, 0.f, false), false);
+        const float sa = lanes_sum<16>(lo + hi);
+        const float sc = lanes_sum<16>(1024.f * lo + 64.f * hi);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          if (4 * sg + qq < TMAX) {
+            sA[4 * sg + qq][tk] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sa), 16 * qq));
+            sC[4 * sg + qq][tk] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), 16 * qq));
+          }
+      }
+    }
+    if constexpr (LN) {
+#pragma unroll
+      for (int tk = 0; tk < SMR; ++tk) {
+        const float tot = wave_sum(ss[tk]);
+        if (lane == 0) ((float*)(smem + ssq_off))[wave * 16 + tk] = tot;
+      }
+    }
   }
   // this lane's (scale, zero) words, one per tile, out of the four-tile requests
   uint32_t szj[NTW][TMAX];
@@ -188,6 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
 
   // ---- 4. the tiles, in the order they land ----
   const bool odd = (lane & 1) != 0;
+  (void)odd;
   floatx4 acc[NTW];
 #pragma unroll
   for (int c = 0; c < NTW; ++c) acc[c] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -198,13 +249,25 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
       half8_t xf[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) xf[t] = *(const half8_t*)(xl + ko + 64 * t);
-      floatx4 xa, nc;
+      if constexpr (LN && MR == 16) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float mine = sm[j][r];
-        const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0xB1, 0xf, 0xf, false));
-        xa[r] = odd ? other : mine;
-        nc[r] = -(odd ? mine : other);
+        for (int t = 0; t < 4; ++t) xf[t] = xf[t] * *(const half8_t*)(gl + ko + 64 * t);
+      }
+      floatx4 xa, nc;
+      if constexpr (MR == 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mine = sm[j][r];
+          const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0xB1, 0xf, 0xf, false));
+          xa[r] = odd ? other : mine;
+          nc[r] = -(odd ? mine : other);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // (lanes q = 0 hold tokens 0..3; the other rows are never stored)
+          xa[r] = sA[j][r % SMR];
+          nc[r] = -sC[j][r % SMR];
+        }
       }
       if constexpr (STAMP) {
         if (j == 0) {
@@ -243,7 +306,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) sum += red[(w * NTW + wave) * 64 + lane];
     // lane (n16, q) holds tokens 4q .. 4q+3 of channel n16
-    if (ln) {
+    if constexpr (LN) {
       const float* sqp = (const float*)(smem + ssq_off);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

@@ -1,0 +1,8 @@
+// Lean small-M kernels (w4a16_lean.hpp): instantiations, part a (one translation unit per group of builds: they compile in parallel).
+#include "w4a16_common.hpp"
+#include "w4a16_lean_inst.hpp"
+
+namespace quick_amd {
+QA_LEAN_INSTANTIATE(8, 4, 1)
+QA_LEAN_INSTANTIATE(8, 4, 2)
+}  // namespace quick_amd

@@ -1,0 +1,70 @@
+// Lean small-M kernels: the per-build launcher template (group mode, RMSNorm prologue and token-count flavours of one (waves, tiles per wave,
+// channel tiles) build).  Explicitly instantiated in w4a16_lean_a/b/c.hip so that the builds compile in parallel; w4a16_lean.hip dispatches.
+#pragma once
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+
+#include "w4a16_args.hpp"
+#include "w4a16_lean.hpp"
+#include "w4a16_lean_host.hpp"
+
+namespace quick_amd {
+
+template <int WAVES, int TMAX, int NTW, int GM, int ABL, bool LN, int MR>
+static bool lean_go(const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+  auto kfn = w4a16_lean_kernel<WAVES, TMAX, NTW, GM, ABL, LN, MR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const unsigned lds = lean_lds_need(a.M, a.K, WAVES, NTW, a.ln_w != nullptr);
+  LeanRest rest{};
+  rest.Y = a.Y; rest.bias = a.bias; rest.residual = a.residual; rest.silu_mul = a.silu_mul; rest.ln_eps = a.ln_eps; rest.span = a.span; rest.dbg = a.dbg;
+  hipExtLaunchKernelGGL(kfn, dim3(grid_x, grid_y), dim3(WAVES * 64), lds, st, start, stop, 0, a.X, a.QW, a.S, a.ln_w, a.K, a.N, a.M, (unsigned)(a.K / a.G), grid_x,
+                        (unsigned)a.tpg, rest);
+  return true;
+}
+
+// token-count flavour: 1 token / up to 4 tokens with the unit sums as scalars (while TMAX * 4 * 2 of them fit the SGPRs), else the matrix-core sums
+template <int WAVES, int TMAX, int NTW, int GM, int ABL, bool LN>
+static bool lean_go_m(const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+  if (a.M == 1) return lean_go<WAVES, TMAX, NTW, GM, ABL, LN, 1>(a, grid_x, grid_y, st, start, stop);
+  if constexpr (TMAX <= 8) {
+    if (a.M <= 4) return lean_go<WAVES, TMAX, NTW, GM, ABL, LN, 4>(a, grid_x, grid_y, st, start, stop);
+  }
+  return lean_go<WAVES, TMAX, NTW, GM, ABL, LN, 16>(a, grid_x, grid_y, st, start, stop);
+}
+
+template <int WAVES, int TMAX, int NTW, int ABL>
+bool lean_build(const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+  if constexpr (ABL == 0) {
+    if (a.ln_w != nullptr) {
+      if (a.G == 128) return lean_go_m<WAVES, TMAX, NTW, 0, ABL, true>(a, grid_x, grid_y, st, start, stop);
+      return lean_go_m<WAVES, TMAX, NTW, 1, ABL, true>(a, grid_x, grid_y, st, start, stop);
+    }
+    if (a.G == 128) return lean_go_m<WAVES, TMAX, NTW, 0, ABL, false>(a, grid_x, grid_y, st, start, stop);
+    return lean_go_m<WAVES, TMAX, NTW, 1, ABL, false>(a, grid_x, grid_y, st, start, stop);
+  } else {  // span / phase stamps: G = 128, the stamps of the RMSNorm prologue on the 8 x 4 builds only
+    if (a.G != 128) return false;
+    if (a.ln_w != nullptr) {
+      if constexpr (ABL == 64 && WAVES == 8 && TMAX == 4) return lean_go_m<WAVES, TMAX, NTW, 0, ABL, true>(a, grid_x, grid_y, st, start, stop);
+      return false;
+    }
+    return lean_go_m<WAVES, TMAX, NTW, 0, ABL, false>(a, grid_x, grid_y, st, start, stop);
+  }
+}
+
+#ifdef QUICK_AMD_TOOLS
+#define QA_LEAN_INSTANTIATE(W, T, C)                                                                                    \
+  template bool lean_build<W, T, C, 0>(const GemmArgs&, int, int, hipStream_t, hipEvent_t, hipEvent_t);                 \
+  template bool lean_build<W, T, C, 32>(const GemmArgs&, int, int, hipStream_t, hipEvent_t, hipEvent_t);                \
+  template bool lean_build<W, T, C, 64>(const GemmArgs&, int, int, hipStream_t, hipEvent_t, hipEvent_t);
+#else
+#define QA_LEAN_INSTANTIATE(W, T, C)                                                                                    \
+  template bool lean_build<W, T, C, 0>(const GemmArgs&, int, int, hipStream_t, hipEvent_t, hipEvent_t);                 \
+  template bool lean_build<W, T, C, 32>(const GemmArgs&, int, int, hipStream_t, hipEvent_t, hipEvent_t);
+#endif
+
+}  // namespace quick_amd

@@ -1352,3 +1352,71 @@ def test_decode_full_stack_llama2_7b_fused_against_torch_ops(qa, device):
             mask[..., ctx + step + 1] = 0
         del ma, mb_
         torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------
+# lean small-M kernels (r05, w4a16_lean.hpp): x by LDS-DMA first in the memory queue, every weight tile of a wave requested
+# up front, unit sums and the RMSNorm sum of squares from the matrix core
+# ------------------------------------------------------------------------------------------------
+LEAN = 6
+
+
+def lean(ntw, waves):
+    return LEAN | (ntw << 4) | ((waves // 4) << 8)
+
+
+LEAN_SHAPES = [(1, 1024, 256, 128), (3, 2048, 384, 128), (16, 1024, 128, 128), (5, 1536, 256, 256), (9, 4096, 512, 128), (2, 1152, 256, 384),
+               (20, 1024, 256, 128), (4, 2176, 256, 128), (7, 8192, 256, 128), (1, 11008, 128, 128), (13, 1280, 1280, 128), (2, 8192, 256, 128),
+               (4, 4096, 384, 256), (1, 5120, 256, 128), (3, 14336, 128, 128), (4, 7168, 256, 128)]
+
+
+@pytest.mark.parametrize("ntw,waves", [(1, 8), (1, 16), (2, 8), (2, 16)])
+@pytest.mark.parametrize("M,K,N,G", LEAN_SHAPES)
+def test_lean_family_against_oracle(qa, device, M, K, N, G, ntw, waves):
+    """Every build of the lean kernel on ragged k ranges (k tiles that do not divide by the waves, partly filled x segments), one and
+    two token blocks, G = 128 / 256 / 384; the plain GEMM twice (bit-identical), bias + residual, SiLU * mul and the RMSNorm prologue."""
+    from quick_amd import kernels as K_
+    kid = lean(ntw, waves)
+    if "tiles_per_wave<=0" in K_.plan_describe(M, K, N, G, kid):
+        pytest.skip("no lean build for this k range / LDS footprint")
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + K + N + G + waves)
+    want = oracle.w4a16_forward(x, iw, s, z, G).astype(np.float32)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device)
+    y = qa.gemm_forward(xd, *packed, kernel_id=kid)
+    assert rel_err(y.cpu().numpy(), want) <= TOL
+    assert torch.equal(y, qa.gemm_forward(xd, *packed, kernel_id=kid))
+    bias = np.linspace(-1, 1, N).astype(np.float16)
+    res = (np.random.default_rng(M + N).standard_normal((M, N)) * 0.5).astype(np.float16)
+    y = qa.gemm_forward(xd, *packed, bias=_dev(bias, device), residual=_dev(res, device), kernel_id=kid)
+    assert rel_err(y.cpu().numpy(), want + bias.astype(np.float32) + res.astype(np.float32)) <= TOL
+    gu = torch.from_numpy(want).half().view(M, N // 16, 2, 8)                  # gate / up interleaved by 8
+    ref = (torch.nn.functional.silu(gu[:, :, 0].float()).half() * gu[:, :, 1]).reshape(M, N // 2).float().numpy()
+    y = qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kid)
+    assert tuple(y.shape) == (M, N // 2) and rel_err(y.cpu().numpy(), ref) <= 2 * TOL
+    lnw = (torch.rand(K, device=device) + 0.5).half()
+    x3 = xd * 3
+    xn = (x3.float() * torch.rsqrt(x3.float().pow(2).mean(-1, keepdim=True) + 1e-5)).half() * lnw
+    want_ln = oracle.w4a16_forward(xn.cpu().numpy(), iw, s, z, G).astype(np.float32) + res.astype(np.float32)
+    y = qa.gemm_forward(x3, *packed, rmsnorm_weight=lnw, rmsnorm_eps=1e-5, residual=_dev(res, device), kernel_id=kid)
+    assert rel_err(y.cpu().numpy(), want_ln) <= TOL
+
+
+def test_lean_reference_pin_and_poisoned_output(qa, device, pin):
+    """The reference-made 4096^2 pin through every lean build (sampled outputs of the REFERENCE's CPU path on the same layer), results
+    into a NaN-poisoned buffer: every element of y is written, nothing next to it is."""
+    from quick_amd import kernels as K_
+    g, iw, s, z = pin
+    packed = _pack_dev(iw, s, z, device)
+    ref = g["y_ref"].astype(np.float32)
+    x = _dev(g["x"], device)
+    M, N = x.shape[0], packed[0].shape[1] // 4 * 8
+    for kid in (lean(1, 8), lean(1, 16), lean(2, 8), lean(2, 16), 0):
+        if "tiles_per_wave<=0" in K_.plan_describe(M, 4096, N, 128, kid):
+            continue                                        # (16 tokens x 4096 k of x beside 16 waves' partials: beyond 160 KiB of LDS)
+        out = torch.full((M + 2, N), float("nan"), dtype=torch.float16, device=device)
+        y = qa.gemm_forward(x, *packed, kernel_id=kid, out=out[1:M + 1]).cpu().numpy().astype(np.float32)
+        assert float(np.abs(y[g["y_rows"], g["y_cols"]] - ref).max()) <= TOL * float(np.abs(ref).max())
+        assert float(np.abs(np.abs(y).sum(0) - g["col_abs_sum"]).max()) <= TOL * float(g["col_abs_sum"].max())
+        assert torch.isnan(out[0]).all() and torch.isnan(out[M + 1]).all() and not torch.isnan(out[1:M + 1]).any()
+    assert K_.plan_describe(1, 4096, 4096, 128).startswith("lean")

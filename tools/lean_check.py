@@ -44,15 +44,15 @@ for spec in specs:
     algo = K * N / 2 + (K // G) * N * 2.5 + 2 * M * K + 2 * M * N
     base = timed(M, K, N, 0, sets, x, y, ws)
     print(f"{spec}: planner [{kernels.plan_describe(M, K, N, G)}] span {base[0]:.2f} us ({algo / base[0] / 8e6 * 100:.1f}% of 8 TB/s), dispatch {base[1]:.2f}")
-    for waves in (4, 8, 16):
-        kid = LEAN | ((waves // 4) << 8)
+    for ntw, waves in ((1, 8), (1, 16), (2, 8), (2, 16)):
+        kid = LEAN | (ntw << 4) | ((waves // 4) << 8)
         try:
             plan = kernels.plan_describe(M, K, N, G, kid)
         except Exception as e:
-            print(f"   waves={waves}: {e}")
+            print(f"   ntw={ntw} waves={waves}: {e}")
             continue
         if "tiles_per_wave<=0" in plan:
-            print(f"   waves={waves}: no build")
+            print(f"   ntw={ntw} waves={waves}: no build")
             continue
         err = ""
         if check:
@@ -63,4 +63,4 @@ for spec in specs:
             e = np.abs(got - want.astype(np.float32)).max() / np.abs(want.astype(np.float32)).max()
             err = f" rel_err {e:.2e}{'  <-- WRONG' if not e <= 2e-3 else ''}"
         t = timed(M, K, N, kid, sets, x, y, ws)
-        print(f"   lean waves={waves:2d} [{plan}] span {t[0]:.2f} us ({algo / t[0] / 8e6 * 100:.1f}%), dispatch {t[1]:.2f}{err}")
+        print(f"   [{plan}] span {t[0]:.2f} us ({algo / t[0] / 8e6 * 100:.1f}%), dispatch {t[1]:.2f}{err}")

@@ -10,6 +10,8 @@ dev = torch.device("cuda:0")
 G = 128
 args = sys.argv[1:]
 waves_list = [4, 8]
+use_ln = "--ln" in args
+args = [a for a in args if a != "--ln"]
 if args and args[0] == "--waves":
     waves_list = [int(v) for v in args[1].split(",")]
     args = args[2:]
@@ -22,6 +24,7 @@ for spec in (args or ["1x4096x4096", "8x4096x4096", "1x4096x22016", "8x4096x2201
     nsets = max(2, min(40, int(400e6 / (K * N / 2)) + 1))
     sets = [packing.random_mi355x(K, N, G, dev) for _ in range(nsets)]
     y = torch.empty(M, N, dtype=torch.float16, device=dev)
+    lnw = (torch.rand(K, device=dev) + 0.5).half()
     for waves in waves_list:
         kid = 6 | ((waves // 4) << 8)
         plan = kernels.plan_describe(M, K, N, G, kid)
@@ -34,8 +37,14 @@ for spec in (args or ["1x4096x4096", "8x4096x4096", "1x4096x22016", "8x4096x2201
         for i in range(nsets + REP):
             qw, sc, qz = sets[i % nsets]
             ws.zero_()
-            rc = lib.quick_w4a16_gemm_f16_ex(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, y.data_ptr(), ws.data_ptr(),
-                                             ws.numel() * 8, M, K, N, G, k16, 0, None)
+            if use_ln:
+                fu = _lib.GemmFusion(None, None, lnw.data_ptr(), 1e-5, 0)
+                import ctypes
+                rc = lib.quick_w4a16_gemm_f16_fused(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), ctypes.byref(fu), y.data_ptr(), ws.data_ptr(),
+                                                    ws.numel() * 8, M, K, N, G, k16, 0, None)
+            else:
+                rc = lib.quick_w4a16_gemm_f16_ex(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, y.data_ptr(), ws.data_ptr(),
+                                                 ws.numel() * 8, M, K, N, G, k16, 0, None)
             assert rc == 0, _lib.last_error()
             if i >= nsets:
                 torch.cuda.synchronize()
@@ -44,7 +53,7 @@ for spec in (args or ["1x4096x4096", "8x4096x4096", "1x4096x22016", "8x4096x2201
                 acc.append(np.concatenate([raw[:, :1], raw[:, 11:13], raw[:, 10:11], raw[:, 1:10]], axis=1))
         nw = len(acc[0])
         tot = np.mean([d[:, 12].max() - d[:, 0].min() for d in acc])
-        print(f"{spec}: {plan}\n   {nw} waves stamped (of {N // 16 * waves}), {REP} launches; first entry -> last exit {tot:.2f} us")
+        print(f"{spec}{' +rmsnorm' if use_ln else ''}: {plan}\n   {nw} waves stamped (of {N // 16 * waves}), {REP} launches; first entry -> last exit {tot:.2f} us")
         print(f"   {'phase (us since the first wave entered)':52s} {'first':>7s} {'mean':>7s} {'last':>7s}    own: min  mean  max (since the wave's previous stamp)")
         for i, n in enumerate(NAMES):
             rel = [d[:, i] - d[:, 0].min() for d in acc]
