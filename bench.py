@@ -97,20 +97,23 @@ def pmc_traffic(M, K, N, G, kernel, plan):
 def pmc_issue_mix(M, K, N, G, kernel, src):
     """north_star: "evidenced by rocprof MFMA-busy %".  From the same committed counter pass as `traffic` (accepted only if it is
     about the kernel the planner picks today): the share of the launch during which the matrix pipes were busy --
-    SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the 1024 SIMDs) / (1024 * GRBM_GUI_ACTIVE / 8 XCDs) -- and the VALU-class
-    instructions issued per MFMA (SQ_INSTS_VALU counts the MFMAs themselves)."""
+    SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the 1024 SIMDs) / (1024 * SQ_BUSY_CYCLES / 32 shader engines) -- and the VALU-class
+    instructions issued per MFMA (SQ_INSTS_VALU counts the MFMAs themselves).  [r05] The denominator was GRBM_GUI_ACTIVE / 8 until
+    r04: that counter carries ~20 k cycles of dispatch overhead per launch (30.8 k "active" cycles for a 5.9 us dispatch would be a
+    5.2 GHz clock), which under-read every short launch; SQ_BUSY_CYCLES / 32 agrees with the kernels' own s_memtime clocks."""
     if not src or "file" not in src or "rejected" in src:
         return {}
     here = os.path.dirname(os.path.abspath(__file__))
     vals = {}
     for line in open(os.path.join(here, src["file"])):
         f = line.split()
-        if len(f) >= 2 and f[0] in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_WAVE_CYCLES",
+        if len(f) >= 2 and f[0] in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_WAVE_CYCLES",
                                     "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") and f[0] not in vals:
             vals[f[0]] = float(f[1])
     out = {}
-    if vals.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
-        out["mfma_busy_frac"] = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0)
+    if vals.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
+        out["mfma_busy_frac"] = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * vals["SQ_BUSY_CYCLES"] / 32.0)
+        out["mfma_busy_denominator"] = "1024 SIMDs x SQ_BUSY_CYCLES / 32"
     if vals.get("SQ_INSTS_MFMA") and "SQ_INSTS_VALU" in vals:
         out["valu_per_mfma"] = vals["SQ_INSTS_VALU"] / vals["SQ_INSTS_MFMA"]
     if vals.get("SQ_WAVE_CYCLES"):
@@ -250,8 +253,11 @@ def main():
         # ... and bring the clocks back up on weight sets the timed replay does not touch (the flush is memory-bound: the first
         # launches behind it would otherwise read the clock ramp, 20 steps are only 0.1-0.5 ms)
         spare = [j % n_sets for j in range(warmup + steps, warmup + steps + n_sets) if (j % n_sets) not in {(warmup + i) % n_sets for i in range(steps)}]
-        for j in spare[:12]:
-            launch(j)
+        # [r05] 12 launches were 0.05-0.26 ms: shorter than the clock ramp (the driver's 20-step run read the M = 512 step 1.4 us above the
+        # kernel's own duration measured later in the same process).  150 launches round-robin over the spare sets = 0.6-3.5 ms.
+        n_warm = 150 if spare else 0
+        for r in range(n_warm):
+            launch(spare[r % len(spare)])
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -316,8 +322,16 @@ def main():
         roof.update({"kernel_us": k_us, "kernel_us_event_pairs": k_us_events, "kernel_us_cache_resident": k_us_hot,
                      "algorithmic_bytes": nbytes, "flops": flops})
         roof.update(pmc_issue_mix(M, K, N, G, args.kernel, roof["traffic_source"]))
+        # the ONE headline fraction: whole-step throughput (what `value` is made of) over the peak; `frac` is the same work over the
+        # kernel's own dispatch duration (the clock rocprofv3 --kernel-trace reads), `frac_inkernel` over the first-wave-in -> last-wave-out span
+        step_work = (nbytes / 1e9 if roof["bound"] == "hbm" else flops / 1e12) / (ms_step * 1e-3)
+        roof["frac_step"] = step_work / roof["peak"]
+        roof["headline_fraction"] = "frac_step"
+        roof["frac_clocks"] = {"frac_step": "graph-replayed step, barrier to barrier", "frac": "dispatch duration (event pair = rocprofv3 kernel trace)",
+                               "frac_inkernel": "per-wave s_memrealtime stamps, first wave in -> last wave out"}
         return {"M": M, "ms_per_step": ms_step, "tops": flops / (ms_step * 1e-3) / 1e12, "tops_kernel_only": flops / (k_us * 1e-6) / 1e12,
                 "launch": mode, "weight_sets_in_timed_region": min(steps, n_sets), "cache_flushed_before_timed_region": True,
+                "clock_warmup_launches_on_other_weight_sets": n_warm,
                 "roofline": roof}, y
 
     fl = (ctypes.c_float * 60)()
@@ -473,6 +487,13 @@ def main():
         t0 = time.perf_counter()
         torch.matmul(x_t, w_cpu)
         t_mm = time.perf_counter() - t0
+        # companion figure: the same product in fp32 (hosts whose BLAS has no fast fp16 GEMM read the fp16 line hundreds of times slower than
+        # the arithmetic warrants; the reference's CPU path IS the fp16 one, this one only makes the line readable)
+        x32, w32 = x_t.float(), w_cpu.float()
+        torch.matmul(x32, w32)
+        t0 = time.perf_counter()
+        torch.matmul(x32, w32)
+        t_mm32 = time.perf_counter() - t0
         full_layer_ms = dt * 1e3 * N / n_cpu
         out["cpu_baseline"] = {
             "value": algorithmic_flops(args.M, K, n_cpu) / dt / 1e12, "unit": "TFLOP/s", "cores": cores,
@@ -481,6 +502,8 @@ def main():
                       f"oracle/cpu_path.py) on output channels 0..{n_cpu - 1} of the M={args.M} K={K} N={N} g={G} layer, "
                       f"{total:.1f} s on {cores} torch threads",
             "split_ms": {"dequantize": t_deq * 1e3, "matmul_fp16": t_mm * 1e3},
+            "companion_fp32": {"kind": "port-fp32", "value": algorithmic_flops(args.M, K, n_cpu) / (t_deq + t_mm32) / 1e12, "unit": "TFLOP/s",
+                               "ms_per_call": (t_deq + t_mm32) * 1e3, "what": "the same dequantisation + torch.matmul in fp32 on the same slice, one call"},
             "full_layer_ms_extrapolated": full_layer_ms, "baseline_md_full_layer_ms": 73.3,
             "deviates_over_10x_from_baseline_md": bool(full_layer_ms > 733.0 or full_layer_ms < 7.33),
             "torch_parallel_info": torch.__config__.parallel_info().strip().splitlines()[:6],

@@ -101,6 +101,19 @@ int quick_w4a16_gemm_f16(const void* x, const void* qweight, const void* scales,
 
 size_t quick_w4a16_workspace_bytes(int M, int K, int N, int group_size, int split_k_iters);
 
+/* Is the workspace in the state every launch expects -- arrival counters, part state words and the exchange zone all-zero?  One pass
+ * over the guarded regions (64 KiB + 16 MiB, or the whole buffer if smaller) on `hip_stream`, then a stream synchronise: QUICK_OK, or
+ * QUICK_ERR_WORKSPACE with the first dirty byte offset in quick_amd_last_error().  Why it exists: the K slices of an exchange launch
+ * hand their partial tiles over in 16-byte granules that are their own arrival flags (no dword of a payload granule is ever 0), and the
+ * payload -- eight fp16 partial sums -- has no spare bits for a launch epoch; a separate epoch word per box would need the sender's
+ * stores acknowledged before it may be written, the round trip the protocol exists to avoid.  So a granule left behind by an aborted
+ * launch cannot be told from a partner's, and the contract is "zero between launches": the library keeps it on every path (also when
+ * waves give up), this call verifies it, and QUICK_AMD_CHECK_WORKSPACE=1 in the environment runs it in front of every
+ * launch that uses the regions (debugging: it synchronises).  Python: quick_amd.kernels zeroes its per-stream workspace again
+ * whenever a launch returns an error.  The reference's split-K scratch + `.sum(0)` (csrc/gemm_cuda_quick.cu:1468,1515) holds no state
+ * between launches; this is the price of reducing inside the launch. */
+int quick_w4a16_workspace_check(const void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Same as quick_w4a16_gemm_f16 with an explicit kernel choice, an optional fp16 bias[N] added in the
  * epilogue (NULL = none; replaces the separate torch add of quick/awq/modules/linear/quick.py:165), and a
  * forced K split across workgroups (0 = heuristic).

@@ -19,6 +19,7 @@ _SIGNATURES = {
     "quick_amd_last_error": (ctypes.c_char_p, []),
     "quick_w4a16_gemm_f16": (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     "quick_w4a16_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "quick_w4a16_workspace_check": (_I, [_P, _Z, _P]),
     "quick_w4a16_gemm_f16_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),
     "quick_w4a16_workspace_bytes_ex": (_Z, [_I, _I, _I, _I, _I, _I]),
     "quick_w4a16_gemm_profile": (_I, [_P, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -6,7 +6,7 @@ The shared object lands in quick_amd/lib/ (git-ignored, but it travels to the GP
 working-tree snapshot).  Cross-compiles without a GPU.  Every translation unit is compiled to its own
 object (in parallel, rebuilt only when it or a header changed) and the objects are linked.
 
---tools builds quick_amd/lib/libquick_amd_tools.so instead: the same library plus the timing-experiment
+--tools builds tools/bin/libquick_amd_tools.so instead: the same library plus the timing-experiment
 kernels (ablations with wrong results, phase stamps) that tools/*.py ask for through kernel-id bits 16-20
 (-DQUICK_AMD_TOOLS).  The product library contains none of them.
 """
@@ -21,7 +21,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libquick_amd.so")
-TOOLS_LIB = os.path.join(LIBDIR, "libquick_amd_tools.so")
+TOOLS_DIR = os.path.join(os.path.dirname(PKG), "tools", "bin")   # measurement builds live with the tools, not with the product
+TOOLS_LIB = os.path.join(TOOLS_DIR, "libquick_amd_tools.so")
 SOURCES = ["w4a16_gemm.hip", "w4a16_xk.hip", "w4a16_xw.hip", "w4a16_lean.hip", "w4a16_lean_a.hip", "w4a16_lean_b.hip", "w4a16_lean_c.hip", "repack.hip", "decode_ops.hip"]
 HEADERS = ["w4a16_common.hpp", "w4a16_args.hpp", "w4a16_wide.hpp", "w4a16_xk.hpp", "w4a16_xk_host.hpp", "w4a16_xw.hpp", "w4a16_xw_host.hpp", "w4a16_xw_loop.inc", "w4a16_lean.hpp", "w4a16_lean_host.hpp", "w4a16_lean_inst.hpp",
            os.path.join("..", "..", "include", "quick_amd.h")]
@@ -63,13 +64,13 @@ def _compile(src, obj, flags, verbose):
 
 
 def build(force=False, verbose=False, tools=False):
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(TOOLS_DIR if tools else LIBDIR, exist_ok=True)
     lib = TOOLS_LIB if tools else LIB
     stamp = lib + ".sha256"
     dig = _digest(tools)
     if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return lib
-    objdir = os.path.join(LIBDIR, "obj_tools" if tools else "obj")
+    objdir = os.path.join(TOOLS_DIR, "obj_tools") if tools else os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     flags = CFLAGS + (["-DQUICK_AMD_TOOLS"] if tools else [])
     hdr = [os.path.join(CSRC, h) for h in HEADERS]

@@ -1196,6 +1196,19 @@ __global__ __launch_bounds__(512) void w4a16_empty_kernel(unsigned* sink) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// workspace check: the counter region and the exchange zone must be all-zero between launches (include/quick_amd.h, "workspace").
+// One pass over them; the lowest dirty byte offset lands in *first (0xffffffff = clean).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void w4a16_workspace_scan_kernel(const u32x4* __restrict__ ws, unsigned n16, unsigned* __restrict__ first) {
+  unsigned lo = 0xffffffffu;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) {
+    const u32x4 v = __builtin_nontemporal_load(ws + i);
+    if ((v[0] | v[1] | v[2] | v[3]) != 0u) lo = min(lo, i * 16u);
+  }
+  if (lo != 0xffffffffu) atomicMin(first, lo);
+}
+
+// ------------------------------------------------------------------------------------------------
 // dense dequantisation (debug / parity aid): W[k, n] = fp16((w - z) * s), row-major [K, N]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void w4a16_dequant_kernel(const u32x4* __restrict__ QW, const half_t* __restrict__ S,
@@ -1218,6 +1231,7 @@ __global__ __launch_bounds__(64) void w4a16_dequant_kernel(const u32x4* __restri
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+extern "C" int quick_w4a16_workspace_check(const void* workspace, size_t workspace_bytes, void* hip_stream);
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -1471,7 +1485,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
                                    : cand[c].c + cand[c].a * n + stages * (cand[c].b_ceil * n + cand[c].b_frac * f) +
                                          (s > 1 ? cand[c].split0 + cand[c].split1 * s * (mb * 32.0 * pairs * 128 * 4 / 1e6) : 0.0) -
                                          (s == 2 && mb * pairs <= 8 ? 1.2 : 0.0);   // (two slices: the own partial stays in registers, measured after the fit)
-      // [r03 audit, profiles/r03_xk_audit.jsonl] tiles of <= 128 x 128 in SEVERAL rounds run 10-20 % behind this fit on the r03 boxes
+      // [r03 audit, profiles/archive/r03_xk_audit.jsonl] tiles of <= 128 x 128 in SEVERAL rounds run 10-20 % behind this fit on the r03 boxes
       // (measured / predicted, medians: 64 x 128 1.13-1.21, 64 x 256 1.14-1.21, 128 x 128 1.22 against 1.12 in one round; 128 x 256
       // 1.04-1.10 and 256 x 256 1.01-1.05 as fitted): 640 x 5120 x 13824 121 us on 540 tiles against 101 on 162 of 256 x 256
       static const double several_rounds[5] = {1.2, 1.2, 1.2, 1.0, 1.0};  // (replayed on the audit's rows, tools/audit_replay.py: mean gap 0.95 -> 0.37 %, worst 19 -> 7 %)
@@ -2254,6 +2268,15 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     const size_t need = workspace_need(p);
     if (!workspace || workspace_bytes < need)
       return fail(QUICK_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    // QUICK_AMD_CHECK_WORKSPACE=1 (a debugging aid: it synchronises the stream): every launch that meets its partners through the workspace
+    // first proves the guarded regions all-zero and answers QUICK_ERR_WORKSPACE otherwise -- a stale granule is indistinguishable from a
+    // partner's partial sum, see include/quick_amd.h
+    static const bool check_ws = [] {
+      const char* e = getenv("QUICK_AMD_CHECK_WORKSPACE");
+      return e && *e && atoi(e) != 0;
+    }();
+    if (check_ws)
+      if (int rcw = quick_w4a16_workspace_check(workspace, workspace_bytes, (void*)L.st)) return rcw;
     a.counters = (unsigned*)workspace;  // zero on entry (caller's contract), zero again when the launch completes
     a.slabs = (float*)((char*)workspace + ((p.kernel == QUICK_KERNEL_XK || p.kernel == QUICK_KERNEL_XW) ? counters_bytes(p) : slabs_offset(p)));  // (exchange-K / XW: the zone)
   }
@@ -2506,6 +2529,27 @@ int quick_amd_dispatch_floor(int iters, float* kernel_us, void* hip_stream) {
     kernel_us[i] = ms * 1000.f;
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int quick_w4a16_workspace_check(const void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!workspace || workspace_bytes == 0) return QUICK_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const size_t guarded = std::min(workspace_bytes, (size_t)kMaxSplitTiles * 4 + kXkZoneBytesHost) & ~(size_t)15;
+  unsigned* first = nullptr;
+  if (hipMalloc(&first, sizeof(unsigned)) != hipSuccess) return fail(QUICK_ERR_LAUNCH, "hipMalloc failed");
+  int rc = QUICK_OK;
+  unsigned host = 0xffffffffu;
+  if (hipMemsetAsync(first, 0xff, sizeof(unsigned), st) != hipSuccess) rc = fail(QUICK_ERR_LAUNCH, "memset failed");
+  if (rc == QUICK_OK) {
+    hipLaunchKernelGGL(w4a16_workspace_scan_kernel, dim3(1024), dim3(256), 0, st, (const u32x4*)workspace, (unsigned)(guarded / 16), first);
+    if (hipMemcpyAsync(&host, first, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      rc = fail(QUICK_ERR_LAUNCH, "workspace scan failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  (void)hipFree(first);
+  if (rc == QUICK_OK && host != 0xffffffffu)
+    rc = fail(QUICK_ERR_WORKSPACE, "workspace is not zero at byte %u (%s): an aborted launch, a buffer that was never zeroed, or two streams sharing it; zero it again before the next call",
+              host, (size_t)host < (size_t)kMaxSplitTiles * 4 ? "arrival counters / part state words" : "exchange zone");
   return rc;
 }
 

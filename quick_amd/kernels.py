@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 
-KERNEL_AUTO, KERNEL_SKINNY, KERNEL_TILED, KERNEL_WIDE, KERNEL_XK, KERNEL_XW = 0, 1, 2, 3, 4, 5
+KERNEL_AUTO, KERNEL_SKINNY, KERNEL_TILED, KERNEL_WIDE, KERNEL_XK, KERNEL_XW, KERNEL_LEAN = 0, 1, 2, 3, 4, 5, 6
 _OK, _INVALID, _WORKSPACE, _LAUNCH, _UNSUPPORTED = 0, 1, 2, 3, 4
 
 
@@ -132,8 +132,25 @@ def gemm_forward(in_feats, kernel, scaling_factors, zeros, bias=None, kernel_id=
             ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, M, K, N, G, kernel_id,
             grid_split_k, _stream())
     if rc != _OK:
+        if ws is not None:                                # whatever went wrong, the next launch finds the state it expects: all-zero
+            ws.zero_()
         _raise(rc)
     return out
+
+
+def workspace_check(device=None):
+    """Verify that this stream's workspace is all-zero where the library expects it (quick_w4a16_workspace_check: synchronises).
+    Raises RuntimeError naming the first dirty byte -- and zeroes the buffer again -- otherwise."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ws = _WORKSPACES.get((device.index, _stream()))
+    if ws is None:
+        return True
+    with torch.cuda.device(device):
+        rc = _lib.load().quick_w4a16_workspace_check(ws.data_ptr(), ws.numel(), _stream())
+    if rc != _OK:
+        ws.zero_()
+        _raise(rc)
+    return True
 
 
 def _tensor_version(t):

@@ -1420,3 +1420,52 @@ def test_lean_reference_pin_and_poisoned_output(qa, device, pin):
         assert float(np.abs(np.abs(y).sum(0) - g["col_abs_sum"]).max()) <= TOL * float(g["col_abs_sum"].max())
         assert torch.isnan(out[0]).all() and torch.isnan(out[M + 1]).all() and not torch.isnan(out[1:M + 1]).any()
     assert K_.plan_describe(1, 4096, 4096, 128).startswith("lean")
+
+
+def test_workspace_check_detects_a_dirty_exchange_zone(qa, device):
+    """The K slices of an exchange launch cannot tell a stale granule from a partner's partial sum (include/quick_amd.h,
+    quick_w4a16_workspace_check): the contract is "all-zero between launches".  The check proves it after real launches, finds a planted
+    granule, the Python layer zeroes the buffer again; with QUICK_AMD_CHECK_WORKSPACE=1 (own process: the switch is read once) a launch
+    into a dirty workspace answers QUICK_ERR_WORKSPACE instead of computing with it."""
+    import subprocess
+    import sys
+    from quick_amd import kernels as K_, packing
+    M, K, N, G = 512, 1024, 512, 128
+    assert "slices=2" in K_.plan_describe(M, K, N, G, 5 | (4 << 4) | (1 << 12) | (2 << 8))
+    kid = 5 | (4 << 4) | (1 << 12) | (2 << 8)                      # xw 128 x 128, two slices
+    gen = torch.Generator(device=device).manual_seed(5)
+    qw, sc, qz = packing.random_mi355x(K, N, G, device, generator=gen)
+    x = (torch.randn(M, K, device=device, generator=gen) * 0.5).half()
+    y0 = qa.gemm_forward(x, qw, sc, qz, kernel_id=kid)
+    assert K_.workspace_check(device)
+    ws = K_._WORKSPACES[(device.index, torch.cuda.current_stream().cuda_stream)]
+    ws[65536 + 4096 * 3 + 32:65536 + 4096 * 3 + 48] = 0x3c       # a granule nobody sent
+    with pytest.raises(RuntimeError, match="not zero at byte 77856"):
+        K_.workspace_check(device)
+    assert K_.workspace_check(device)                              # ... zeroed again by the Python layer
+    assert torch.equal(y0, qa.gemm_forward(x, qw, sc, qz, kernel_id=kid))
+    ws[1000:1004] = 7                                              # a part state word
+    with pytest.raises(RuntimeError, match="arrival counters"):
+        K_.workspace_check(device)
+    code = f"""
+import torch, sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import quick_amd
+from quick_amd import kernels as K_, packing
+dev = torch.device("cuda:0")
+qw, sc, qz = packing.random_mi355x({K}, {N}, {G}, dev)
+x = torch.randn({M}, {K}, device=dev).half()
+y0 = quick_amd.gemm_forward(x, qw, sc, qz, kernel_id={kid})
+ws = K_._WORKSPACES[(0, torch.cuda.current_stream().cuda_stream)]
+ws[65536 + 64:65536 + 80] = 0x3c
+try:
+    quick_amd.gemm_forward(x, qw, sc, qz, kernel_id={kid})
+    print("NO ERROR")
+except RuntimeError as e:
+    print("ERR", e)
+y1 = quick_amd.gemm_forward(x, qw, sc, qz, kernel_id={kid})
+print("EQUAL", bool(torch.equal(y0, y1)))
+"""
+    env = dict(os.environ, QUICK_AMD_CHECK_WORKSPACE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert "ERR" in r.stdout and "not zero at byte 65600 (exchange zone)" in r.stdout and "EQUAL True" in r.stdout, r.stdout + r.stderr

@@ -135,7 +135,8 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 4096, 128, 8) == 0
     # N = 1024 at M = 1: 64 channel tiles x 4 K slices, one 1 KiB fp32 slab each, behind 64 KiB of arrival counters and the
     # 16 MiB exchange zone (include/quick_amd.h, "workspace")
-    assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 1024, 128, 8) == 65536 + (16 << 20) + 64 * 4 * 256 * 4
+    assert _lib.load().quick_w4a16_workspace_bytes_ex(1, 4096, 1024, 128, 1, 0) == 65536 + (16 << 20) + 64 * 4 * 256 * 4   # (the r01 skinny kernel; AUTO: a lean launch, no workspace)
+    assert _lib.load().quick_w4a16_workspace_bytes(1, 4096, 1024, 128, 8) == 0
     # exchange-K launch with two slices per tile: counters + zone, no slabs
     assert _lib.load().quick_w4a16_workspace_bytes_ex(512, 4096, 4096, 128, 4, 0) == 65536 + (16 << 20)
 
@@ -188,9 +189,9 @@ def test_plan_describe_pins_the_shape_heuristics():
         return kernels.plan_describe(M, K, N, G, **kw)
 
     # decode shapes: one token -> deferred-zero table kernel, persistent over the channel blocks when there are many
-    assert plan(1, 4096, 4096).startswith("skinny ntw=1 waves=8 x=lds dequant=deferred-zero-table grid=256x1x1")
-    assert "grid=464x1x1" in plan(1, 4096, 22016)          # 1376 blocks in 3 rounds of <= 464
-    assert "dequant=exact" in plan(8, 4096, 4096)            # one block per workgroup: the table does not pay
+    assert plan(1, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=1 waves=8 x=lds dequant=deferred-zero-table grid=256x1x1")   # (r01-r04 skinny rules: family forced; AUTO runs the lean kernels at 1..4 tokens since r05, below)
+    assert "grid=464x1x1" in plan(1, 4096, 22016, kernel_id=kernels.KERNEL_SKINNY)          # 1376 blocks in 3 rounds of <= 464
+    assert "dequant=exact" in plan(8, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)            # one block per workgroup: the table does not pay
     assert plan(64, 4096, 4096).startswith("skinny ntw=4") and "deferred-zero-fragment" in plan(64, 4096, 4096)
     assert plan(65, 4096, 4096).startswith("xk tokens=64") and "slices=4" in plan(65, 4096, 4096)   # r03: 32 exchange-K tiles x 4 K slices = one round
     assert plan(32, 4096, 8192).startswith("skinny ntw=4")   # 256 workgroups of 64 channels x 16 tokens: one round, 32 stages each
@@ -248,14 +249,14 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "waves=8 ring=6" in plan(512, 4096, 4096, kernel_id=W | (2 << 4) | (1 << 8) | (1 << 15))   # eight-wave ring
     assert "ring=0" in plan(512, 4096, 4096, kernel_id=W | (2 << 4) | (1 << 8) | (1 << 12))           # double-buffered instead
     # r02 planner audit (profiles/r02_planner_audit*.jsonl): the rules it added
-    assert "waves=16" in plan(1, 11008, 4096) and "waves=8" in plan(1, 4096, 4096) and "waves=8" in plan(1, 4096, 22016)   # long K, one workgroup per CU
+    assert "waves=16" in plan(1, 11008, 4096, kernel_id=kernels.KERNEL_SKINNY) and "waves=8" in plan(1, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY) and "waves=8" in plan(1, 4096, 22016, kernel_id=kernels.KERNEL_SKINNY)   # long K, one workgroup per CU
     assert "waves=16" in plan(1, 11008, 4096, G=64) and "waves=8" in plan(1, 11008, 4096, G=32)                            # (not with four units per k-tile)
-    assert plan(16, 4096, 6144).startswith("skinny ntw=2") and "deferred-zero-fragment" in plan(16, 4096, 6144)    # 384 blocks: one round of 192
-    assert plan(6, 8192, 8192).startswith("skinny ntw=2") and plan(4, 28672, 8192).startswith("skinny ntw=4")
+    assert plan(16, 4096, 6144, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=2") and "deferred-zero-fragment" in plan(16, 4096, 6144, kernel_id=kernels.KERNEL_SKINNY)    # 384 blocks: one round of 192
+    assert plan(6, 8192, 8192, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=2") and plan(4, 28672, 8192).startswith("skinny ntw=4")
     assert "deferred-zero-table" in plan(12, 4096, 22016) and plan(16, 4096, 22016).startswith("skinny ntw=4")
     assert plan(16, 8192, 57344).startswith("skinny ntw=4")
     # r03 audit: from five tokens no LDS copy of x outside the table flavour; one-tile launches with K = 4096 run sixteen waves
-    assert plan(6, 4096, 4096).startswith("skinny ntw=1 waves=16 x=l2 dequant=exact") and "waves=8 x=lds" in plan(4, 4096, 4096)
+    assert plan(6, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=1 waves=16 x=l2 dequant=exact") and "waves=8 x=lds" in plan(4, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)
     assert plan(6, 4096, 12288).startswith("skinny ntw=4 waves=8 x=l2") and plan(10, 11008, 4096).startswith("skinny ntw=4 waves=8 x=l2")
     # third audit (17..64 tokens, layer shapes the rules were not tuned on): the four-tile skinny kernel by its own geometry
     assert plan(32, 4096, 6144).startswith("skinny ntw=4") and plan(32, 4096, 4096).startswith("skinny ntw=4")    # one round of workgroups, <= 64 stages each
@@ -266,8 +267,22 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(64, 11008, 4096, kernel_id=T).startswith("tiled tokens=32") and "slices=8" in plan(48, 11008, 4096)
     assert plan(64, 28672, 8192).startswith("xk tokens=64") and "slices=4" in plan(64, 28672, 8192)               # long K slices fill the chip
     assert "slices=4" in plan(48, 28672, 8192) and "slices=4" in plan(64, 8192, 8192) and "slices=4" in plan(64, 4096, 8192)
-    assert "deferred-zero-table" in plan(3, 13824, 5120) and "dequant=exact" in plan(3, 18944, 3584)              # M = 3: the table from 256 channel blocks
-    assert plan(8, 11008, 4096).startswith("skinny ntw=4") and plan(6, 11008, 4096).startswith("skinny ntw=1")    # x too large for LDS: share the L2 fragments (r03 audit: among four tiles)
+    assert "deferred-zero-table" in plan(3, 13824, 5120, kernel_id=kernels.KERNEL_SKINNY) and "dequant=exact" in plan(3, 18944, 3584, kernel_id=kernels.KERNEL_SKINNY)              # M = 3: the table from 256 channel blocks
+    assert plan(8, 11008, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4") and plan(6, 11008, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=1")    # x too large for LDS: share the L2 fragments (r03 audit: among four tiles)
+    # [r05] the lean small-M kernels: 1..4 tokens wherever a build exists (G % 128 == 0, k tiles between the waves and 8 / 12 per wave), up to 16
+    # tokens on layers of <= 512 channel blocks; two channel tiles per workgroup where that fills the rounds no worse
+    L = kernels.KERNEL_LEAN
+    assert plan(1, 4096, 4096).startswith("lean ntw=1 waves=8 tiles_per_wave<=4 grid=256x1") and "workspace=0" in plan(1, 4096, 4096)
+    assert plan(1, 4096, 12288).startswith("lean ntw=1 waves=8") and plan(1, 4096, 22016).startswith("lean ntw=2 waves=8 tiles_per_wave<=4 grid=688x1")
+    assert plan(1, 11008, 4096).startswith("lean ntw=1 waves=16 tiles_per_wave<=8") and plan(1, 8192, 8192).startswith("lean ntw=2 waves=16 tiles_per_wave<=4 grid=256x1")
+    assert plan(1, 8192, 10240).startswith("lean ntw=1 waves=8 tiles_per_wave<=8") and plan(4, 4096, 22016).startswith("lean ntw=2")
+    assert plan(16, 4096, 4096).startswith("lean") and plan(8, 4096, 8192).startswith("lean") and plan(17, 4096, 4096).startswith("skinny")
+    assert plan(8, 4096, 22016).startswith("skinny") and plan(5, 4096, 12288).startswith("skinny")          # each workgroup fetches its own x: the r01-r04 kernels on wide layers
+    assert plan(1, 28672, 8192).startswith("skinny") and plan(1, 512, 256).startswith("skinny")              # 224 / 4 k tiles: no build
+    assert plan(1, 4096, 4096, G=64).startswith("skinny") and plan(2, 4096, 4096, G=256).startswith("lean")
+    assert "tiles_per_wave<=0" in plan(1, 28672, 8192, kernel_id=L) and "tiles_per_wave<=0" in plan(1, 4096, 4096, G=64, kernel_id=L)   # forced without a build: UNSUPPORTED at launch
+    assert plan(1, 4096, 4096, kernel_id=L | (2 << 4) | (4 << 8)).startswith("lean ntw=2 waves=16 tiles_per_wave<=4 grid=128x1")
+    assert kernels.can_fuse_rmsnorm(1, 4096, 12288, 128) and kernels.can_fuse_rmsnorm(16, 4096, 4096, 128)
     # forcing a family / a split through the kernel id and grid_split_k
     assert plan(512, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny")
     assert "ksplit=4" in plan(64, 4096, 4096, kernel_id=kernels.KERNEL_TILED, grid_split_k=4)

@@ -7,7 +7,7 @@ names=$1; rounds=${2:-2}
 DEFAULT_SHAPES=$'1 4096 22016\n1 4096 12288\n1 11008 4096\n1 4096 4096\n8 4096 22016\n8 4096 4096\n16 4096 12288'
 for r in $(seq $rounds); do
 for n in $names; do
-  export QUICK_AMD_LIB_OVERRIDE=$PWD/quick_amd/lib/ab_$n.so
+  export QUICK_AMD_LIB_OVERRIDE=$PWD/tools/bin/ab_$n.so
   echo "== $n (round $r)"
   while read -r s; do
     [ -z "$s" ] && continue

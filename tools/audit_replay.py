@@ -1,7 +1,7 @@
 """Replay a planner audit on the CPU: for every shape of a `tools/wide_probe.py --jsonl` audit file, ask the library
 what it would launch NOW (quick_w4a16_plan_describe is host-only) and look that launch up among the variants the
 audit measured on the GPU.  Prints the mean / worst gap to the best measured variant and the shapes whose plan was
-not among the measured ones.  Usage: python tools/audit_replay.py profiles/r03_xk_audit.jsonl [--top 15]"""
+not among the measured ones.  Usage: python tools/audit_replay.py profiles/archive/r03_xk_audit.jsonl [--top 15]"""
 import argparse
 import collections
 import json

@@ -12,6 +12,7 @@ G = 128
 LEAN = 6
 args = sys.argv[1:]
 check = "--no-check" not in args
+planner_only = "--planner-only" in args
 args = [a for a in args if not a.startswith("--")]
 specs = args or ["1x4096x4096", "2x4096x4096", "4x4096x4096", "8x4096x4096", "16x4096x4096", "1x4096x12288", "1x4096x22016", "1x11008x4096"]
 
@@ -42,9 +43,10 @@ for spec in specs:
     y = torch.empty(M, N, dtype=torch.float16, device=dev)
     ws = torch.zeros(32 << 20, dtype=torch.uint8, device=dev)
     algo = K * N / 2 + (K // G) * N * 2.5 + 2 * M * K + 2 * M * N
+    timed(M, K, N, 0, sets, x, y, ws)   # (clocks, caches)
     base = timed(M, K, N, 0, sets, x, y, ws)
     print(f"{spec}: planner [{kernels.plan_describe(M, K, N, G)}] span {base[0]:.2f} us ({algo / base[0] / 8e6 * 100:.1f}% of 8 TB/s), dispatch {base[1]:.2f}")
-    for ntw, waves in ((1, 8), (1, 16), (2, 8), (2, 16)):
+    for ntw, waves in (() if planner_only else ((1, 8), (1, 16), (2, 8), (2, 16))):
         kid = LEAN | (ntw << 4) | ((waves // 4) << 8)
         try:
             plan = kernels.plan_describe(M, K, N, G, kid)

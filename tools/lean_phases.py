@@ -1,5 +1,5 @@
 """Diagnostic: anatomy of a lean small-M launch (needs the QUICK_AMD_TOOLS library: `python -m quick_amd.build --tools`,
-QUICK_AMD_LIB_OVERRIDE=quick_amd/lib/libquick_amd_tools.so).  Per-wave s_memrealtime stamps (10 ns ticks), HBM-cold weights.
+QUICK_AMD_LIB_OVERRIDE=tools/bin/libquick_amd_tools.so).  Per-wave s_memrealtime stamps (10 ns ticks), HBM-cold weights.
     python tools/lean_phases.py [--waves 4|8|16] [MxKxN ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """Diagnostic: where an exchange-K launch spends its time (needs the QUICK_AMD_TOOLS library: `python -m quick_amd.build --tools`,
-QUICK_AMD_LIB_OVERRIDE=quick_amd/lib/libquick_amd_tools.so).  Per-wave s_memrealtime stamps at the phase boundaries.
+QUICK_AMD_LIB_OVERRIDE=tools/bin/libquick_amd_tools.so).  Per-wave s_memrealtime stamps at the phase boundaries.
     python tools/xk_phases.py [--kernel ID] [MxKxN ...]        ID: QUICK_KERNEL_XK | mb << 4 | slices << 8 ..., default 128-token tiles"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
