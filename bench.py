@@ -255,13 +255,17 @@ def main():
         spare = [j % n_sets for j in range(warmup + steps, warmup + steps + n_sets) if (j % n_sets) not in {(warmup + i) % n_sets for i in range(steps)}]
         # [r05] 12 launches were 0.05-0.26 ms: shorter than the clock ramp (the driver's 20-step run read the M = 512 step 1.4 us above the
         # kernel's own duration measured later in the same process).  150 launches round-robin over the spare sets = 0.6-3.5 ms.
+        # [r05] ... and NO host synchronisation between them and the timed steps: barrier + synchronize come first, then the untimed launches,
+        # the first event, the K graph-replayed steps and the second event go into the stream back to back.  With a synchronize in front of
+        # the first event the GPU sat idle while the host submitted the graph: the 20-step protocol read M = 512 at 24.3 us per step against
+        # 20.5 with 2000 steps in the same process (M = 1: 4.5 against 4.0) -- the idle gap and the clock ramp behind it, not the kernels.
         n_warm = 150 if spare else 0
-        for r in range(n_warm):
-            launch(spare[r % len(spare)])
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        for r in range(n_warm):
+            launch(spare[r % len(spare)])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         if graph is not None:
@@ -332,6 +336,8 @@ def main():
         return {"M": M, "ms_per_step": ms_step, "tops": flops / (ms_step * 1e-3) / 1e12, "tops_kernel_only": flops / (k_us * 1e-6) / 1e12,
                 "launch": mode, "weight_sets_in_timed_region": min(steps, n_sets), "cache_flushed_before_timed_region": True,
                 "clock_warmup_launches_on_other_weight_sets": n_warm,
+                "timed_region": "two hipEvents on the stream around exactly K graph-replayed steps; barrier + synchronize before the untimed "
+                                "launches that precede the first event and after the second event",
                 "roofline": roof}, y
 
     fl = (ctypes.c_float * 60)()

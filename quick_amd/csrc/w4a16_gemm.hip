@@ -1559,7 +1559,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // (where the 256 x 256 tile is the pick they compete only if it runs with a K split: 1024 x 28672 x 8192, 128 tiles x 2 slices, 419 us
     // against 379 on 256 tiles of 128 x 256 -- profiles/r04_xw256.txt)
     if (best > 0 && allow_xk && (wide_mb != 8 || (N % 256 == 0 && wide_split((long)((M + 255) / 256) * (N / 256)) > 1)) && (G / 128 & (G / 128 - 1)) == 0 &&
-        (M >= 160 || (M >= 96 && N >= 10240)) &&
+        M >= 96 &&   // [r05 sweep, profiles/r05_mid_sweep.txt: from 96 tokens on the narrow layers as well -- 96 / 128 x 4096 x 4096 12.4 / 12.6 -> 11.4 / 11.6 us, x 5120 x 5120 14.8 / 16.9 -> 13.6 / 13.9, x 8192 x 8192 27.9 / 29.1 -> 25.0 / 26.0, x 13824 x 5120 29.5 -> 25.4; at 33..64 tokens no four-wave tile beats the r03 picks by more than the session noise]
+
         (size_t)M * (size_t)K * 2 < ((size_t)1 << 32) && (size_t)M * (size_t)N * 2 < ((size_t)1 << 32)) {
       struct XwCand { int mb, pairs; double c, a, b_ceil, b_frac, s0, s1, d; };
       static const XwCand xwc[3] = {{4, 2, -2.8632, 5.8843, 0.8799, 0.6018, -0.6402, 1.2461, 5.8244},

@@ -22,7 +22,8 @@ static bool xw_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t 
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipExtLaunchKernelGGL(kfn, dim3(workgroups), dim3(256), lds, st, start, stop, 0, a);
+  XwRest rest{a.bias, a.residual, a.Y, a.slabs, a.counters, a.dbg, a.span, a.silu_mul, a.G};
+  hipExtLaunchKernelGGL(kfn, dim3(workgroups), dim3(256), lds, st, start, stop, 0, a.X, a.QW, a.S, a.M, a.K, a.N, a.tpg, a.ksplit, a.kt_per_split, a.xcd_gm, rest);
   return true;
 }
 
