@@ -1363,11 +1363,12 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       return !(e && *e && atoi(e) == 0);
     }();
     const bool envelope = G % 128 == 0 && (size_t)K * N / 2 < ((size_t)1 << 31) && (size_t)M * K * 2 < ((size_t)1 << 31);
-    if (forced || (family == QUICK_KERNEL_AUTO && lean_on && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M <= 16 &&
-                   (M <= 4 || N / 16 <= 512))) {
+    if (forced || (family == QUICK_KERNEL_AUTO && lean_on && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M <= 16)) {
+      const bool one_block_ok = forced || M <= 4 || N / 16 <= 512;
       int bw = 0, bt = 0, bn = 0;
       double bcost = 0;
       for (const auto& b : builds) {
+        if (!one_block_ok) break;
         const int waves = b[0], tmax = b[1], ntw = b[2];
         if (forced && ((waves_req && waves != waves_req) || (mt_req && ntw != mt_req))) continue;
         if (KT < waves || (KT + waves - 1) / waves > tmax || (N / 16) % ntw != 0) continue;
@@ -1395,7 +1396,30 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         p.lean_tmax = envelope ? bt : 0;
         p.ntiles = (N / 16) * mblocks;
         p.grid_x = N / 16 / p.mt;
+        // persistent launches (fewer workgroups than channel blocks; builds of <= 4 tiles per wave, G = 128, one token block): forced by
+        // kernel bits 22-24 = workgroups per CU
+        const int slots_req = (kernel >> 22) & 7;
+        if (forced && slots_req && bt && bt <= 4 && p.waves == 8 && G == 128 && mblocks == 1 && lean_lds_need(M, K, p.waves, p.mt, true, true) <= kLdsPerCu)
+          p.grid_x = std::min(p.grid_x, cu_count() * slots_req);
         return p;
+      }
+      // 8..16 tokens on a wide layer: every one-block workgroup would fetch its own copy of x (more L2 -> LDS bytes than weights) -- one
+      // persistent workgroup per CU instead, x staged once, the next block's weights requested under this block's tiles [profiles/r05_lean_persist.txt,
+      // in-kernel spans against the r01-r04 picks: 16 x 4096 x 22016 18.0 -> 14.4 us, 16 x 4096 x 12288 10.2 -> 9.0, 8 x 4096 x 22016 13.7 -> 12.4]
+      if (!forced && family == QUICK_KERNEL_AUTO && lean_on && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && G == 128 && M >= 8 &&
+          M <= 16 && N / 16 > 512 && KT >= 8 && KT <= 32) {
+        const int ntw = ((N / 16) % 2 == 0 && M <= 12 && N / 16 >= 1024 && lean_lds_need(M, K, 8, 2, true, true) <= kLdsPerCu) ? 2 : 1;
+        if (lean_lds_need(M, K, 8, ntw, true, true) <= kLdsPerCu) {
+          p.kernel = QUICK_KERNEL_LEAN;
+          p.ksplit = 1;
+          p.kt_per_split = KT;
+          p.mt = ntw;
+          p.waves = 8;
+          p.lean_tmax = 4;
+          p.ntiles = (N / 16) * mblocks;
+          p.grid_x = std::min(N / 16 / ntw, cu_count());
+          return p;
+        }
       }
     }
   }

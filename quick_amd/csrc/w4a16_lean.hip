@@ -14,7 +14,7 @@ namespace quick_amd {
 template <int WAVES, int TMAX, int NTW, int ABL>
 bool lean_build(const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, hipEvent_t start, hipEvent_t stop);
 
-unsigned lean_lds_need(int M, int K, int waves, int ntw, bool ln) { return lean_lds_bytes(std::min(M, 16), K, waves, ntw, ln); }
+unsigned lean_lds_need(int M, int K, int waves, int ntw, bool ln, bool persist) { return lean_lds_bytes(std::min(M, 16), K, waves, ntw, ln, persist); }
 
 template <int ABL>
 static bool lean_go_w(int waves, int tmax, int ntw, const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, hipEvent_t start, hipEvent_t stop) {

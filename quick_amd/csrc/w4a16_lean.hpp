@@ -28,9 +28,11 @@ namespace quick_amd {
 constexpr int kLeanStamps = 16;  // phase stamps per wave (tools builds): u64 s_memrealtime ticks
 
 // LDS of one lean workgroup (host and device agree through these functions)
-__host__ __device__ constexpr unsigned lean_red_bytes(int waves, int ntw) { return (unsigned)(waves * ntw) * 1024u + (unsigned)waves * 64u; }
-__host__ __device__ inline unsigned lean_lds_bytes(int rows, int K, int waves, int ntw, bool ln) {
-  return lean_red_bytes(waves, ntw) + (ln ? (unsigned)K * 2u : 0u) + (unsigned)rows * ((unsigned)K * 2u + 16u);
+__host__ __device__ constexpr unsigned lean_red_bytes(int waves, int ntw, bool persist = false) {
+  return (persist ? 2u : 1u) * (unsigned)(waves * ntw) * 1024u + (unsigned)waves * 64u;
+}
+__host__ __device__ inline unsigned lean_lds_bytes(int rows, int K, int waves, int ntw, bool ln, bool persist = false) {
+  return lean_red_bytes(waves, ntw, persist) + (ln ? (unsigned)K * 2u : 0u) + (unsigned)rows * ((unsigned)K * 2u + 16u);
 }
 
 // Arguments: the ones every request of the head depends on come FIRST and as scalars -- the translation unit is built with
@@ -60,12 +62,15 @@ __device__ __forceinline__ void lean_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned
 // unit sums between two tiles and halves the workgroup count: on wide layers all of them are resident at once and the whole weight
 // matrix is in flight after the first microsecond.  Straight-line code: hipcc's s_waitcnt placement is
 // exact there (one counted wait per tile), while any loop carrying requests around its back edge made it drain the queue at the loop head.
-template <int WAVES, int TMAX, int NTW, int GM, int ABL, bool LN, int MR>
+template <int WAVES, int TMAX, int NTW, int GM, int ABL, bool LN, int MR, int NSETS = 1>
 __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __restrict__ aX, const u32x4* __restrict__ aQW, const half_t* __restrict__ aS,
                                                                 const half_t* __restrict__ a_lnw, int aK, int aN, int aM, unsigned groups, int gx, unsigned tpg,
                                                                 const LeanRest rest) {
   constexpr bool SPAN = ABL == 32, STAMP = ABL == 64;
+  constexpr bool PERSIST = NSETS > 1;   // a workgroup walks the channel blocks nb, nb + gx, ...: x, unit sums and sum of squares made once
+  static_assert(!(PERSIST && STAMP), "phase stamps: the one-block launches only");
   constexpr int NSZ = (TMAX + 3) / 4;
+  constexpr int LSET = NTW * (TMAX + NSZ);   // requests per channel block and wave
   unsigned long long t_entry = 0;
   if constexpr (SPAN) t_entry = __builtin_amdgcn_s_memrealtime();  // (stored once the arguments are here: the span starts at the wave's first instruction)
   unsigned long long ts[kLeanStamps];
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
   if constexpr (STAMP) ts[11] = __builtin_amdgcn_s_memrealtime();
   // LDS: [red WAVES x NTW x 1 KiB][ssq WAVES x 16 f32][ln weight K x 2 B][x rows x (2 K + 16) B]
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned ssq_off = WAVES * NTW * 1024u, lnw_off = lean_red_bytes(WAVES, NTW);
+  const unsigned ssq_off = (PERSIST ? 2u : 1u) * WAVES * NTW * 1024u, lnw_off = lean_red_bytes(WAVES, NTW, PERSIST);
   const unsigned x_off = lnw_off + (ln ? (unsigned)aK * 2u : 0u);
   const unsigned pitch = (unsigned)aK * 2u + 16u;
   const int nseg = (T + 3) >> 2;
@@ -123,25 +128,33 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
   const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)aS, 0, groups * (unsigned)aN * 4u, 0x00020000);
   uint32_t szr[NTW][NSZ];
   u32x4 wq[NTW][TMAX];
-#pragma unroll
-  for (int c = 0; c < NTW; ++c)
-#pragma unroll
-    for (int i = 0; i < NSZ; ++i) {
-      const unsigned kt = (unsigned)(kb + 4 * i + q);
-      const unsigned g = GM == 0 ? kt : kt / tpg;
-      szr[c][i] = __builtin_amdgcn_raw_buffer_load_b32(sr, g * 64u + 4u * (unsigned)n16 + ((int)kt < ke ? 0u : 0x80000000u), (unsigned)(nb * NTW + c) * groups * 64u, 0);
-    }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int j = 0; j < TMAX; ++j)
+  // PERSIST: every pass of the block loop requests its block's tiles and consumes them before the next pass -- nothing is in flight around the
+  // loop's back edge, which is what hipcc's s_waitcnt placement needs (requests it cannot see, kept in flight across the back edge, were tried:
+  // it copies the destination registers at the loop head, before the data has landed).  What a persistent launch saves is the x traffic: at
+  // 8..16 tokens a one-block workgroup fetches more bytes of x than of weights.
+  const int nblocks = (aN >> 4) / NTW;
+  const auto request = [&](int blk) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < NTW; ++c)
-      wq[c][j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)lane * 16u + (j < T ? 0u : 0x80000000u), ((unsigned)(nb * NTW + c) * (unsigned)KT + (unsigned)(kb + j)) * 1024u, 0);
-  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NSZ; ++i) {
+        const unsigned kt = (unsigned)(kb + 4 * i + q);
+        const unsigned g = GM == 0 ? kt : kt / tpg;
+        szr[c][i] = __builtin_amdgcn_raw_buffer_load_b32(sr, g * 64u + 4u * (unsigned)n16 + ((int)kt < ke ? 0u : 0x80000000u), (unsigned)(blk * NTW + c) * groups * 64u, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < TMAX; ++j)
+#pragma unroll
+      for (int c = 0; c < NTW; ++c)
+        wq[c][j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)lane * 16u + (j < T ? 0u : 0x80000000u), ((unsigned)(blk * NTW + c) * (unsigned)KT + (unsigned)(kb + j)) * 1024u, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  request(nb);
   if constexpr (STAMP) ts[1] = __builtin_amdgcn_s_memrealtime();
 
   // ---- 3. x has landed (it is older than every other request) ----
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NTW * (TMAX + NSZ)) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LSET) : "memory");
   if constexpr (STAMP) ts[2] = __builtin_amdgcn_s_memrealtime();
   // the unit sums from the matrix core: B operand with ones in the even columns and b_k (1024 / 64 in biased8's order) in the odd ones,
   // so lane (n16, q) ends up with A (even n16) or C (odd n16) of its tokens 4q .. 4q+3
@@ -228,114 +241,128 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
       }
     }
   }
-  // this lane's (scale, zero) words, one per tile, out of the four-tile requests
-  uint32_t szj[NTW][TMAX];
-#pragma unroll
-  for (int c = 0; c < NTW; ++c)
-#pragma unroll
-    for (int j = 0; j < TMAX; ++j) szj[c][j] = (uint32_t)__builtin_amdgcn_ds_bpermute(((j & 3) * 16 + n16) * 4, (int)szr[c][j >> 2]);
   if constexpr (STAMP) ts[3] = __builtin_amdgcn_s_memrealtime();
 
-  // ---- 4. the tiles, in the order they land ----
+  // ---- 4. a channel block's tiles, in the order they land; 5. the waves' partials meet in LDS, NTW waves finish one channel tile each ----
   const bool odd = (lane & 1) != 0;
   (void)odd;
-  floatx4 acc[NTW];
+  const auto compute_and_finish = [&](uint32_t (&sz)[NTW][NSZ], u32x4 (&wv)[NTW][TMAX], int blk, int it) __attribute__((always_inline)) {
+    // this lane's (scale, zero) words, one per tile, out of the four-tile requests
+    uint32_t szj[NTW][TMAX];
 #pragma unroll
-  for (int c = 0; c < NTW; ++c) acc[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NTW; ++c)
 #pragma unroll
-  for (int j = 0; j < TMAX; ++j) {
-    if (j < T) {  // wave-uniform
-      const unsigned ko = (unsigned)(kb + j) * 256u;
-      half8_t xf[4];
+      for (int j = 0; j < TMAX; ++j) szj[c][j] = (uint32_t)__builtin_amdgcn_ds_bpermute(((j & 3) * 16 + n16) * 4, (int)sz[c][j >> 2]);
+    floatx4 acc[NTW];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) xf[t] = *(const half8_t*)(xl + ko + 64 * t);
-      if constexpr (LN && MR == 16) {
+    for (int c = 0; c < NTW; ++c) acc[c] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xf[t] = xf[t] * *(const half8_t*)(gl + ko + 64 * t);
+    for (int j = 0; j < TMAX; ++j) {
+      if (j < T) {  // wave-uniform
+        const unsigned ko = (unsigned)(kb + j) * 256u;
+        half8_t xf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xf[t] = *(const half8_t*)(xl + ko + 64 * t);
+        if constexpr (LN && MR == 16) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) xf[t] = xf[t] * *(const half8_t*)(gl + ko + 64 * t);
+        }
+        floatx4 xa, nc;
+        if constexpr (MR == 16) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float mine = sm[j][r];
+            const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0xB1, 0xf, 0xf, false));
+            xa[r] = odd ? other : mine;
+            nc[r] = -(odd ? mine : other);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {  // (lanes q = 0 hold tokens 0..3; the other rows are never stored)
+            xa[r] = sA[j][r % SMR];
+            nc[r] = -sC[j][r % SMR];
+          }
+        }
+        if constexpr (STAMP) {
+          if (j == 0) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NTW * TMAX - 1) : "memory");
+            ts[4] = __builtin_amdgcn_s_memrealtime();
+          }
+          if (j == T - 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ts[5] = __builtin_amdgcn_s_memrealtime();
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NTW; ++c) {
+          const u32x4 w = wv[c][j];
+          floatx4 g = nc;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) g = mfma16(xf[t], biased8(w[t]), g);
+          const GroupRaw raw{szj[c][j]};
+          const float s = group_scale_f32(raw), z = group_zero_f32(raw);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[c][r] = __builtin_fmaf(s, __builtin_fmaf(-z, xa[r], g[r]), acc[c][r]);
+        }
       }
-      floatx4 xa, nc;
-      if constexpr (MR == 16) {
+    }
+    if constexpr (STAMP) ts[6] = __builtin_amdgcn_s_memrealtime();
+
+    // PERSIST: two reduction buffers alternate (a wave that runs ahead writes the other one; one barrier per block is enough), and the
+    // finishing waves rotate, so that nobody is late at every barrier
+    floatx4* red = (floatx4*)smem + (PERSIST ? (it & 1) * (WAVES * NTW * 64) : 0);
+#pragma unroll
+    for (int c = 0; c < NTW; ++c) red[(wave * NTW + c) * 64 + lane] = acc[c];
+    if constexpr (STAMP) ts[7] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    if constexpr (STAMP) ts[8] = __builtin_amdgcn_s_memrealtime();
+    const int first = PERSIST ? (it % (WAVES / NTW)) * NTW : 0;
+    if (wave >= first && wave < first + NTW) {
+      const int ct = wave - first;
+      floatx4 sum = red[ct * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) sum += red[(w * NTW + ct) * 64 + lane];
+      // lane (n16, q) holds tokens 4q .. 4q+3 of channel n16
+      if constexpr (LN) {
+        const float* sqp = (const float*)(smem + ssq_off);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float mine = sm[j][r];
-          const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine), 0xB1, 0xf, 0xf, false));
-          xa[r] = odd ? other : mine;
-          nc[r] = -(odd ? mine : other);
+          float ss = 0.f;
+#pragma unroll
+          for (int w = 0; w < WAVES; ++w) ss += sqp[w * 16 + 4 * q + r];
+          sum[r] *= rsqrtf(ss / (float)aK + rest.ln_eps);
+        }
+      }
+      const int nt = blk * NTW + ct, n = nt * 16 + n16;
+      if (rest.silu_mul) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float up = __shfl_xor(sum[r], 8);  // channels 0..7 gate, 8..15 up
+          const int m = row0 + 4 * q + r;
+          if (4 * q + r < rows && n16 < 8) rest.Y[(size_t)m * (aN >> 1) + nt * 8 + n16] = silu_mul_f16((half_t)sum[r], (half_t)up);
         }
       } else {
+        const float bv = rest.bias ? (float)rest.bias[n] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {  // (lanes q = 0 hold tokens 0..3; the other rows are never stored)
-          xa[r] = sA[j][r % SMR];
-          nc[r] = -sC[j][r % SMR];
-        }
-      }
-      if constexpr (STAMP) {
-        if (j == 0) {
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NTW * TMAX - 1) : "memory");
-          ts[4] = __builtin_amdgcn_s_memrealtime();
-        }
-        if (j == T - 1) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          ts[5] = __builtin_amdgcn_s_memrealtime();
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < NTW; ++c) {
-        const u32x4 w = wq[c][j];
-        floatx4 g = nc;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) g = mfma16(xf[t], biased8(w[t]), g);
-        const GroupRaw raw{szj[c][j]};
-        const float s = group_scale_f32(raw), z = group_zero_f32(raw);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[c][r] = __builtin_fmaf(s, __builtin_fmaf(-z, xa[r], g[r]), acc[c][r]);
-      }
-    }
-  }
-  if constexpr (STAMP) ts[6] = __builtin_amdgcn_s_memrealtime();
-
-  // ---- 5. the waves' partials meet in LDS; wave c finishes channel tile c ----
-  floatx4* red = (floatx4*)smem;
-#pragma unroll
-  for (int c = 0; c < NTW; ++c) red[(wave * NTW + c) * 64 + lane] = acc[c];
-  if constexpr (STAMP) ts[7] = __builtin_amdgcn_s_memrealtime();
-  __syncthreads();
-  if constexpr (STAMP) ts[8] = __builtin_amdgcn_s_memrealtime();
-  if (wave < NTW) {
-    floatx4 sum = red[wave * 64 + lane];
-#pragma unroll
-    for (int w = 1; w < WAVES; ++w) sum += red[(w * NTW + wave) * 64 + lane];
-    // lane (n16, q) holds tokens 4q .. 4q+3 of channel n16
-    if constexpr (LN) {
-      const float* sqp = (const float*)(smem + ssq_off);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float ss = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) ss += sqp[w * 16 + 4 * q + r];
-        sum[r] *= rsqrtf(ss / (float)aK + rest.ln_eps);
-      }
-    }
-    const int nt = nb * NTW + wave, n = nt * 16 + n16;
-    if (rest.silu_mul) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float up = __shfl_xor(sum[r], 8);  // channels 0..7 gate, 8..15 up
-        const int m = row0 + 4 * q + r;
-        if (4 * q + r < rows && n16 < 8) rest.Y[(size_t)m * (aN >> 1) + nt * 8 + n16] = silu_mul_f16((half_t)sum[r], (half_t)up);
-      }
-    } else {
-      const float bv = rest.bias ? (float)rest.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = row0 + 4 * q + r;
-        if (4 * q + r < rows) {
-          float v = sum[r] + bv;
-          if (rest.residual) v += (float)rest.residual[(size_t)m * aN + n];
-          rest.Y[(size_t)m * aN + n] = (half_t)v;
+        for (int r = 0; r < 4; ++r) {
+          const int m = row0 + 4 * q + r;
+          if (4 * q + r < rows) {
+            float v = sum[r] + bv;
+            if (rest.residual) v += (float)rest.residual[(size_t)m * aN + n];
+            rest.Y[(size_t)m * aN + n] = (half_t)v;
+          }
         }
       }
     }
+  };
+  if constexpr (PERSIST) {
+    int it = 0;
+    for (int blk = nb; blk < nblocks; blk += gx) {
+      if (it > 0) request(blk);
+      compute_and_finish(szr, wq, blk, it++);
+    }
+  } else {
+    compute_and_finish(szr, wq, nb, 0);
   }
   if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

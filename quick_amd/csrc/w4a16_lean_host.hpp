@@ -11,6 +11,6 @@ namespace quick_amd {
 // channels, grid_y token blocks of 16.  false: no build for this configuration / group size.
 bool lean_launch(int waves, int tmax, int ntw, int abl, const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, hipEvent_t start, hipEvent_t stop);
 // dynamic LDS of one workgroup
-unsigned lean_lds_need(int M, int K, int waves, int ntw, bool ln);
+unsigned lean_lds_need(int M, int K, int waves, int ntw, bool ln, bool persist = false);
 
 }  // namespace quick_amd

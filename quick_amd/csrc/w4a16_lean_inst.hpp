@@ -11,15 +11,15 @@
 
 namespace quick_amd {
 
-template <int WAVES, int TMAX, int NTW, int GM, int ABL, bool LN, int MR>
+template <int WAVES, int TMAX, int NTW, int GM, int ABL, bool LN, int MR, int NSETS = 1>
 static bool lean_go(const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
-  auto kfn = w4a16_lean_kernel<WAVES, TMAX, NTW, GM, ABL, LN, MR>;
+  auto kfn = w4a16_lean_kernel<WAVES, TMAX, NTW, GM, ABL, LN, MR, NSETS>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const unsigned lds = lean_lds_need(a.M, a.K, WAVES, NTW, a.ln_w != nullptr);
+  const unsigned lds = lean_lds_need(a.M, a.K, WAVES, NTW, a.ln_w != nullptr, NSETS > 1);
   LeanRest rest{};
   rest.Y = a.Y; rest.bias = a.bias; rest.residual = a.residual; rest.silu_mul = a.silu_mul; rest.ln_eps = a.ln_eps; rest.span = a.span; rest.dbg = a.dbg;
   hipExtLaunchKernelGGL(kfn, dim3(grid_x, grid_y), dim3(WAVES * 64), lds, st, start, stop, 0, a.X, a.QW, a.S, a.ln_w, a.K, a.N, a.M, (unsigned)(a.K / a.G), grid_x,
@@ -30,6 +30,20 @@ static bool lean_go(const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, h
 // token-count flavour: 1 token / up to 4 tokens with the unit sums as scalars (while TMAX * 4 * 2 of them fit the SGPRs), else the matrix-core sums
 template <int WAVES, int TMAX, int NTW, int GM, int ABL, bool LN>
 static bool lean_go_m(const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
+  // fewer workgroups than channel blocks: persistent (two register sets, the next block's requests in flight under this block's tiles);
+  // builds with up to four tiles per wave, G = 128, no phase stamps
+  if (grid_x < (a.N >> 4) / NTW) {
+    // eight waves (sixteen would need more registers than a 1024-thread workgroup may have), up to four tiles per wave, G = 128, no stamps;
+    // two register sets (four were measured slower, 16 x 4096 x 22016 14.4 -> 14.8 us: with one workgroup per CU the block time is the waves'
+    // own dependency chains, not the depth of the requests in flight)
+    if constexpr (WAVES == 8 && TMAX <= 4 && GM == 0 && ABL != 64) {
+      constexpr int NS = 2;
+      if (a.M == 1) return lean_go<WAVES, TMAX, NTW, GM, ABL, LN, 1, NS>(a, grid_x, grid_y, st, start, stop);
+      if (a.M <= 4) return lean_go<WAVES, TMAX, NTW, GM, ABL, LN, 4, NS>(a, grid_x, grid_y, st, start, stop);
+      return lean_go<WAVES, TMAX, NTW, GM, ABL, LN, 16, NS>(a, grid_x, grid_y, st, start, stop);
+    }
+    return false;
+  }
   if (a.M == 1) return lean_go<WAVES, TMAX, NTW, GM, ABL, LN, 1>(a, grid_x, grid_y, st, start, stop);
   if constexpr (TMAX <= 8) {
     if (a.M <= 4) return lean_go<WAVES, TMAX, NTW, GM, ABL, LN, 4>(a, grid_x, grid_y, st, start, stop);

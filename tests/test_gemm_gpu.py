@@ -1469,3 +1469,31 @@ print("EQUAL", bool(torch.equal(y0, y1)))
     env = dict(os.environ, QUICK_AMD_CHECK_WORKSPACE="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert "ERR" in r.stdout and "not zero at byte 65600 (exchange zone)" in r.stdout and "EQUAL True" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("ntw,waves,slots", [(1, 8, 1), (2, 8, 1), (1, 8, 2)])
+@pytest.mark.parametrize("M,K,N,G", [(1, 1024, 8320, 128), (4, 2048, 8448, 128), (16, 1024, 4224, 128), (9, 4096, 12288, 128), (3, 4096, 22016, 128),
+                                     (2, 8192, 8448, 128)])
+def test_lean_persistent_launches_equal_the_one_block_launches(qa, device, M, K, N, G, ntw, waves, slots):
+    """Persistent lean launches (a workgroup walks several channel blocks; the next block's requests, invisible to hipcc's wait counting,
+    are in flight under this block's tiles): bit-identical to the one-block-per-workgroup launch of the same build -- same arithmetic,
+    block by block -- for the plain GEMM, bias + residual, SiLU * mul and the RMSNorm prologue; and the one-block launch against the oracle."""
+    from quick_amd import kernels as K_
+    one, per = lean(ntw, waves), lean(ntw, waves) | (slots << 22)
+    p1, pp = K_.plan_describe(M, K, N, G, one), K_.plan_describe(M, K, N, G, per)
+    if "tiles_per_wave<=0" in p1 or p1.split("grid=")[1].split()[0] == pp.split("grid=")[1].split()[0]:
+        pytest.skip("no build, or nothing to walk (as many workgroups as blocks)")
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + K + N + waves)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device)
+    y1 = qa.gemm_forward(xd, *packed, kernel_id=one)
+    cols = np.random.default_rng(N).choice(N, 512, replace=False)
+    want = oracle.w4a16_forward(x, iw[:, cols], s[:, cols], z[:, cols], G).astype(np.float32)
+    assert rel_err(y1.cpu().numpy()[:, cols], want) <= TOL
+    for _ in range(3):
+        assert torch.equal(y1, qa.gemm_forward(xd, *packed, kernel_id=per))
+    bias = _dev(np.linspace(-1, 1, N).astype(np.float16), device)
+    res = torch.randn(M, N, device=device).half()
+    lnw = (torch.rand(K, device=device) + 0.5).half()
+    for kw in (dict(bias=bias, residual=res), dict(silu_mul=True), dict(rmsnorm_weight=lnw, rmsnorm_eps=1e-5, residual=res)):
+        assert torch.equal(qa.gemm_forward(xd, *packed, kernel_id=one, **kw), qa.gemm_forward(xd, *packed, kernel_id=per, **kw)), kw.keys()

@@ -277,7 +277,10 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(1, 11008, 4096).startswith("lean ntw=1 waves=16 tiles_per_wave<=8") and plan(1, 8192, 8192).startswith("lean ntw=2 waves=16 tiles_per_wave<=4 grid=256x1")
     assert plan(1, 8192, 10240).startswith("lean ntw=1 waves=8 tiles_per_wave<=8") and plan(4, 4096, 22016).startswith("lean ntw=2")
     assert plan(16, 4096, 4096).startswith("lean") and plan(8, 4096, 8192).startswith("lean") and plan(17, 4096, 4096).startswith("skinny")
-    assert plan(8, 4096, 22016).startswith("skinny") and plan(5, 4096, 12288).startswith("skinny")          # each workgroup fetches its own x: the r01-r04 kernels on wide layers
+    assert plan(5, 4096, 12288).startswith("skinny") and plan(7, 4096, 22016).startswith("skinny")          # 5..7 tokens on wide layers: the r01-r04 kernels
+    # 8..16 tokens on wide layers: one persistent workgroup per CU (x staged once; a one-block workgroup would fetch more bytes of x than of weights)
+    assert plan(8, 4096, 22016).startswith("lean ntw=2 waves=8 tiles_per_wave<=4 grid=256x1") and plan(16, 4096, 22016).startswith("lean ntw=1 waves=8 tiles_per_wave<=4 grid=256x1")
+    assert plan(16, 4096, 12288).startswith("lean ntw=1") and "grid=256x1" in plan(16, 4096, 12288) and plan(16, 8192, 57344).startswith("skinny")   # (x of 16 x 8192 does not fit LDS)
     assert plan(1, 28672, 8192).startswith("skinny") and plan(1, 512, 256).startswith("skinny")              # 224 / 4 k tiles: no build
     assert plan(1, 4096, 4096, G=64).startswith("skinny") and plan(2, 4096, 4096, G=256).startswith("lean")
     assert "tiles_per_wave<=0" in plan(1, 28672, 8192, kernel_id=L) and "tiles_per_wave<=0" in plan(1, 4096, 4096, G=64, kernel_id=L)   # forced without a build: UNSUPPORTED at launch

@@ -46,8 +46,11 @@ for spec in specs:
     timed(M, K, N, 0, sets, x, y, ws)   # (clocks, caches)
     base = timed(M, K, N, 0, sets, x, y, ws)
     print(f"{spec}: planner [{kernels.plan_describe(M, K, N, G)}] span {base[0]:.2f} us ({algo / base[0] / 8e6 * 100:.1f}% of 8 TB/s), dispatch {base[1]:.2f}")
-    for ntw, waves in (() if planner_only else ((1, 8), (1, 16), (2, 8), (2, 16))):
-        kid = LEAN | (ntw << 4) | ((waves // 4) << 8)
+    variants = () if planner_only else ((1, 8, 0), (1, 16, 0), (2, 8, 0), (2, 16, 0))
+    if "--persist" in sys.argv:
+        variants = ((1, 8, 0), (1, 8, 1), (1, 8, 2), (2, 8, 0), (2, 8, 1), (2, 8, 2))
+    for ntw, waves, slots in variants:
+        kid = LEAN | (ntw << 4) | ((waves // 4) << 8) | (slots << 22)
         try:
             plan = kernels.plan_describe(M, K, N, G, kid)
         except Exception as e:
