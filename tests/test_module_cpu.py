@@ -253,7 +253,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "waves=16" in plan(1, 11008, 4096, G=64) and "waves=8" in plan(1, 11008, 4096, G=32)                            # (not with four units per k-tile)
     assert plan(16, 4096, 6144, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=2") and "deferred-zero-fragment" in plan(16, 4096, 6144, kernel_id=kernels.KERNEL_SKINNY)    # 384 blocks: one round of 192
     assert plan(6, 8192, 8192, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=2") and plan(4, 28672, 8192).startswith("skinny ntw=4")
-    assert "deferred-zero-table" in plan(12, 4096, 22016) and plan(16, 4096, 22016).startswith("skinny ntw=4")
+    assert "deferred-zero-table" in plan(12, 4096, 22016, kernel_id=kernels.KERNEL_SKINNY) and plan(16, 4096, 22016, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4")
     assert plan(16, 8192, 57344).startswith("skinny ntw=4")
     # r03 audit: from five tokens no LDS copy of x outside the table flavour; one-tile launches with K = 4096 run sixteen waves
     assert plan(6, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=1 waves=16 x=l2 dequant=exact") and "waves=8 x=lds" in plan(4, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)
