@@ -1652,6 +1652,28 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       xk_auto_mb = 2;
     }
   }
+  // [r05 audit, profiles/r05_planner_audit.txt / r05_mid_sweep.txt: AUTO against forced launches of every family, 234 + 65 shapes, two sessions]
+  // two corrections where a four-wave tile was consistently ahead of the models' pick:
+  //  * 33..95 tokens, 160..256 workgroups of 64 x 128 tiles x TWO slices (N = 12288, 13824, 10240): 33 / 48 / 64 x 4096 x 12288 13.8 / 14.9 / 15.1 ->
+  //    12.5 / 13.4 / 13.7 us, 48 / 64 x 8192 x 10240 26.6 / 25.4 -> 21.8 / 22.2, 64 x 5120 x 13824 21.0 -> 18.7;
+  //  * 96..128 tokens where ONE row of 128 x 128 tiles x FOUR slices fits a round (N <= 8192): 96 / 128 x 4096 x 4096 12.0 / 12.1 -> 11.0 / 11.0,
+  //    x 4096 x 6144 13.7 / 14.0 -> 11.7 / 12.0, x 5120 x 5120 14.8 / 16.9 -> 13.6 / 13.9
+  if (allow_xk && family == QUICK_KERNEL_AUTO && G % 128 == 0 && ((G / 128) & (G / 128 - 1)) == 0 && !mt_req && !waves_req && grid_split_k <= 1 &&
+      (size_t)M * (size_t)K * 2 < ((size_t)1 << 32) && (size_t)M * (size_t)N * 2 < ((size_t)1 << 32)) {
+    const long t64 = (long)((M + 63) / 64) * (N / 128), t128 = (long)(N / 128);
+    const auto splits_evenly = [KT](int sx) { return KT / sx >= 4 && (KT + (KT + sx - 1) / sx - 1) / ((KT + sx - 1) / sx) == sx; };
+    if (M >= 33 && M <= 95 && t64 * 2 >= 160 && t64 * 2 <= 256 && splits_evenly(2)) {
+      p.kernel = QUICK_KERNEL_XW;
+      xw_auto_mb = 2;
+      xw_auto_pairs = 1;
+      xw_auto_s = 2;
+    } else if (M >= 96 && M <= 128 && t128 * 4 <= 256 && t128 * 4 >= 96 && splits_evenly(4)) {
+      p.kernel = QUICK_KERNEL_XW;
+      xw_auto_mb = 4;
+      xw_auto_pairs = 1;
+      xw_auto_s = 4;
+    }
+  }
   int ks = 1;
   if ((p.kernel == QUICK_KERNEL_WIDE || p.kernel == QUICK_KERNEL_XK) && G % 128 != 0) p.kernel = QUICK_KERNEL_TILED;  // small groups: r01's tiled kernel
   // x travels through a buffer descriptor with 32-bit offsets in the wide / exchange-K kernels: from 4 GiB of activations on, r01's

@@ -203,7 +203,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     p = plan(128, 4096, 4096)
     # (what workspace_bytes_ex asks for also covers the launch a SiLU * mul epilogue falls back to where the exchange-K plan cannot carry it)
     assert "slices=4" in p and int(p.rsplit("workspace=", 1)[1]) == 65536 + (16 << 20) <= _lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, 0, 0)
-    assert "grid=80x3 ksplit=3" in plan(64, 8192, 10240)     # not only powers of two: 240 of 256 CUs (tiled and wide kernels alike)
+    assert plan(64, 8192, 10240).startswith("xw tokens=64 channels=128") and "grid=160 slices=2" in plan(64, 8192, 10240)   # r05 audit: 80 tiles of 64 x 128 x two slices (r02-r04: wide tiles, three K slices)
     assert "grid=80x3 ksplit=3" in plan(64, 8192, 10240, kernel_id=kernels.KERNEL_TILED)
     # r01's tiled kernel (kernel_id TILED; the planner's own choice for G < 128): 256-channel tiles by how they quantise onto 256 CUs
     T = kernels.KERNEL_TILED
@@ -224,14 +224,15 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(512, 4096, 4096, kernel_id=X).startswith("xk tokens=128") and plan(512, 4096, 4096, kernel_id=X | (2 << 4)).startswith(
         "xk tokens=64 channels=128 waves=8 ring=5 queue=4 grid=256 slices=1")                            # r03's bench line: one 64 x 128 tile per CU
     assert plan(64, 4096, 22016).startswith("xk tokens=64") and "slices=2" in plan(64, 4096, 12288)   # 172 / 96 tiles of 64 x 128 (below 96 tokens: r03's picks)
-    assert "xk tokens=64" in plan(128, 4096, 4096) and "slices=4" in plan(128, 4096, 4096)            # ... and below 160 on the narrow layers
+    assert plan(128, 4096, 4096).startswith("xw tokens=128 channels=128") and "grid=128 slices=4" in plan(128, 4096, 4096)   # r05 audit: one row of 128 x 128 tiles x four slices (r03-r04: xk 64-token tiles)
+    assert plan(64, 4096, 12288).startswith("xw tokens=64 channels=128") and plan(64, 4096, 6144).startswith("xk tokens=64")        # 33..95 tokens: 64 x 128 x two slices where that is 160..256 workgroups
     # r04: the four-wave kernels with generated loops (w4a16_xw.hpp) from 160 tokens (96 on wide layers), picked by their own launch-time model
     assert plan(512, 4096, 4096).startswith("xw tokens=128 channels=128 waves=4 ring=4 queue=4 grid=256 slices=2")    # the bench line: 128 x 128 tiles, two K slices
     assert plan(256, 4096, 4096).startswith("xw tokens=64 channels=128 waves=4 ring=8 queue=8 grid=256 slices=2")
     assert plan(160, 4096, 6144).startswith("xw tokens=128 channels=128") and "slices=2" in plan(160, 4096, 6144)
     assert plan(1024, 4096, 4096).startswith("xw tokens=128 channels=128 waves=4 ring=4 queue=4 grid=256 slices=1")   # 256 tiles of 128 x 128: one round, nothing to exchange
     assert "slices=2" in plan(512, 11008, 4096) and "xw tokens=128 channels=128" in plan(512, 11008, 4096)            # 128 tiles x 2 slices of 43 stages
-    assert plan(96, 4096, 22016).startswith("xw tokens=128 channels=128") and plan(96, 4096, 4096).startswith("xk")   # below 160 tokens only on wide layers
+    assert plan(96, 4096, 22016).startswith("xw tokens=128 channels=128") and plan(96, 4096, 4096).startswith("xw tokens=128 channels=128")   # from 96 tokens on every layer since r05
     assert plan(2048, 3584, 18944).startswith("xw tokens=256 channels=256")                            # several rounds: the 256 x 256 tile, since r04 with the generated loop
     assert plan(2048, 4096, 4096).startswith("xw tokens=128 channels=256") and "xw tokens=256 channels=256 waves=4 ring=2 queue=2 grid=2752 slices=1" in plan(8192, 4096, 22016)
     assert plan(1024, 28672, 8192).startswith("xw tokens=128 channels=256 waves=4 ring=4 queue=4 grid=256 slices=1")   # (r02: 128 tiles of 256 x 256 x 2 K slices; 256 one-slice tiles of 128 x 256 are 10 % ahead)
@@ -263,7 +264,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(32, 5120, 5120).startswith("skinny ntw=4") and plan(64, 5120, 5120).startswith("xk tokens=64")    # 320 skinny workgroups would be two rounds; r03: 40 tiles x 4 slices
     assert plan(32, 13824, 5120).startswith("tiled") and "slices=8" in plan(48, 14336, 4096)                      # slices of > 64 stages; r03 from 33 tokens: 32 tiles x 8 slices of 14 stages
     assert "tokens=32 channels=128 waves=8 grid=192x1 ksplit=1" in plan(64, 4096, 12288, kernel_id=T)              # twice the tiles, nothing to reduce
-    assert "tokens=64" in plan(48, 8192, 10240) and "ksplit=3" in plan(48, 8192, 10240)
+    assert "tokens=64" in plan(48, 8192, 10240) and "slices=2" in plan(48, 8192, 10240)   # (r05: four-wave 64 x 128 tiles x two slices; r02-r04: wide tiles, three K slices)
     assert plan(64, 11008, 4096, kernel_id=T).startswith("tiled tokens=32") and "slices=8" in plan(48, 11008, 4096)
     assert plan(64, 28672, 8192).startswith("xk tokens=64") and "slices=4" in plan(64, 28672, 8192)               # long K slices fill the chip
     assert "slices=4" in plan(48, 28672, 8192) and "slices=4" in plan(64, 8192, 8192) and "slices=4" in plan(64, 4096, 8192)
