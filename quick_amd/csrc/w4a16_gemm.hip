@@ -1573,7 +1573,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       }
     }
     // [r04] the four-wave kernels with generated hand-placed loops (w4a16_xw.hpp) -- 128 x 256, 128 x 128 and 64 x 128 tiles, 1 / 2 / 4 K
-    // slices per tile.  Their own launch-time model (same form as above; fitted, relative least squares, to scripts/r04/gpu_xw_sweep.sh:
+    // slices per tile.  Their own launch-time model (same form as above; fitted, relative least squares, to scripts/archive/r04_gpu_xw_sweep.sh:
     // 9 layer shapes x 12 token counts x 6 forced variants, 4.3 / 4.7 / 1.7 % rms) picks the tile and the slice count; WHETHER one of them
     // runs is decided on the sweep's own rows, against the pick of the rules above (profiles/r04_xw_sweep.jsonl, tools/xw_sweep_report.py):
     // they replace the 64- / 128-token wide tiles, the tiled kernel and the exchange-K tiles (6 % faster on the geometric mean of the 108
@@ -1613,7 +1613,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     }
     // [r04] where the r02 model's pick is the 256 x 256 tile with ONE K slice, the four-wave kernel with the generated 256 x 256 loop runs it
     // instead: 0.935-0.965 of the hipcc-scheduled kernel's time on 28 prefill shapes of 1024..8192 tokens in one session, bit-identical
-    // results (scripts/r04/gpu_xw82.sh, profiles/r04_xw256_sweep.jsonl; 4096^3 117.3 -> 111.6 us, 8192 x 4096 x 22016 1232 -> 1170).
+    // results (scripts/archive/r04_gpu_xw82.sh, profiles/r04_xw256_sweep.jsonl; 4096^3 117.3 -> 111.6 us, 8192 x 4096 x 22016 1232 -> 1170).
     // QUICK_AMD_XW256=0 keeps r02's kernel (the A/B switch).
     if (best > 0 && wide_mb == 8 && !xw_auto_mb && !xk_auto_mb && N % 256 == 0 && (G / 128 & (G / 128 - 1)) == 0 && KT >= 2 &&
         wide_split((long)((M + 255) / 256) * (N / 256)) == 1 &&
@@ -1627,7 +1627,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       }
     }
     p.est_us = best;
-    // ... unless the models say the r02 / r03 candidate is clearly ahead: on the audit's 133 four-wave picks (scripts/r04/gpu_audit_vs_r03.sh, this
+    // ... unless the models say the r02 / r03 candidate is clearly ahead: on the audit's 133 four-wave picks (scripts/archive/r04_gpu_audit_vs_r03.sh, this
     // tree against r03's library in one session) the r03 model reads 0.95x and the four-wave model 1.03x the measured time, and "four-wave
     // iff its estimate < 1.10 x the other" is the best threshold (geometric mean 0.904 against 0.905 for always; it returns 320 x 4096 x 12288 /
     // 22016 -- 430 tiles of 64 x 256 against 516 of 128 x 128, a nearly empty third round -- to the r02 ring kernel: 43.5 -> 39.6 us, 82.9 -> 75.0)

@@ -1,4 +1,4 @@
-"""Report of scripts/r04/gpu_audit_vs_r03.sh: this tree's planner pick against r03's library, per shape (two alternating rounds each)."""
+"""Report of scripts/archive/r04_gpu_audit_vs_r03.sh: this tree's planner pick against r03's library, per shape (two alternating rounds each)."""
 import json, sys, collections, glob, os, math
 d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r04")
 t = collections.defaultdict(lambda: collections.defaultdict(list))

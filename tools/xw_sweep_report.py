@@ -1,4 +1,4 @@
-"""Report + fit of scripts/r04/gpu_xw_sweep.sh (profiles/r04_xw_sweep.jsonl): per shape the planner's r03 pick against six forced four-wave
+"""Report + fit of scripts/archive/r04_gpu_xw_sweep.sh (profiles/r04_xw_sweep.jsonl): per shape the planner's r03 pick against six forced four-wave
 variants, the launch-time model of the four-wave kernels fitted to those rows (the coefficients in make_plan, w4a16_gemm.hip), and the
 policy "four-wave kernel with the smallest estimate unless r03 picked the 256 x 256 tile" replayed on the measurements.
     python tools/xw_sweep_report.py [file]"""
