@@ -25,6 +25,11 @@
 
 namespace quick_amd {
 
+#ifndef QA_LEAN_WAUX
+#define QA_LEAN_WAUX 2   // cache policy of the weight requests: nt (streaming).  Against the default policy, alternating builds in one session
+                         // (profiles/r05_ab_lean_nt.txt): 1 x 4096 x 22016 10.2 -> 9.0 us in-kernel, x 12288 6.05 -> 5.63, 11008 x 4096 6.2 -> 5.8,
+                         // 16 x 4096 x 22016 15.6 -> 14.5; level at 4096 x 4096 -- the weights are read once and x stays in L2
+#endif
 constexpr int kLeanStamps = 16;  // phase stamps per wave (tools builds): u64 s_memrealtime ticks
 
 // LDS of one lean workgroup (host and device agree through these functions)
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
     for (int j = 0; j < TMAX; ++j)
 #pragma unroll
       for (int c = 0; c < NTW; ++c)
-        wq[c][j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)lane * 16u + (j < T ? 0u : 0x80000000u), ((unsigned)(blk * NTW + c) * (unsigned)KT + (unsigned)(kb + j)) * 1024u, 0);
+        wq[c][j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)lane * 16u + (j < T ? 0u : 0x80000000u), ((unsigned)(blk * NTW + c) * (unsigned)KT + (unsigned)(kb + j)) * 1024u, QA_LEAN_WAUX);
     __builtin_amdgcn_sched_barrier(0);
   };
   request(nb);
