@@ -77,7 +77,10 @@ __device__ __forceinline__ SkinnyBufs skinny_bufs(const GemmArgs& a, int lane) {
 }
 
 // chunk of U k-tiles starting at kt of channel block `cb` (in units of 16 channels: block index * NTW)
-template <int NTW, int GM, int U, bool XLDS, bool LN = false>
+// NT: the weight requests carry the nt (streaming) cache policy -- launches with ONE token block, where every weight byte is read once
+// [r05 A/B builds, profiles/r05_ab_skinny_nt.txt: 1 x 28672 x 8192 24.0 -> 21.9 us, 16 x 8192 x 57344 59.3 -> 57.5, Llama-2-70B bs = 16 1358 -> 1379 tok/s;
+// with two token blocks the second one's re-read misses L2: 32 x 4096 x 8192 8.6 -> 9.1, so those keep the default policy]
+template <int NTW, int GM, int U, bool XLDS, bool LN = false, bool NT = false>
 __device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS, LN>& c, int kt, int kt_last, const SkinnyBufs& b,
                                             int cb, const half_t* xp, const GemmArgs& a, const half_t* gp = nullptr) {
   constexpr int NG = groups_per_tile<GM>();
@@ -85,7 +88,7 @@ __device__ __forceinline__ void skinny_load(SkinnyChunk<NTW, GM, U, XLDS, LN>& c
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int j = 0; j < NTW; ++j)  // past the end: replay
-      c.w[u][j] = __builtin_amdgcn_raw_buffer_load_b128(b.w, b.w_voff, (unsigned)(cb + j) * b.wstride_bytes + (unsigned)min(kt + u, kt_last) * 1024u, 0);
+      c.w[u][j] = __builtin_amdgcn_raw_buffer_load_b128(b.w, b.w_voff, (unsigned)(cb + j) * b.wstride_bytes + (unsigned)min(kt + u, kt_last) * 1024u, NT ? 2 : 0);
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -403,7 +406,7 @@ __device__ __forceinline__ void skinny_finish(const GemmArgs& a, floatx4 (&acc)[
 // the Llama-2-70B shapes at M = 16 [r01]).
 // (span stamps: written out at the kernel's own two exits -- moving the body into a forceinline device function called between
 // two stamps changed hipcc's code for the deferred-zero paths into something that fails the parity tests [r02])
-template <int NTW, int WAVES, int GM, bool XLDS, bool DZ, bool LN = false, bool SPAN = false>
+template <int NTW, int WAVES, int GM, bool XLDS, bool DZ, bool LN = false, bool SPAN = false, bool NT = false>
 __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs a) {
   if constexpr (SPAN) span_stamp(a.span, 0);
   constexpr bool PERSIST = XLDS;
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
   int parity = 0;
   // The load of the next chunk is issued in a block that always issues it: a guarded load would make hipcc's
   // s_waitcnt pass assume the smaller in-flight count and wait for most of the prefetch before the compute.
-#define QA_SKINNY_LOAD(c) skinny_load<NTW, GM, U, XLDS, LN>(c, kt_nxt, kt_last, bufs, nb_nxt * NTW, xp, a)
+#define QA_SKINNY_LOAD(c) skinny_load<NTW, GM, U, XLDS, LN, NT>(c, kt_nxt, kt_last, bufs, nb_nxt * NTW, xp, a)
 #define QA_SKINNY_ADVANCE(nb, kt)                                                                                  \
   do {                                                                                                             \
     kt += U;                                                                                                       \
@@ -484,15 +487,15 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     const u32x4 bc_bits = (lane & 1) ? u32x4{0x64006400u, 0x54005400u, 0x64006400u, 0x54005400u}
                                      : u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
     const half8_t bconst = __builtin_bit_cast(half8_t, bc_bits);
-    if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS, LN>(cA, kt_begin, kt_end - 1, bufs, cb, xp, a, gp);
+    if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS, LN, NT>(cA, kt_begin, kt_end - 1, bufs, cb, xp, a, gp);
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
-      if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS, LN>(cB, kt + U, kt_end - 1, bufs, cb, xp, a, gp);
+      if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS, LN, NT>(cB, kt + U, kt_end - 1, bufs, cb, xp, a, gp);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DZ) skinny_compute_dzf<NTW, GM, U, LN>(cA, kt, kt_end, bconst, (lane & 1) != 0, acc, &ssq);
       else skinny_compute<NTW, GM, U, XLDS>(cA, kt, kt_end, nullptr, acc);
       if (kt + U >= kt_end) break;
-      if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS, LN>(cA, kt + 2 * U, kt_end - 1, bufs, cb, xp, a, gp);
+      if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS, LN, NT>(cA, kt + 2 * U, kt_end - 1, bufs, cb, xp, a, gp);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DZ) skinny_compute_dzf<NTW, GM, U, LN>(cB, kt + U, kt_end, bconst, (lane & 1) != 0, acc, &ssq);
       else skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, acc);
@@ -2039,6 +2042,16 @@ static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) 
       }
     }
     g_span_unsupported = true;
+    return;
+  }
+  if (a.M <= 16 && group_mode(a.G) == 0) {  // one token block: weights streamed once -> nt requests (see skinny_load)
+    auto kfn = w4a16_skinny_kernel<NTW, WAVES, 0, XLDS, DZ, LN, false, true>;
+    static bool attr_set_nt = false;
+    if (!attr_set_nt) {
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+      attr_set_nt = true;
+    }
+    hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)lds, L.st, L.start, L.stop, 0, a);
     return;
   }
 #define QA_SKINNY(GMV)                                                                                             \
