@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)   # one graph replay costs ~0.4 ms on top of its K launches: 7 % at K = 200
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--timed-launch", default="auto", choices=("auto", "graph", "eager"),
+                    help="how the K timed steps reach the GPU: one hipGraph replay, or launches queued behind the untimed warm-up (auto: eager up to 256 steps)")
     ap.add_argument("--M", type=int, default=512, help="token count of the headline step")
     ap.add_argument("--K", type=int, default=4096)
     ap.add_argument("--N", type=int, default=4096)
@@ -259,16 +261,35 @@ def main():
         # the first event, the K graph-replayed steps and the second event go into the stream back to back.  With a synchronize in front of
         # the first event the GPU sat idle while the host submitted the graph: the 20-step protocol read M = 512 at 24.3 us per step against
         # 20.5 with 2000 steps in the same process (M = 1: 4.5 against 4.0) -- the idle gap and the clock ramp behind it, not the kernels.
-        n_warm = 150 if spare else 0
+        # [r05] ... and the untimed launches are 40 replays of a 50-launch hipGraph on the spare sets (2000 launches, 8-45 ms): 150 launches
+        # (0.6-3.5 ms) still left the 20-step M = 512 step at 24.2 us against 21.9 behind 2000 (gpu_m512.sh, one box, one session).
+        # [r05] ... and with few steps the timed launches are queued EAGERLY behind that untimed work instead of replayed as a graph: the
+        # host gets K <= 256 launches into the queue long before the GPU reaches them, so they run back to back exactly as graph nodes do,
+        # without the ~30-50 us a graph replay needs to start (M = 512, 20 steps: graph 21.9 us per step, queued eager 21.2-21.5, 2000-step
+        # graph 21.2; M = 1: 4.55 / 4.13 / 3.94).  Above 256 steps the graph is kept: its start is amortised and the host could fall behind.
+        n_warm, gwarm = (2000 if spare else 0), None
+        if spare and graph is not None:
+            try:
+                gwarm = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gwarm):
+                    for r in range(50):
+                        launch(spare[r % len(spare)])
+            except Exception:                    # pragma: no cover
+                gwarm = None
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        for r in range(n_warm):
-            launch(spare[r % len(spare)])
+        if gwarm is not None:
+            for _ in range(n_warm // 50):
+                gwarm.replay()
+        else:
+            for r in range(n_warm):
+                launch(spare[r % len(spare)])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        if graph is not None:
+        queued_eager = args.timed_launch == "eager" or (args.timed_launch == "auto" and steps <= 256 and n_warm > 0)
+        if graph is not None and not queued_eager:
             graph.replay()
         else:
             for i in range(steps):
@@ -278,6 +299,8 @@ def main():
         if dist is not None:
             dist.barrier()
         ms_step = replicas.max_over_ranks(dist, e0.elapsed_time(e1) / steps)
+        if graph is not None and queued_eager:
+            mode = "queued-eager"
 
         # the kernel's own duration: event pair bound to each dispatch, cycling the same weight sets
         # per-dispatch event pairs: 200 launches whatever --steps says (the mean of 15 separated launches wanders by +-8 % from run
@@ -292,7 +315,7 @@ def main():
         # The dispatch-bound event pair over-reads on some boxes (r01: 0.7 % above the step; r02: 27.1 us against a 24.4 us step
         # and rocprofv3's 25.1 us average in the same session).  A launch cannot take longer than the back-to-back step of
         # identical launches it is part of, so the step bounds it; both numbers go into the JSON.
-        k_us = min(k_us_events, ms_step * 1e3) if mode == "hipgraph" else k_us_events
+        k_us = min(k_us_events, ms_step * 1e3) if mode in ("hipgraph", "queued-eager") else k_us_events
         # same, cache-resident (one weight set): what a launch sees when the layer was just touched
         rc = lib.quick_w4a16_gemm_profile(x.data_ptr(), qw_arr, sc_arr, qz_arr, 1, y.data_ptr(), ws.data_ptr(), ws_bytes,
                                           M, K, N, G, args.kernel, args.split_k, psteps, kus, stream.cuda_stream)
@@ -331,13 +354,14 @@ def main():
         step_work = (nbytes / 1e9 if roof["bound"] == "hbm" else flops / 1e12) / (ms_step * 1e-3)
         roof["frac_step"] = step_work / roof["peak"]
         roof["headline_fraction"] = "frac_step"
-        roof["frac_clocks"] = {"frac_step": "graph-replayed step, barrier to barrier", "frac": "dispatch duration (event pair = rocprofv3 kernel trace)",
+        roof["frac_clocks"] = {"frac_step": "back-to-back step (graph replay or queued launches), event to event on the stream", "frac": "dispatch duration (event pair = rocprofv3 kernel trace)",
                                "frac_inkernel": "per-wave s_memrealtime stamps, first wave in -> last wave out"}
         return {"M": M, "ms_per_step": ms_step, "tops": flops / (ms_step * 1e-3) / 1e12, "tops_kernel_only": flops / (k_us * 1e-6) / 1e12,
                 "launch": mode, "weight_sets_in_timed_region": min(steps, n_sets), "cache_flushed_before_timed_region": True,
                 "clock_warmup_launches_on_other_weight_sets": n_warm,
-                "timed_region": "two hipEvents on the stream around exactly K graph-replayed steps; barrier + synchronize before the untimed "
-                                "launches that precede the first event and after the second event",
+                "timed_region": "two hipEvents on the stream around exactly K steps (K <= 256: launches queued behind the untimed ones, "
+                                "K > 256: one hipGraph replay); barrier + synchronize before the untimed launches that precede the first "
+                                "event and after the second event",
                 "roofline": roof}, y
 
     fl = (ctypes.c_float * 60)()
