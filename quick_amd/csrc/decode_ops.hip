@@ -3,6 +3,7 @@
 // extensions (awq_ext.layernorm_forward_cuda, quick/awq/modules/fused/norm.py:18; awq_ft_ext.single_query_attention,
 // quick/awq/modules/fused/attn.py:217) or from eager torch (attn.py:166-210); here they are small HBM/latency-bound
 // HIP kernels so that one decode layer is 9 launches instead of ~40.  fp16 in/out, fp32 arithmetic.
+#include <cstdlib>
 #include "w4a16_common.hpp"
 #include "../../include/quick_amd.h"
 
@@ -209,12 +210,18 @@ __device__ __forceinline__ void rope8(const half8_t x, const half_t* __restrict_
 // passes -- all scores into LDS, softmax, then all V -- with five barriers; with every workgroup of a large batch starting at
 // once its "all K, then all V" phases left HBM idle about half the time, 3.9 TB/s at bs=64, and the single pass is ahead at
 // every batch size: +8 % decode tok/s at bs=1, +1 % at bs=32, +0.5 % at bs=64..128 [r01].)
-__global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
+// [r05] WAVES x 4 row slots, UNR rows per slot and trip.  Few workgroups (batch x heads <= 128: decode at bs <= 4) run eight waves, so
+// that 256 positions are ONE trip -- one round of requests instead of two dependent ones -- and the first trip's requests no longer wait
+// for *pos: rows are clamped to the cache's end instead of to *pos - 1, and rows at or behind *pos are masked out of scores AND of the
+// value sum (their bytes may be anything).  Later trips clamp to *pos - 1 again (re-reading one row instead of fetching rows nobody needs).
+template <int WAVES, int UNR>
+__global__ __launch_bounds__(WAVES * 64) void decode_rope_attention_flash_kernel(
     const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t, const half_t* __restrict__ sin_t,
     const long* __restrict__ pos, half_t* __restrict__ k_cache, half_t* __restrict__ v_cache, half_t* __restrict__ out,
     int nh, int nkv, int L, float scale) {
   constexpr int D = 128;
-  __shared__ float part[4][D + 2];  // per wave: 128 output dims, running max, running sum
+  constexpr int SLOT = WAVES * 4;       // rows one load instruction of the workgroup covers
+  __shared__ float part[WAVES][D + 2];  // per wave: 128 output dims, running max, running sum
   const int b = blockIdx.y, h = blockIdx.x, group = nh / nkv, kvh = h / group;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & 15, rsel = lane >> 4;
@@ -225,20 +232,23 @@ __global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
   const half8_t kraw = *(const half8_t*)(row + (size_t)(nh + kvh) * D + sub * 8);
   const half8_t vn = *(const half8_t*)(row + (size_t)(nh + nkv + kvh) * D + sub * 8);
   const int p = (int)pos[0];  // cache rows 0..p-1 are attended from memory, row p (this token) from registers
+  __builtin_amdgcn_sched_barrier(0);  // (the request for *pos leaves here, its wait sits behind the first trip's cache requests)
 
-  constexpr int UNR = 8;
   const float LOG2E = 1.44269504088896f;
   float m = -INFINITY, l = 0.f;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float qr[8], kr[8];
   bool roped = false;
-  for (int tb = wave * 4; tb < p || !roped; tb += 16 * UNR) {  // wave-uniform trip count
+  int tb = wave * 4;
+  do {  // wave-uniform trip count; the first trip's requests leave before *pos is looked at
     const int t0 = tb + rsel;
     half8_t kv[UNR], vv[UNR];
+    const int last = roped ? p - 1 : L - 1;   // (first trip: *pos is still on its way; later trips re-read row p - 1 instead of rows nobody needs)
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) kv[u] = *(const half8_t*)(kp + (size_t)min(t0 + 16 * u, max(p - 1, 0)) * D);
+    for (int u = 0; u < UNR; ++u) kv[u] = *(const half8_t*)(kp + (size_t)min(t0 + SLOT * u, last) * D);
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) vv[u] = *(const half8_t*)(vp + (size_t)min(t0 + 16 * u, max(p - 1, 0)) * D);
+    for (int u = 0; u < UNR; ++u) vv[u] = *(const half8_t*)(vp + (size_t)min(t0 + SLOT * u, last) * D);
+    __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise hoists the wait for *pos and the cos / sin rows in front of these requests)
     if (!roped) {  // first trip: rotate q and the new k while the cache rows are in flight
       const half8_t cs = *(const half8_t*)(cos_t + (size_t)p * D + sub * 8), sn = *(const half8_t*)(sin_t + (size_t)p * D + sub * 8);
       const float sign = sub < 8 ? -1.f : 1.f;  // rotate_half: dims 0..63 pair with -x[i+64], dims 64..127 with +x[i-64]
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
         qr[j] = (float)(half_t)((float)(half_t)(qj * (float)cs[j]) + (float)(half_t)(sign * qp * (float)sn[j])) * (scale * LOG2E);
         kr[j] = (float)(half_t)((float)(half_t)(kj * (float)cs[j]) + (float)(half_t)(sign * kpn * (float)sn[j]));
       }
-      if (threadIdx.x < 16 && h % group == 0) {  // append to the caches (position p is not read by anyone in this launch)
+      if (threadIdx.x < 16 && h % group == 0) {  // append to the caches (position p is not used by anyone in this launch)
         half8_t kh;
 #pragma unroll
         for (int j = 0; j < 8; ++j) kh[j] = (half_t)kr[j];
@@ -258,8 +268,8 @@ __global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
       }
       roped = true;
     }
-    if (p == 0) break;  // first position: nothing in the cache yet (row 0 is unwritten -- 0 * NaN would poison the sum)
-    // scores in the log2 domain (q carries scale * log2 e): 8 rows of this slot
+    if (tb >= p) break;  // nothing (more) for this wave (first position: nothing in the cache yet)
+    // scores in the log2 domain (q carries scale * log2 e): UNR rows of this slot
     float d[UNR], mb = m;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) x += qr[j] * (float)kv[u][j];
       x = lanes_sum<16>(x);
-      d[u] = t0 + 16 * u < p ? x : -INFINITY;
+      d[u] = t0 + SLOT * u < p ? x : -INFINITY;
       mb = fmaxf(mb, d[u]);
     }
     const float mref = mb == -INFINITY ? 0.f : mb;
@@ -277,13 +287,16 @@ __global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
     for (int j = 0; j < 8; ++j) acc[j] *= corr;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const float e = exp2f(d[u] - mref);
-      l += e;
+      if (t0 + SLOT * u < p) {  // (a row behind the sequence holds anything, NaN included: 0 * NaN would poison the sum)
+        const float e = exp2f(d[u] - mref);
+        l += e;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += e * (float)vv[u][j];
+        for (int j = 0; j < 8; ++j) acc[j] += e * (float)vv[u][j];
+      }
     }
     m = mb;
-  }
+    tb += SLOT * UNR;
+  } while (tb < p);
   if (wave == 0 && rsel == 0) {  // this token (row p), from registers
     float x = 0.f;
 #pragma unroll
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
     for (int j = 0; j < 8; ++j) acc[j] = acc[j] * corr + e * (float)vn[j];
     m = mb;
   }
-  // merge the 4 row slots of the wave, then the 4 waves through LDS
+  // merge the 4 row slots of the wave, then the waves through LDS
   float mw = fmaxf(m, __shfl_xor(m, 16));
   mw = fmaxf(mw, __shfl_xor(mw, 32));
   const float sc_ = exp2f(m - (mw == -INFINITY ? 0.f : mw));
@@ -318,10 +331,12 @@ __global__ __launch_bounds__(256) void decode_rope_attention_flash_kernel(
   }
   __syncthreads();
   if (threadIdx.x < D) {
-    const float M = fmaxf(fmaxf(part[0][D], part[1][D]), fmaxf(part[2][D], part[3][D]));  // finite: wave 0 holds row p
+    float M = part[0][D];  // finite: wave 0 holds row p
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) M = fmaxf(M, part[w][D]);
     float num = 0.f, den = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < WAVES; ++w) {
       const float f = exp2f(part[w][D] - M);
       num += part[w][threadIdx.x] * f;
       den += part[w][D + 1] * f;
@@ -354,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void decode_rope_attention_gqa_kernel(
   const half8_t kraw = *(const half8_t*)(row + (size_t)(nh + kvh) * D + sub * 8);
   const half8_t vn = *(const half8_t*)(row + (size_t)(nh + nkv + kvh) * D + sub * 8);
   const int p = (int)pos[0];  // cache rows 0..p-1 are attended from memory, row p (this token) from registers
+  __builtin_amdgcn_sched_barrier(0);  // (the request for *pos leaves here, its wait sits behind the first trip's cache requests)
 
   const float LOG2E = 1.44269504088896f;
   float m[GROUP], l[GROUP], acc[GROUP][8], qr[GROUP][8], kr[8];
@@ -742,9 +758,21 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
     if (done) return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
   }
 #undef QA_GQA
-  hipLaunchKernelGGL(decode_rope_attention_flash_kernel, dim3(n_heads, batch), dim3(256), 0, (hipStream_t)hip_stream,
-                     (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, (const long*)pos,
-                     (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads, cache_len, scale);
+  // few workgroups and a cache longer than one four-wave trip: eight waves, 256 positions per trip; else four waves, 128 per trip
+  // [r05, profiles/r05_attention.txt: bs = 1, 192 / 512 positions 5.39 / 8.6 -> 5.15 / 7.5 us, 128 positions 4.24 against 5.0; from 256
+  // workgroups on the four-wave form is ahead everywhere; sixteen waves x 4 rows and four waves x 16 rows measured behind both]
+#define QA_FLASH(W, U)                                                                                                       \
+  hipLaunchKernelGGL((decode_rope_attention_flash_kernel<W, U>), dim3(n_heads, batch), dim3((W) * 64), 0, (hipStream_t)hip_stream, \
+                     (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, (const long*)pos,               \
+                     (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads, cache_len, scale)
+  static const int forced = [] {   // (A/B runs: 4 or 8 waves)
+    const char* e = getenv("QUICK_AMD_ATTN_WAVES");
+    return e ? atoi(e) : 0;
+  }();
+  const int pick = forced ? forced : (((long)n_heads * batch <= 128 && cache_len > 128) ? 8 : 4);
+  if (pick == 8) QA_FLASH(8, 8);
+  else QA_FLASH(4, 8);
+#undef QA_FLASH
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
 }
 
