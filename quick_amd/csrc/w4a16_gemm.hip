@@ -1661,6 +1661,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   //    12.5 / 13.4 / 13.7 us, 48 / 64 x 8192 x 10240 26.6 / 25.4 -> 21.8 / 22.2, 64 x 5120 x 13824 21.0 -> 18.7;
   //  * 96..128 tokens where ONE row of 128 x 128 tiles x FOUR slices fits a round (N <= 8192): 96 / 128 x 4096 x 4096 12.0 / 12.1 -> 11.0 / 11.0,
   //    x 4096 x 6144 13.7 / 14.0 -> 11.7 / 12.0, x 5120 x 5120 14.8 / 16.9 -> 13.6 / 13.9
+  // Final tree, two boxes (tools/audit_auto_vs_forced.py): geometric mean AUTO / best forced 1.0013, worst 1.048 (96 x 8192 x 8192, where two
+  // token tiles of 64 x 128 x two slices are ahead of the four-slice 128 x 128 tile; a rule for it was tried and lost 18 % at 96 / 128 x
+  // 28672 x 8192 -- the 64-token loop is the slower one per MFMA, only its exchange is cheaper -- so it stays a 5 % gap).
   if (allow_xk && family == QUICK_KERNEL_AUTO && G % 128 == 0 && ((G / 128) & (G / 128 - 1)) == 0 && !mt_req && !waves_req && grid_split_k <= 1 &&
       (size_t)M * (size_t)K * 2 < ((size_t)1 << 32) && (size_t)M * (size_t)N * 2 < ((size_t)1 << 32)) {
     const long t64 = (long)((M + 63) / 64) * (N / 128), t128 = (long)(N / 128);
