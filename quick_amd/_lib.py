@@ -58,7 +58,10 @@ def load():
                 f"{LIB} is missing: the HIP extension has not been built. "
                 "Run `python -m quick_amd.build` (needs hipcc); there is no CPU fallback for the W4A16 GEMM.")
         lib = ctypes.CDLL(LIB)
+        older = LIB != _DEFAULT_LIB      # an A/B library built from an earlier tree (tools/audit_vs_r03.py) may lack later entry points
         for name, (res, args) in _SIGNATURES.items():
+            if older and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
         for name, (res, args) in _TOOLS_ONLY.items():

@@ -30,7 +30,7 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"]
 # per-source extras: the lean small-M kernels take their leading arguments preloaded into SGPRs (w4a16_lean.hpp)
 _PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
-EXTRA_CFLAGS = {"w4a16_xw.hip": _PRELOAD, "w4a16_lean_a.hip": _PRELOAD, "w4a16_lean_b.hip": _PRELOAD, "w4a16_lean_c.hip": _PRELOAD}
+EXTRA_CFLAGS = {"w4a16_xw.hip": _PRELOAD, "w4a16_xk.hip": _PRELOAD, "w4a16_lean_a.hip": _PRELOAD, "w4a16_lean_b.hip": _PRELOAD, "w4a16_lean_c.hip": _PRELOAD}
 FLAGS = CFLAGS + ["-shared"]   # (what the library is built with, for the record)
 
 

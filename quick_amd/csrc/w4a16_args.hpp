@@ -27,6 +27,28 @@ struct GemmArgs {
   unsigned long long* span;  // measurement aid: per-wave start / end stamps in s_memrealtime ticks (100 MHz), see span_stamp; or null
 };
 
+// [r05] The exchange-K and four-wave kernels take what their first requests depend on as leading SCALAR parameters (13 dwords) and the rest as
+// this by-value block: their translation units are built with -amdgpu-kernarg-preload-count=16, so the scalars arrive in SGPRs with the
+// wave instead of through dependent s_load round trips to memory the host has just written (see w4a16_lean.hpp).
+struct XwRest {
+  const half_t* bias;
+  const half_t* residual;
+  half_t* Y;
+  float* slabs;
+  unsigned* counters;
+  unsigned long long* dbg;
+  unsigned long long* span;
+  int silu_mul, G;
+};
+__device__ __forceinline__ GemmArgs xw_args(const half_t* aX, const u32x4* aQW, const half_t* aS, int aM, int aK, int aN, int a_tpg, int a_ksplit, int a_kps,
+                                            int a_xcd_gm, const XwRest& rest) {
+  GemmArgs a;
+  a.X = aX; a.QW = aQW; a.S = aS; a.QZ = nullptr; a.bias = rest.bias; a.residual = rest.residual; a.silu_mul = rest.silu_mul; a.Y = rest.Y;
+  a.slabs = rest.slabs; a.counters = rest.counters; a.M = aM; a.K = aK; a.N = aN; a.G = rest.G; a.tpg = a_tpg; a.ksplit = a_ksplit;
+  a.kt_per_split = a_kps; a.xcd_gm = a_xcd_gm; a.dbg = rest.dbg; a.ln_w = nullptr; a.ln_eps = 0.f; a.span = rest.span;
+  return a;
+}
+
 // In-kernel wall-clock span of a launch: first wave's start -> last wave's end on the constant 100 MHz counter.  The
 // dispatch-duration clock (event pair / rocprofv3) cannot read below ~4.2 us -- an EMPTY kernel reads that -- so for the
 // microsecond-scale small-M launches this is the clock that can see the kernel (quick_w4a16_gemm_span, bench.py

@@ -20,6 +20,7 @@ static bool xk_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t 
   const dim3 grid(workgroups), block(KQ == 4 ? 1024 : ((ABL & 4096) ? 768 : 512));
   const int gm = a.G == 128 ? 0 : (a.G % 128 == 0 ? 1 : -1);
   if (gm < 0) return false;
+  const XwRest rest{a.bias, a.residual, a.Y, a.slabs, a.counters, a.dbg, a.span, a.silu_mul, a.G};
 #define QA_XK_K(GMV)                                                                                               \
   do {                                                                                                             \
     auto kfn = w4a16_xk_kernel<MB, GMV, NBUF, WD, S, ABL, KQ>;                                                     \
@@ -28,7 +29,8 @@ static bool xk_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t 
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
       attr_set = true;                                                                                             \
     }                                                                                                              \
-    hipExtLaunchKernelGGL(kfn, grid, block, lds, st, start, stop, 0, a);                                           \
+    hipExtLaunchKernelGGL(kfn, grid, block, lds, st, start, stop, 0, a.X, a.QW, a.S, a.M, a.K, a.N, a.tpg, a.ksplit, a.kt_per_split, a.xcd_gm,    \
+                          rest);                                                                                   \
   } while (0)
   if constexpr (ABL != 0) {
     if (gm != 0) return false;
@@ -47,6 +49,7 @@ static bool xl_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t 
   const dim3 grid(workgroups), block(768);
   const int gm = a.G == 128 ? 0 : (a.G % 128 == 0 ? 1 : -1);
   if (gm < 0 || (ABL != 0 && gm != 0)) return false;
+  const XwRest rest{a.bias, a.residual, a.Y, a.slabs, a.counters, a.dbg, a.span, a.silu_mul, a.G};
 #define QA_XL_K(GMV)                                                                                               \
   do {                                                                                                             \
     auto kfn = w4a16_xl_kernel<MB, GMV, S, ABL>;                                                                   \
@@ -55,7 +58,8 @@ static bool xl_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t 
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
       attr_set = true;                                                                                             \
     }                                                                                                              \
-    hipExtLaunchKernelGGL(kfn, grid, block, lds, st, start, stop, 0, a);                                           \
+    hipExtLaunchKernelGGL(kfn, grid, block, lds, st, start, stop, 0, a.X, a.QW, a.S, a.M, a.K, a.N, a.tpg, a.ksplit, a.kt_per_split, a.xcd_gm,    \
+                          rest);                                                                                   \
   } while (0)
   if constexpr (ABL != 0) {
     QA_XL_K(0);

@@ -743,7 +743,8 @@ __device__ __forceinline__ void xk_way_out16(const GemmArgs& a, const XkTile& t,
 // are summed through LDS on the way out.  [r03: two co-resident eight-wave workgroups per CU (tools build, <= 128 registers) run a
 // 64 x 128 x 4096 tile in 24.4 k clocks each-equivalent where one alone takes 33.8 k -- scripts/gpu_occ.sh]
 template <int MB, int GM, int NBUF, int WD, int S, int ABL = 0, int KQ = 2>
-__global__ __launch_bounds__(KQ == 4 ? 1024 : ((ABL & 4096) ? 768 : 512), (KQ == 4 || (ABL & 131072)) ? 4 : 1) void w4a16_xk_kernel(const GemmArgs a) {  // (131072, tools: <= 128 registers, two workgroups per CU)
+__global__ __launch_bounds__(KQ == 4 ? 1024 : ((ABL & 4096) ? 768 : 512), (KQ == 4 || (ABL & 131072)) ? 4 : 1) void w4a16_xk_kernel(const half_t* __restrict__ aX, const u32x4* __restrict__ aQW, const half_t* __restrict__ aS, int aM, int aK, int aN, int a_tpg, int a_ksplit, int a_kps, int a_xcd_gm, const XwRest rest) {  // (131072, tools: <= 128 registers, two workgroups per CU)
+  const GemmArgs a = xw_args(aX, aQW, aS, aM, aK, aN, a_tpg, a_ksplit, a_kps, a_xcd_gm, rest);
   constexpr int KH = KQ / 2;   // 128-k halves of a stage
   constexpr int NW = 4 * KQ, NG = 1;
   static_assert(KQ == 2 || (KQ == 4 && MB == 2 && S == 1 && !(ABL & 4096)), "sixteen waves: 64-token tiles, one slice");
@@ -1012,7 +1013,8 @@ __global__ __launch_bounds__(KQ == 4 ? 1024 : ((ABL & 4096) ? 768 : 512), (KQ ==
 // a stage (what r02's ring kernel did) and otherwise see only LDS, VALU and the matrix core.  168 registers per wave (three per SIMD).
 // ------------------------------------------------------------------------------------------------
 template <int MB, int GM, int S, int ABL = 0>
-__global__ __launch_bounds__(768) void w4a16_xl_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(768) void w4a16_xl_kernel(const half_t* __restrict__ aX, const u32x4* __restrict__ aQW, const half_t* __restrict__ aS, int aM, int aK, int aN, int a_tpg, int a_ksplit, int a_kps, int a_xcd_gm, const XwRest rest) {
+  const GemmArgs a = xw_args(aX, aQW, aS, aM, aK, aN, a_tpg, a_ksplit, a_kps, a_xcd_gm, rest);
   constexpr int NXS = MB == 2 ? 4 : 3, NWS = 5;   // (64 tokens: a stage is too short for one stage of lookahead)
   constexpr int SLOTX = MB * 8192, SLOTW = 8192 + 512;
   constexpr int UM = 4 - wide_bdepth<MB, 1>();   // the unit of a stage that first reads the NEXT stage's tokens
