@@ -800,11 +800,8 @@ int quick_lm_head_argmax_f16(const void* x, const void* norm_weight, float eps, 
 #define QA_LM(BV)                                                                                                     \
   do {                                                                                                                \
     auto kfn = lm_head_kernel<BV>;                                                                                    \
-    static bool attr_set = false;                                                                                     \
-    if (!attr_set) {                                                                                                  \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);             \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
+    static std::atomic<unsigned long long> attr_set{0};                                                                \
+    (void)lds_limit_once(attr_set, (const void*)kfn, 72 * 1024);                                                   \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), (unsigned)lds, st, (const half_t*)x, (const half_t*)norm_weight, eps, \
                        (const half_t*)weight, vocab, hidden, (half_t*)hidden_out, (half_t*)logits,                    \
                        (unsigned long long*)workspace);                                                               \

@@ -3,6 +3,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+
+namespace quick_amd {
+// Raise a kernel's dynamic-LDS limit once per (kernel, DEVICE): `done` is the call site's own static word, one bit per device ordinal
+// (the attribute is per device; a plain process-wide flag left a second GPU's first launch without it -- ADVICE r04).  Concurrent first
+// launches may both set it (idempotent).  A refusal is not cached: it stays in hipGetLastError() for the launch check behind the
+// launch (QUICK_ERR_LAUNCH) and the next call tries again.
+inline bool lds_limit_once(std::atomic<unsigned long long>& done, const void* kfn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return true;
+  if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  done.fetch_or(bit, std::memory_order_release);
+  return true;
+}
+}  // namespace quick_amd
 
 namespace quick_amd {
 

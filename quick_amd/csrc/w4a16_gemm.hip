@@ -1686,9 +1686,13 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   // tiled kernel (64-bit pointers) runs instead
   if ((p.kernel == QUICK_KERNEL_WIDE || p.kernel == QUICK_KERNEL_XK) && (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32)) p.kernel = QUICK_KERNEL_TILED;
   if (p.kernel == QUICK_KERNEL_XK && (size_t)M * (size_t)N * 2 >= ((size_t)1 << 32)) p.kernel = QUICK_KERNEL_TILED;  // (y through a buffer descriptor as well)
-  if (p.kernel == QUICK_KERNEL_XW && (G % 128 != 0 || ((G / 128) & (G / 128 - 1)) != 0 || (N % 256 != 0 && !xw_auto_mb && mt_req != 2 && !no_xlds) || (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32) ||
+  // (the tile the id asks for, worked out BEFORE the width check: a forced id with bit 12 or two token blocks and a block count of 8 means
+  // 256-channel tiles all the same, and N % 256 == 128 would leave the last 128 channels unwritten -- ADVICE r04)
+  const int xw_mb = xw_auto_mb ? xw_auto_mb : (mt_req == 2 ? 2 : (mt_req == 8 ? 8 : 4));
+  const int xw_pairs = xw_auto_mb ? xw_auto_pairs : (xw_mb == 8 ? 2 : ((xw_mb == 2 || no_xlds) ? 1 : 2));
+  if (p.kernel == QUICK_KERNEL_XW && (G % 128 != 0 || ((G / 128) & (G / 128 - 1)) != 0 || N % (xw_pairs * 128) != 0 || (size_t)M * (size_t)K * 2 >= ((size_t)1 << 32) ||
                                       (size_t)M * (size_t)N * 2 >= ((size_t)1 << 32)))
-    p.kernel = QUICK_KERNEL_TILED;  // (the loop shifts the k tile by log2(G / 128); 256-channel tiles; 32-bit buffer offsets)
+    p.kernel = QUICK_KERNEL_TILED;  // (the loop shifts the k tile by log2(G / 128); whole channel tiles; 32-bit buffer offsets)
   if (p.kernel == QUICK_KERNEL_XW) {
     // Four waves, one per SIMD, hand-placed K loops (w4a16_xw.hpp): tiles of 128 x 256, 128 x 128 or 64 x 128; S = 1, 2, 4 K slices per
     // tile on S compute units.  Nobody has to be co-resident (a wave that waits too long gives its block up, the last partner finishes it),
@@ -1696,7 +1700,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // bits 4-7: 32-token blocks per tile (2, 4; 0 = 4); bit 12: 128-channel tiles (implied by 2 blocks); bits 8-11: S (0 = as many as fit
     // the CUs); bits 22-26: log2 of the poll limit in ticks of 10 ns (tests: 1 = every wave gives up at once).
     // (bits 4-7 = 8: the 256 x 256 tile -- waves of 256 tokens x 64 channels, a ring of two 64 KiB slots, one slice only)
-    const int mb = xw_auto_mb ? xw_auto_mb : (mt_req == 2 ? 2 : (mt_req == 8 ? 8 : 4)), pairs = xw_auto_mb ? xw_auto_pairs : (mb == 8 ? 2 : ((mb == 2 || no_xlds) ? 1 : 2));
+    const int mb = xw_mb, pairs = xw_pairs;
     const int MBk = (M + mb * 32 - 1) / (mb * 32), NBk = N / (pairs * 128);
     p.wide_mb = mb;
     p.wide_pairs = pairs;
@@ -2049,22 +2053,16 @@ static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) 
   }
   if (a.M <= 16 && group_mode(a.G) == 0) {  // one token block: weights streamed once -> nt requests (see skinny_load)
     auto kfn = w4a16_skinny_kernel<NTW, WAVES, 0, XLDS, DZ, LN, false, true>;
-    static bool attr_set_nt = false;
-    if (!attr_set_nt) {
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
-      attr_set_nt = true;
-    }
+    static std::atomic<unsigned long long> attr_set_nt{0};
+    (void)lds_limit_once(attr_set_nt, (const void*)kfn, (int)kLdsPerCu);
     hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)lds, L.st, L.start, L.stop, 0, a);
     return;
   }
 #define QA_SKINNY(GMV)                                                                                             \
   do {                                                                                                             \
     auto kfn = w4a16_skinny_kernel<NTW, WAVES, GMV, XLDS, DZ, LN>;                                                 \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);     \
-      attr_set = true;                                                                                             \
-    }                                                                                                              \
+    static std::atomic<unsigned long long> attr_set{0};                                                                \
+    (void)lds_limit_once(attr_set, (const void*)kfn, (int)kLdsPerCu);                                              \
     hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)lds, L.st, L.start, L.stop, 0, a);                           \
   } while (0)
   if constexpr (LN) {  // only reached with G % 128 == 0
@@ -2123,11 +2121,8 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
 #define QA_TILED_K(GMV, ABLV)                                                                                      \
   do {                                                                                                             \
     auto kfn = w4a16_tiled_kernel<BMT, TN, WK, GMV, ABLV, WN>;                                                        \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-      attr_set = true;                                                                                             \
-    }                                                                                                              \
+    static std::atomic<unsigned long long> attr_set{0};                                                                \
+    (void)lds_limit_once(attr_set, (const void*)kfn, (int)lds);                                                    \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
 #ifdef QUICK_AMD_TOOLS
@@ -2153,11 +2148,8 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
 #define QA_TILED32_K(GMV)                                                                                          \
   do {                                                                                                             \
     auto kfn = w4a16_tiled32_kernel<BMT, TN, WK, GMV>;                                                             \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-      attr_set = true;                                                                                             \
-    }                                                                                                              \
+    static std::atomic<unsigned long long> attr_set{0};                                                                \
+    (void)lds_limit_once(attr_set, (const void*)kfn, (int)lds);                                                    \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
     switch (group_mode(a.G)) {
@@ -2187,11 +2179,8 @@ static void launch_ring(const Plan& p, const GemmArgs& a, const Launch& L) {
 #define QA_RING_K(GMV)                                                                                             \
   do {                                                                                                             \
     auto kfn = w4a16_ring_kernel<MB, PAIRS, GMV, NBUF, 0, WK>;                                                     \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-      attr_set = true;                                                                                             \
-    }                                                                                                              \
+    static std::atomic<unsigned long long> attr_set{0};                                                                \
+    (void)lds_limit_once(attr_set, (const void*)kfn, (int)lds);                                                    \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
 #ifdef QUICK_AMD_TOOLS
@@ -2270,11 +2259,8 @@ static void launch_wide(const Plan& p, const GemmArgs& a, const Launch& L) {
 #define QA_WIDE_K(GMV)                                                                                             \
   do {                                                                                                             \
     auto kfn = w4a16_wide_kernel<MB, PAIRS, GMV>;                                                                  \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-      attr_set = true;                                                                                             \
-    }                                                                                                              \
+    static std::atomic<unsigned long long> attr_set{0};                                                                \
+    (void)lds_limit_once(attr_set, (const void*)kfn, (int)lds);                                                    \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
   } while (0)
 #ifdef QUICK_AMD_TOOLS

@@ -14,11 +14,8 @@ namespace quick_amd {
 template <int WAVES, int TMAX, int NTW, int GM, int ABL, bool LN, int MR, int NSETS = 1>
 static bool lean_go(const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
   auto kfn = w4a16_lean_kernel<WAVES, TMAX, NTW, GM, ABL, LN, MR, NSETS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_set{0};
+  (void)lds_limit_once(attr_set, (const void*)kfn, 160 * 1024);
   const unsigned lds = lean_lds_need(a.M, a.K, WAVES, NTW, a.ln_w != nullptr, NSETS > 1);
   LeanRest rest{};
   rest.Y = a.Y; rest.bias = a.bias; rest.residual = a.residual; rest.silu_mul = a.silu_mul; rest.ln_eps = a.ln_eps; rest.span = a.span; rest.dbg = a.dbg;

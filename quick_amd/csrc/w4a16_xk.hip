@@ -24,11 +24,8 @@ static bool xk_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t 
 #define QA_XK_K(GMV)                                                                                               \
   do {                                                                                                             \
     auto kfn = w4a16_xk_kernel<MB, GMV, NBUF, WD, S, ABL, KQ>;                                                     \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-      attr_set = true;                                                                                             \
-    }                                                                                                              \
+    static std::atomic<unsigned long long> attr_set{0};                                                                \
+    (void)lds_limit_once(attr_set, (const void*)kfn, (int)lds);                                                    \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, st, start, stop, 0, a.X, a.QW, a.S, a.M, a.K, a.N, a.tpg, a.ksplit, a.kt_per_split, a.xcd_gm,    \
                           rest);                                                                                   \
   } while (0)
@@ -53,11 +50,8 @@ static bool xl_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t 
 #define QA_XL_K(GMV)                                                                                               \
   do {                                                                                                             \
     auto kfn = w4a16_xl_kernel<MB, GMV, S, ABL>;                                                                   \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-      attr_set = true;                                                                                             \
-    }                                                                                                              \
+    static std::atomic<unsigned long long> attr_set{0};                                                                \
+    (void)lds_limit_once(attr_set, (const void*)kfn, (int)lds);                                                    \
     hipExtLaunchKernelGGL(kfn, grid, block, lds, st, start, stop, 0, a.X, a.QW, a.S, a.M, a.K, a.N, a.tpg, a.ksplit, a.kt_per_split, a.xcd_gm,    \
                           rest);                                                                                   \
   } while (0)

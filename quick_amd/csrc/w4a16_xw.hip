@@ -17,11 +17,8 @@ template <int MB, int PAIRS, int S, int ABL>
 static bool xw_go(const GemmArgs& a, int workgroups, hipStream_t st, hipEvent_t start, hipEvent_t stop) {
   constexpr unsigned lds = 128 * 1024;
   auto kfn = w4a16_xw_kernel<MB, PAIRS, S, ABL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_set{0};
+  (void)lds_limit_once(attr_set, (const void*)kfn, (int)lds);
   XwRest rest{a.bias, a.residual, a.Y, a.slabs, a.counters, a.dbg, a.span, a.silu_mul, a.G};
   hipExtLaunchKernelGGL(kfn, dim3(workgroups), dim3(256), lds, st, start, stop, 0, a.X, a.QW, a.S, a.M, a.K, a.N, a.tpg, a.ksplit, a.kt_per_split, a.xcd_gm, rest);
   return true;

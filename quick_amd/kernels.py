@@ -181,20 +181,22 @@ def reference_to_mi355x_cached(kernel, scaling_factors, zeros):
     if ent is not None and ent.versions == versions and all(r() is t for r, t in zip(ent.refs, tensors)):
         if kernel.is_cuda:
             cur = torch.cuda.current_stream(kernel.device)
-            if cur != ent.stream and cur.cuda_stream not in ent.seen:
+            sid = (cur.stream_id, cur.cuda_stream)     # (torch's id AND the raw handle: the runtime recycles handles of destroyed streams)
+            if cur != ent.stream:
                 # Made on another stream.  Outside a capture: wait for the repack ONCE on the host -- from then on the copy is visible to
-                # every stream -- and tell the allocator once per stream who else reads it; later hits cost nothing.
-                # Inside a capture nothing may block: the capturing stream waits for the event, every time, until a call outside one.
-                if torch.cuda.is_current_stream_capturing():
-                    if not ent.done:
+                # every stream and later hits cost two comparisons.  Inside a capture nothing may block: the capturing stream
+                # waits for the event, on every hit, until a call outside one has synchronised.  Either way the allocator learns once per
+                # stream who else reads the copy (record_stream is capture-safe: a graph captured on a side stream is covered -- ADVICE r04).
+                if not ent.done:
+                    if torch.cuda.is_current_stream_capturing():
                         cur.wait_event(ent.event)
-                else:
-                    if not ent.done:
+                    else:
                         ent.event.synchronize()
                         ent.done = True
+                if sid not in ent.seen:
                     for t in ent.packed:
                         t.record_stream(cur)
-                    ent.seen.add(cur.cuda_stream)
+                    ent.seen.add(sid)
         return ent.packed
     ent = _Repacked()
     ent.stream = ent.event = None

@@ -429,7 +429,7 @@ def run_macro(c):
         ins += ['[xv%d] "v"(b.x_voff[%d])' % (i, i) for i in range(c.NX)]
     ins += ['[wv] "v"(b.w_voff)', '[sv] "v"(b.s_voff)', '[xrd] "v"(xrd)', '[xdst] "s"(xdst)', '[ktlo] "s"(kt_lo)', '[kthi] "s"(kt_hi)']
     ins += ['[mlast] "s"(m_last)'] if c.big else ['[wps] "s"(b.w_pstride)', '[sps] "s"(b.s_pstride)']
-    cl = ['"memory"', '"scc"'] + ['"v%d"' % r for r in range(48, c.VEND)] + ['"s%d"' % r for r in range(52, 82 if c.big else 78)]
+    cl = ['"memory"', '"scc"', '"m0"'] + ['"v%d"' % r for r in range(48, c.VEND)] + ['"s%d"' % r for r in range(52, 82 if c.big else 78)]
     stamps = '[t0] "=&s"(t0), [t1] "=&s"(t1)' + ('' if c.big else ', [clk] "=&s"(clk)')
     body = "#define QA_XW_RUN_%s() asm volatile(QA_XW_ASM_%s : %s : %s : %s)\n" % (c.name, c.name, outs, ", ".join(ins), ", ".join(cl))
     body += ("#define QA_XW_RUN_STAMPED_%s() asm volatile(QA_XW_ASM_STAMPED_%s : %s, %s : %s : %s)\n"
