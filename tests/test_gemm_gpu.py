@@ -483,7 +483,7 @@ def test_function_level_drop_in_cache_hits_from_other_streams(qa, device):
     assert ent.stream == maker and not ent.done
     with torch.cuda.stream(other):
         y1 = quick_kernels.gemm_forward_cuda_quick(xd, *ref, 8)
-        assert ent.done and other.cuda_stream in ent.seen
+        assert ent.done and (other.stream_id, other.cuda_stream) in ent.seen   # (torch's id AND the raw handle: handles are recycled)
         seen = set(ent.seen)
         y2 = quick_kernels.gemm_forward_cuda_quick(xd, *ref, 8)
         assert ent.seen == seen
@@ -496,6 +496,7 @@ def test_function_level_drop_in_cache_hits_from_other_streams(qa, device):
     with torch.cuda.stream(third):
         with torch.cuda.graph(g, stream=third):
             static_y = quick_kernels.gemm_forward_cuda_quick(static_x, *ref, 8)
+    assert (third.stream_id, third.cuda_stream) in ent.seen     # the allocator knows about the capturing stream too
     static_x.copy_(xd * 2)
     g.replay()
     torch.cuda.synchronize()
@@ -635,6 +636,7 @@ def test_runs_on_current_stream_and_is_graph_capturable(qa, device):
     static_x = xd.clone()
     with torch.cuda.graph(g):
         static_y = qa.gemm_forward(static_x, *packed)
+    assert (third.stream_id, third.cuda_stream) in ent.seen     # the allocator knows about the capturing stream too
     static_x.copy_(xd * 2)
     g.replay()
     torch.cuda.synchronize()
@@ -1171,6 +1173,20 @@ XW = 5
 
 def xw(mb, pairs, s=0, poll_log2=0):
     return XW | ((mb << 4) if mb != 4 else 0) | ((1 << 12) if pairs == 1 else 0) | (s << 8) | (poll_log2 << 22)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kid", [5 | (8 << 4) | (1 << 12), 5 | (8 << 4), 5 | (1 << 12), 5 | (2 << 4)], ids=["256tok+bit12", "256tok", "bit12", "64tok"])
+def test_forced_four_wave_id_with_half_a_256_channel_tile(qa, device, kid):
+    """N % 256 == 128 under a forced four-wave id -- every output channel is written (NaN-poisoned output), whichever
+    kernel the id resolves to."""
+    M, K, N, G = 256, 1024, 384, 128
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=kid)
+    want = oracle.w4a16_forward(x, iw, s, z, G).astype(np.float32)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=device)
+    y = qa.gemm_forward(_dev(x, device), *_pack_dev(iw, s, z, device), kernel_id=kid, out=out)
+    assert not torch.isnan(y).any()
+    assert rel_err(y.cpu().numpy(), want) <= TOL
 
 
 XW_TILES = [(4, 2), (4, 1), (2, 1), (8, 2)]

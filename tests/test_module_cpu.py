@@ -294,6 +294,19 @@ def test_plan_describe_pins_the_shape_heuristics():
         plan(4, 4096, 4100)
 
 
+def test_forced_four_wave_id_checks_the_width_against_its_own_tile():
+    """XW | 8 token blocks | bit 12 means 256-channel tiles (bit 12 is ignored at 8 blocks); with N % 256 == 128 the launch
+    used to drop the last 128 channels and answer QUICK_OK.  The width is now checked against the tile the id resolves to."""
+    from quick_amd import kernels
+    XW = kernels.KERNEL_XW if hasattr(kernels, "KERNEL_XW") else 5
+    for kid in (XW | (8 << 4) | (1 << 12), XW | (8 << 4), XW):                      # 256-channel tiles
+        assert kernels.plan_describe(256, 1024, 384, 128, kernel_id=kid).startswith("tiled"), hex(kid)
+        assert kernels.plan_describe(256, 1024, 512, 128, kernel_id=kid).startswith("xw "), hex(kid)
+    for kid in (XW | (1 << 12), XW | (2 << 4)):                                      # 128-channel tiles take N = 384
+        p = kernels.plan_describe(256, 1024, 384, 128, kernel_id=kid)
+        assert p.startswith("xw ") and "channels=128" in p, (hex(kid), p)
+
+
 @pytest.mark.parametrize("K,N,G", [(96, 128, 32), (320, 256, 64), (192, 128, 96), (480, 128, 32)])
 def test_in_features_not_a_multiple_of_128_runs_on_a_zero_padded_copy(K, N, G):
     """The reference takes in_features % 32 == 0 (csrc/gemm_cuda_quick.cu:1479-1484); the MI355X weight order needs 128-k tiles.
