@@ -238,38 +238,20 @@ __global__ __launch_bounds__(WAVES * 64) void decode_rope_attention_flash_kernel
   float m = -INFINITY, l = 0.f;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float qr[8], kr[8];
-  bool roped = false;
-  int tb = wave * 4;
-  do {  // wave-uniform trip count; the first trip's requests leave before *pos is looked at
+  // [r05] Software-pipelined like the grouped-query kernel below: two register sets of UNR rows of K and of V per slot, the requests for
+  // trip t + 1 leave before trip t is consumed.  The FIRST trip's requests leave before *pos is known (rows clamped to the cache's end,
+  // rows at or behind *pos masked out of scores and value sum: their bytes may be anything); later trips clamp to *pos - 1 (re-reading
+  // one row instead of fetching rows nobody needs).
+  auto request = [&](half8_t (&kv)[UNR], half8_t (&vv)[UNR], int tb, int last) __attribute__((always_inline)) {
     const int t0 = tb + rsel;
-    half8_t kv[UNR], vv[UNR];
-    const int last = roped ? p - 1 : L - 1;   // (first trip: *pos is still on its way; later trips re-read row p - 1 instead of rows nobody needs)
 #pragma unroll
     for (int u = 0; u < UNR; ++u) kv[u] = *(const half8_t*)(kp + (size_t)min(t0 + SLOT * u, last) * D);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) vv[u] = *(const half8_t*)(vp + (size_t)min(t0 + SLOT * u, last) * D);
-    __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise hoists the wait for *pos and the cos / sin rows in front of these requests)
-    if (!roped) {  // first trip: rotate q and the new k while the cache rows are in flight
-      const half8_t cs = *(const half8_t*)(cos_t + (size_t)p * D + sub * 8), sn = *(const half8_t*)(sin_t + (size_t)p * D + sub * 8);
-      const float sign = sub < 8 ? -1.f : 1.f;  // rotate_half: dims 0..63 pair with -x[i+64], dims 64..127 with +x[i-64]
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float qj = (float)qraw[j], kj = (float)kraw[j];
-        const float qp = __shfl_xor(qj, 8), kpn = __shfl_xor(kj, 8);  // lane sub^8 of the same row slot holds the paired dims
-        qr[j] = (float)(half_t)((float)(half_t)(qj * (float)cs[j]) + (float)(half_t)(sign * qp * (float)sn[j])) * (scale * LOG2E);
-        kr[j] = (float)(half_t)((float)(half_t)(kj * (float)cs[j]) + (float)(half_t)(sign * kpn * (float)sn[j]));
-      }
-      if (threadIdx.x < 16 && h % group == 0) {  // append to the caches (position p is not used by anyone in this launch)
-        half8_t kh;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) kh[j] = (half_t)kr[j];
-        *(half8_t*)(k_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = kh;
-        *(half8_t*)(v_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = vn;
-      }
-      roped = true;
-    }
-    if (tb >= p) break;  // nothing (more) for this wave (first position: nothing in the cache yet)
-    // scores in the log2 domain (q carries scale * log2 e): UNR rows of this slot
+  };
+  // scores in the log2 domain (q carries scale * log2 e): UNR rows of this slot
+  auto consume = [&](const half8_t (&kv)[UNR], const half8_t (&vv)[UNR], int tb) __attribute__((always_inline)) {
+    const int t0 = tb + rsel;
     float d[UNR], mb = m;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -295,8 +277,47 @@ __global__ __launch_bounds__(WAVES * 64) void decode_rope_attention_flash_kernel
       }
     }
     m = mb;
-    tb += SLOT * UNR;
-  } while (tb < p);
+  };
+  half8_t kva[UNR], vva[UNR], kvb[UNR], vvb[UNR];
+  int tb = uniform(wave * 4);
+  request(kva, vva, tb, L - 1);
+  __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise hoists the wait for *pos and the cos / sin rows in front of these requests)
+  {  // rotate q and the new k while the cache rows are in flight
+    const half8_t cs = *(const half8_t*)(cos_t + (size_t)p * D + sub * 8), sn = *(const half8_t*)(sin_t + (size_t)p * D + sub * 8);
+    const float sign = sub < 8 ? -1.f : 1.f;  // rotate_half: dims 0..63 pair with -x[i+64], dims 64..127 with +x[i-64]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float qj = (float)qraw[j], kj = (float)kraw[j];
+      const float qp = __shfl_xor(qj, 8), kpn = __shfl_xor(kj, 8);  // lane sub^8 of the same row slot holds the paired dims
+      qr[j] = (float)(half_t)((float)(half_t)(qj * (float)cs[j]) + (float)(half_t)(sign * qp * (float)sn[j])) * (scale * LOG2E);
+      kr[j] = (float)(half_t)((float)(half_t)(kj * (float)cs[j]) + (float)(half_t)(sign * kpn * (float)sn[j]));
+    }
+    if (threadIdx.x < 16 && h % group == 0) {  // append to the caches (position p is not used by anyone in this launch)
+      half8_t kh;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kh[j] = (half_t)kr[j];
+      *(half8_t*)(k_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = kh;
+      *(half8_t*)(v_cache + (((size_t)b * nkv + kvh) * L + p) * D + sub * 8) = vn;
+    }
+  }
+  if (tb < p) {  // (else: nothing for this wave -- first position: nothing in the cache yet)
+    constexpr int STEP = SLOT * UNR;
+    // (Requests behind a wave-uniform guard: hipcc's s_waitcnt pass then assumes the smaller in-flight count and waits for part of the
+    // set just requested in front of the value sum of the set in hand.  The unconditional form -- clamped rows past the sequence -- counts
+    // exactly, but the same construction in the skinny GEMM kernel's chunk loop produced wrong results that -amdgpu-waitcnt-forcezero
+    // cured: this loop stays with the form the parity tests have seen.)
+    while (true) {  // wave-uniform trip counts
+      const bool more_b = tb + STEP < p;
+      if (more_b) request(kvb, vvb, tb + STEP, p - 1);
+      consume(kva, vva, tb);
+      if (!more_b) break;
+      const bool more_a = tb + 2 * STEP < p;
+      if (more_a) request(kva, vva, tb + 2 * STEP, p - 1);
+      consume(kvb, vvb, tb + STEP);
+      if (!more_a) break;
+      tb += 2 * STEP;
+    }
+  }
   if (wave == 0 && rsel == 0) {  // this token (row p), from registers
     float x = 0.f;
 #pragma unroll
@@ -514,6 +535,214 @@ __global__ __launch_bounds__(256, 2) void decode_rope_attention_gqa_kernel(
   for (int i = threadIdx.x; i < GROUP * D; i += 256) {
     const int g = i / D, dd = i % D;
     const float M = fmaxf(fmaxf(part[0][g][D], part[1][g][D]), fmaxf(part[2][g][D], part[3][g][D]));  // finite: row p
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = exp2f(part[w][g][D] - M);
+      num += part[w][g][dd] * f;
+      den += part[w][g][D + 1] * f;
+    }
+    out[((size_t)b * nh + hbase + g) * D + dd] = (half_t)(num / den);
+  }
+}
+
+// [r05] Grouped-query sweep with the SCORES on the matrix core.  The kernel above spends its time in the vector ALUs (18 us per launch at
+// bs = 64, 8 KV heads, ~190 positions: 50 MB at 2.8 TB/s): per cache row and lane 8 conversions + 8 FMAs per head + a 16-lane sum per
+// head for the score alone.  Here a wave takes 16 cache rows at a time as the A operand of v_mfma_f32_16x16x32_f16 (row = lane % 16,
+// dims 32 s + 8 (lane / 16) .. + 7 of k step s: four 16-byte requests per lane, 64 contiguous bytes of a row per request) and the
+// rotated query heads as the B operand (head = lane % 16, zero beyond GROUP; the same dims): four MFMAs give the 16 x GROUP scores with no
+// conversion, no FMA and no cross-lane sum.  Lane (head, row quarter) then holds the scores of rows 4 (lane / 16) + i of the chunk: the
+// running max / sum of a head live in ONE lane per row quarter and the softmax arithmetic of all heads runs in parallel across the
+// lanes.  The value sum stays on the vector ALUs (V rows in memory have the dims contiguous, the matrix core would want the positions):
+// lane (dims 8 (lane % 16) .., row quarter) requests rows 4 (lane / 16) + i, so that the probabilities it needs sit in its own
+// 16-lane row -- one DPP row broadcast (row_newbcast) per (row, head) delivers them.  Row *pos -- this token -- is part of the sweep:
+// the lanes that would request it take the rotated k and the new v from registers instead (rows behind it are masked).  Software-
+// pipelined like the kernels above (two register sets of UC 16-row chunks per wave).  Rounding: scores are sums of exact fp16 x fp16
+// products in fp32 (as before, in another order), scale * log2 e is applied to the fp32 score.
+__device__ __forceinline__ float row_bcast(float x, int g) {   // the value of lane g of each 16-lane row, to all 16 (g: a constant after unrolling)
+#define QA_BC(G) case G: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + G, 0xf, 0xf, false));
+  switch (g) {
+    QA_BC(0) QA_BC(1) QA_BC(2) QA_BC(3) QA_BC(4) QA_BC(5) QA_BC(6) QA_BC(7)
+    default: return x;
+  }
+#undef QA_BC
+}
+
+template <int GROUP, int UC>
+__global__ __launch_bounds__(256, 2) void decode_rope_attention_gqa_mfma_kernel(
+    const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t, const half_t* __restrict__ sin_t,
+    const long* __restrict__ pos, half_t* __restrict__ k_cache, half_t* __restrict__ v_cache, half_t* __restrict__ out,
+    int nh, int nkv, int L, float scale) {
+  constexpr int D = 128;
+  static_assert(GROUP >= 1 && GROUP <= 8, "query heads per KV head");
+  __shared__ float part[4][GROUP][D + 2];  // per wave and query head: 128 output dims, running max, running sum
+  const int b = blockIdx.y, kvh = blockIdx.x, hbase = kvh * GROUP;
+  const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));
+  const int sub = lane & 15, rsel = lane >> 4;
+  const half_t* row = qkv + (size_t)b * (nh + 2 * nkv) * D;
+  half_t* krow = k_cache + ((size_t)b * nkv + kvh) * L * D;
+  half_t* vrow = v_cache + ((size_t)b * nkv + kvh) * L * D;
+  const half_t* kp = krow + rsel * 8;   // + row * D + 32 s
+  const half_t* vp = vrow + sub * 8;    // + row * D
+  half8_t qraw[4], kraw[4];
+  const int hq = min(sub, GROUP - 1);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qraw[s] = *(const half8_t*)(row + (size_t)(hbase + hq) * D + 32 * s + 8 * rsel);
+    kraw[s] = *(const half8_t*)(row + (size_t)(nh + kvh) * D + 32 * s + 8 * rsel);
+  }
+  const half8_t vn = *(const half8_t*)(row + (size_t)(nh + nkv + kvh) * D + sub * 8);
+
+  auto request = [&](half8_t (&ka)[UC][4], half8_t (&va)[UC][4], int tb, int last) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < UC; ++c)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ka[c][s] = *(const half8_t*)(kp + (size_t)min(tb + 64 * c + sub, last) * D + 32 * s);
+#pragma unroll
+    for (int c = 0; c < UC; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) va[c][i] = *(const half8_t*)(vp + (size_t)min(tb + 64 * c + 4 * rsel + i, last) * D);
+  };
+  half8_t kva[UC][4], vva[UC][4], kvb[UC][4], vvb[UC][4];
+  constexpr int STEP = 64 * UC;
+  int tb = wave * 16;   // first row of this wave's first chunk; a trip of the workgroup covers 64 UC rows
+  const int p = (int)pos[0];  // cache rows 0..p-1 come from memory, row p (this token) from registers
+  const int plast = max(p - 1, 0);
+  // (requesting the first two sets before *pos is known -- rows clamped to the cache's end, masked afterwards -- measured no faster:
+  // 16.4 against 15.2 us at bs = 64, 8 KV heads, 192 positions on two boxes, the same ratio to the vector-ALU sweep within 4 %)
+  request(kva, vva, tb, plast);
+
+  // rotate the q heads and the new k (dims 32 s + 8 rsel + j pair with the same j of k step s ^ 2) while the first rows are in flight
+  half8_t qb[4], kh[4];
+  {
+    half8_t cs[4], sn[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      cs[s] = *(const half8_t*)(cos_t + (size_t)p * D + 32 * s + 8 * rsel);
+      sn[s] = *(const half8_t*)(sin_t + (size_t)p * D + 32 * s + 8 * rsel);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float sign = s < 2 ? -1.f : 1.f;  // rotate_half: dims 0..63 pair with -x[i+64], dims 64..127 with +x[i-64]
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float c = (float)cs[s][j], sj = (float)sn[s][j];
+        qb[s][j] = sub < GROUP ? (half_t)((float)(half_t)((float)qraw[s][j] * c) + (float)(half_t)(sign * (float)qraw[s ^ 2][j] * sj)) : (half_t)0.f;
+        kh[s][j] = (half_t)((float)(half_t)((float)kraw[s][j] * c) + (float)(half_t)(sign * (float)kraw[s ^ 2][j] * sj));
+      }
+    }
+    if (wave == 0 && sub == 0) {  // append to the caches (position p is not requested by anyone in this launch)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) *(half8_t*)(krow + (size_t)p * D + 32 * s + 8 * rsel) = kh[s];
+    }
+    if (wave == 0 && rsel == 0) *(half8_t*)(vrow + (size_t)p * D + sub * 8) = vn;
+  }
+
+  const float qk_scale = scale * 1.44269504088896f;   // scores in the log2 domain
+  float m_ = -INFINITY, l_ = 0.f;   // lane (head sub, row quarter rsel): running max / sum of that head over this quarter's rows
+  float acc[GROUP][8];
+#pragma unroll
+  for (int g = 0; g < GROUP; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+
+  auto consume = [&](half8_t (&ka)[UC][4], half8_t (&va)[UC][4], int tb) __attribute__((always_inline)) {
+    float sc[UC][4], mb = m_;
+#pragma unroll
+    for (int c = 0; c < UC; ++c) {
+      const int base = tb + 64 * c;
+      if (base <= p && p < base + 16) {  // (wave-uniform) this chunk holds row p: from registers
+        if (base + sub == p) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) ka[c][s] = kh[s];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (base + 4 * rsel + i == p) va[c][i] = vn;
+      }
+      floatx4 d4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) d4 = mfma16(ka[c][s], qb[s], d4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        sc[c][i] = base + 4 * rsel + i <= p ? d4[i] * qk_scale : -INFINITY;
+        mb = fmaxf(mb, sc[c][i]);
+      }
+    }
+    const float mref = mb == -INFINITY ? 0.f : mb;
+    const float corr = exp2f(m_ - mref);
+    l_ *= corr;
+#pragma unroll
+    for (int c = 0; c < UC; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        sc[c][i] = exp2f(sc[c][i] - mref);   // (0 for a masked row)
+        l_ += sc[c][i];
+      }
+    m_ = mb;
+#pragma unroll
+    for (int g = 0; g < GROUP; ++g) {
+      const float cg = row_bcast(corr, g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[g][j] *= cg;
+    }
+#pragma unroll
+    for (int c = 0; c < UC; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float pg[GROUP];
+#pragma unroll
+        for (int g = 0; g < GROUP; ++g) pg[g] = row_bcast(sc[c][i], g);   // (DPP: every lane takes part, also for masked rows)
+        if (tb + 64 * c + 4 * rsel + i <= p) {  // (a row behind the sequence holds anything, NaN included: 0 * NaN would poison the sum)
+          float vf[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vf[j] = (float)va[c][i][j];
+#pragma unroll
+          for (int g = 0; g < GROUP; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[g][j] += pg[g] * vf[j];
+        }
+      }
+  };
+  if (tb <= p) {
+    while (true) {  // wave-uniform trip counts; the requests for the next set leave before this one is consumed
+      const bool more_b = tb + STEP <= p;
+      if (more_b) request(kvb, vvb, tb + STEP, plast);
+      consume(kva, vva, tb);
+      if (!more_b) break;
+      const bool more_a = tb + 2 * STEP <= p;
+      if (more_a) request(kva, vva, tb + 2 * STEP, plast);
+      consume(kvb, vvb, tb + STEP);
+      if (!more_a) break;
+      tb += 2 * STEP;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < GROUP; ++g) {
+    const float mg = row_bcast(m_, g), lg = row_bcast(l_, g);   // this row quarter's state of head g, in all of its 16 lanes
+    // merge the 4 row quarters of the wave, then the 4 waves through LDS
+    float mw = fmaxf(mg, __shfl_xor(mg, 16));
+    mw = fmaxf(mw, __shfl_xor(mw, 32));
+    const float sc_ = exp2f(mg - (mw == -INFINITY ? 0.f : mw));
+    float lw = lg * sc_;
+    lw += __shfl_xor(lw, 16);
+    lw += __shfl_xor(lw, 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = acc[g][j] * sc_;
+      a += __shfl_xor(a, 16);
+      a += __shfl_xor(a, 32);
+      if (rsel == 0) part[wave][g][sub * 8 + j] = a;
+    }
+    if (lane == 0) {
+      part[wave][g][D] = mw;
+      part[wave][g][D + 1] = lw;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < GROUP * D; i += 256) {
+    const int g = i / D, dd = i % D;
+    const float M = fmaxf(fmaxf(part[0][g][D], part[1][g][D]), fmaxf(part[2][g][D], part[3][g][D]));  // finite: row p is in somebody's sweep
     float num = 0.f, den = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -773,12 +1002,23 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
     bool done = true;
     // (four rows per slot and register set: 244 registers with four heads, two waves per SIMD; eight rows spill)
 #define QA_GQA_U(GROUP, GSPLIT) QA_GQA(GROUP, 4, GSPLIT)
-    if (group == 8 && pairs * 2 >= 256) QA_GQA_U(4, 2);
+    static const int mfma_on = [] {   // (A/B: QUICK_AMD_ATTN_MFMA=0 runs the vector-ALU sweeps)
+      const char* e = getenv("QUICK_AMD_ATTN_MFMA");
+      return e ? atoi(e) : 1;
+    }();
+#define QA_GQA_M(GROUP, UC)                                                                                          \
+  hipLaunchKernelGGL((decode_rope_attention_gqa_mfma_kernel<GROUP, UC>), dim3(n_kv_heads, batch), dim3(256), 0,        \
+                     (hipStream_t)hip_stream, (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, \
+                     (const long*)pos, (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads, cache_len, scale)
+    if (mfma_on && group == 8 && pairs >= 256) QA_GQA_M(8, 1);
+    else if (mfma_on && group == 4 && pairs >= 256) QA_GQA_M(4, 1);   // (two chunks per set: 256 registers and a spill, 5-10 % behind)
+    else if (group == 8 && pairs * 2 >= 256) QA_GQA_U(4, 2);
     else if (group == 4 && pairs >= 256) QA_GQA_U(4, 1);
     else if (group == 4 && pairs * 2 >= 256) QA_GQA_U(2, 2);  // fewer sequences: two workgroups of 2 heads per KV head
     else if (group == 2 && pairs >= 256) QA_GQA_U(2, 1);
     else done = false;
 #undef QA_GQA_U
+#undef QA_GQA_M
     if (done) return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
   }
 #undef QA_GQA
@@ -794,8 +1034,8 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
     return e ? atoi(e) : 0;
   }();
   const int pick = forced ? forced : (((long)n_heads * batch <= 128 && cache_len > 128) ? 8 : 4);
-  if (pick == 8) QA_FLASH(8, 8);
-  else QA_FLASH(4, 8);
+  if (pick == 8) QA_FLASH(8, 4);   // (two register sets of 4 rows per slot: the same 256 / 128 positions in flight as one set of 8)
+  else QA_FLASH(4, 4);
 #undef QA_FLASH
   return hipGetLastError() == hipSuccess ? QUICK_OK : QUICK_ERR_LAUNCH;
 }

@@ -487,6 +487,14 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     const u32x4 bc_bits = (lane & 1) ? u32x4{0x64006400u, 0x54005400u, 0x64006400u, 0x54005400u}
                                      : u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
     const half8_t bconst = __builtin_bit_cast(half8_t, bc_bits);
+    // [r05, profiles/r05_skinny_variants.txt -- read before touching this loop]  Behind the GUARDED requests below hipcc's s_waitcnt pass
+    // assumes the smaller in-flight count: the ISA waits vmcnt(3..0) in front of the first MFMAs of the chunk in hand, i.e. the chunk just
+    // requested is drained too.  Issuing them unconditionally (replays past the wave's range) gives counted waits (vmcnt(15..12)) and
+    // 3-7 % at 6..16 tokens -- and WRONG results in the four-tile instantiation (tile 0 of every block), as did an eight-tile
+    // instantiation of this guarded form (tile 2, varying from run to run; 62 -> 54 us at 16 x 8192 x 57344, its x fragments being half
+    // the weights' bytes instead of as many).  Both are cured by -mllvm -amdgpu-waitcnt-forcezero: the wait counts hipcc derives for
+    // requests whose results die on the loop's way out cannot be trusted here.  Neither is shipped; the instantiations that are have
+    // been through the parity suite in this exact form since r01.
     if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS, LN, NT>(cA, kt_begin, kt_end - 1, bufs, cb, xp, a, gp);
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
