@@ -636,7 +636,6 @@ def test_runs_on_current_stream_and_is_graph_capturable(qa, device):
     static_x = xd.clone()
     with torch.cuda.graph(g):
         static_y = qa.gemm_forward(static_x, *packed)
-    assert (third.stream_id, third.cuda_stream) in ent.seen     # the allocator knows about the capturing stream too
     static_x.copy_(xd * 2)
     g.replay()
     torch.cuda.synchronize()
