@@ -229,7 +229,11 @@ int quick_rope_kv_write_f16(const void* qkv, const void* cos_table, const void* 
 int quick_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* pos, void* out,
                                int batch, int n_heads, int n_kv_heads, int head_dim, int cache_len, float scale,
                                void* hip_stream);
-/* quick_rope_kv_append_f16 + quick_decode_attention_f16 in one launch, reading the qkv GEMM output directly */
+/* quick_rope_kv_append_f16 + quick_decode_attention_f16 in one launch, reading the qkv GEMM output directly.  One online-softmax sweep
+ * over the cache, software-pipelined (r05); rows at or behind *pos may hold anything (they are never read into a sum).  Grouped-query
+ * models with >= 256 (sequence, KV head) pairs and 4 or 8 query heads per KV head take their scores from the matrix core
+ * (v_mfma_f32_16x16x32_f16 on 16 cache rows x the heads of the group); QUICK_AMD_ATTN_MFMA=0 keeps the vector-ALU sweep (A/B switch,
+ * same results within fp32 summation order). */
 int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, const void* sin_table, const void* pos,
                                     void* k_cache, void* v_cache, void* out, int batch, int n_heads, int n_kv_heads,
                                     int head_dim, int cache_len, float scale, void* hip_stream);

@@ -1010,6 +1010,8 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
   hipLaunchKernelGGL((decode_rope_attention_gqa_mfma_kernel<GROUP, UC>), dim3(n_kv_heads, batch), dim3(256), 0,        \
                      (hipStream_t)hip_stream, (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, \
                      (const long*)pos, (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads, cache_len, scale)
+    // (8 heads per KV head from 128 pairs -- Llama-2-70B at bs = 16, one workgroup per pair on half the CUs -- measured 1 % BEHIND the two
+    // vector-ALU sweeps of 4 heads, profiles/r05_decode70_ab.txt)
     if (mfma_on && group == 8 && pairs >= 256) QA_GQA_M(8, 1);
     else if (mfma_on && group == 4 && pairs >= 256) QA_GQA_M(4, 1);   // (two chunks per set: 256 registers and a spill, 5-10 % behind)
     else if (group == 8 && pairs * 2 >= 256) QA_GQA_U(4, 2);

@@ -2469,7 +2469,17 @@ int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size) {
   // second pass over LDS, not a launch
   const Plan p = make_plan(M, K, N, group_size, QUICK_KERNEL_AUTO, 0);
   if (p.kernel == QUICK_KERNEL_LEAN) return p.lean_tmax > 0;   // x * weight in LDS on the way in, 1 / rms on the fp32 result
-  return p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8));
+  if (!(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8)))) return 0;
+  // The fragment flavour pays for the norm in registers (188 against 134, the weight multiply and the squares on every x fragment of every
+  // channel block): on a very large layer that is more than a separate launch of quick_rmsnorm_f16.  Llama-2-70B at bs = 16, one-session
+  // A/B (profiles/r05_decode70_ab.txt): gate_up (8192 x 57344) un-fused 1412 -> 1456 tok/s, every fragment launch un-fused 1426; Mistral-7B's
+  // 4096 x 28672 at bs = 32 LOSES 2 % un-fused.  So: fused up to K * N = 2^28.  QUICK_AMD_LN_FRAGMENT_MAX overrides the bound (A/B; 0 = never fuse).
+  static const long ln_fragment_max = [] {
+    const char* e = getenv("QUICK_AMD_LN_FRAGMENT_MAX");
+    return e && *e ? atol(e) : (1L << 28);
+  }();
+  if (!p.xlds && (long)K * N > ln_fragment_max) return 0;
+  return 1;
 }
 
 int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, int grid_split_k, char* text, size_t text_bytes) {

@@ -294,6 +294,15 @@ def test_plan_describe_pins_the_shape_heuristics():
         plan(4, 4096, 4100)
 
 
+def test_rmsnorm_prologue_is_not_fused_on_very_large_fragment_layers():
+    """r05: the fragment flavour of the skinny kernel carries the norm in registers; above K * N = 2^28 (Llama-2-70B's gate_up at 9..16 tokens)
+    a separate RMSNorm launch is faster (profiles/r05_decode70_ab.txt), so can_fuse_rmsnorm answers no there and yes below."""
+    from quick_amd import kernels
+    assert "deferred-zero-fragment" in kernels.plan_describe(16, 8192, 57344, 128) and not kernels.can_fuse_rmsnorm(16, 8192, 57344, 128)
+    assert "deferred-zero-fragment" in kernels.plan_describe(16, 8192, 10240, 128) and kernels.can_fuse_rmsnorm(16, 8192, 10240, 128)
+    assert kernels.can_fuse_rmsnorm(8, 8192, 57344, 128) and kernels.can_fuse_rmsnorm(1, 8192, 57344, 128)      # table flavour / lean: x in LDS
+
+
 def test_forced_four_wave_id_checks_the_width_against_its_own_tile():
     """XW | 8 token blocks | bit 12 means 256-channel tiles (bit 12 is ignored at 8 blocks); with N % 256 == 128 the launch
     used to drop the last 128 channels and answer QUICK_OK.  The width is now checked against the tile the id resolves to."""
