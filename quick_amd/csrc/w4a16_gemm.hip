@@ -1283,6 +1283,7 @@ struct Plan {
   int xk_kq;           // exchange-K: K groups of waves per workgroup, 2 (eight waves) or 4 (sixteen; kernel bit 13)
   int poll_log2;       // XW: log2 of the ticks (10 ns) a wave waits for a partner slice before it gives its block up (0 = the kernel's default)
   int lean_tmax;       // LEAN: the most k tiles a wave may own (the build's register ring), 0 = no build for this shape
+  int frag8_t;         // SKINNY, mt == 8: k tiles per wave of the straight-line eight-tile fragment kernel (w4a16_frag8_kernel), 0 = not that kernel
   double est_us, est_xw_us;  // launch-time model: the r02 / r03 candidates' minimum, the four-wave kernels' minimum (0 = not evaluated)
 };
 
@@ -1307,6 +1308,48 @@ static int check_shapes(int M, int K, int N, int G) {
 
 static constexpr size_t kLdsPerCu = 160 * 1024;  // gfx950
 static thread_local bool g_span_unsupported = false;  // set by a launcher asked for span stamps its kernel does not carry
+
+// [r05] EIGHT channel tiles per workgroup in the fragment deferred-zero flavour, as STRAIGHT-LINE code: 9..16 tokens on layers whose x (16 x K
+// fp16) does not fit LDS (K >= 8192: Llama-2-70B).  Why eight: a CU sustains ~48 KB of vector-memory requests in flight whatever their target,
+// and the x fragments of this flavour come from L2 once per workgroup and k tile -- as many bytes as the weights at four tiles, half as many at
+// eight (16 x 8192 x 57344: 62 -> 54 us).  Why straight-line: the chunk loop of w4a16_skinny_kernel instantiated for eight tiles gave wrong
+// results that -amdgpu-waitcnt-forcezero cured (hipcc's wait counts around guarded / replayed requests in a loop).  Here
+// every wave owns EXACTLY T k tiles (the planner only picks the kernel when K / 128 == 8 waves x ksplit x T), every request is unconditional,
+// nothing is replayed and no request's result dies unread: the form in which hipcc's counts are exact (as in the lean kernels).
+template <int T, bool NT>
+__global__ __launch_bounds__(512) void w4a16_frag8_kernel(const GemmArgs a) {
+  constexpr int NTW = 8, WAVES = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  floatx4* red = (floatx4*)smem;  // [WAVES][NTW][64]
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(threadIdx.x >> 6);
+  const int n16 = lane & 15, q = lane >> 4;
+  const int mb = blockIdx.y, ks = blockIdx.z;
+  const int nblocks = a.N / (16 * NTW);
+  const int gx = (int)gridDim.x;
+  const int bx = (gx & 7) == 0 ? ((int)blockIdx.x & 7) * (gx >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;   // XCD-aware block order (skinny kernel)
+  const int kt_begin = (ks * WAVES + wave) * T;   // a.kt_per_split == WAVES * T
+  const SkinnyBufs bufs = skinny_bufs(a, lane);
+  const int row = min(mb * 16 + n16, a.M - 1);  // rows >= M replay row M-1; never stored
+  const half_t* xp = a.X + (size_t)row * a.K + q * 8;
+  floatx4 acc[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 bc_bits = (lane & 1) ? u32x4{0x64006400u, 0x54005400u, 0x64006400u, 0x54005400u}
+                                   : u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+  const half8_t bconst = __builtin_bit_cast(half8_t, bc_bits);
+  const int cb = bx * NTW;
+  const int kt_far = a.K >> 7;   // (no clamp ever bites: every k tile asked for is this wave's own)
+  SkinnyChunk<NTW, 0, 1, false, false> c[2];
+  skinny_load<NTW, 0, 1, false, false, NT>(c[0], kt_begin, kt_far, bufs, cb, xp, a);
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    if (i + 1 < T) skinny_load<NTW, 0, 1, false, false, NT>(c[(i + 1) & 1], kt_begin + i + 1, kt_far, bufs, cb, xp, a);   // (compile-time condition)
+    __builtin_amdgcn_sched_barrier(0);
+    skinny_compute_dzf<NTW, 0, 1, false>(c[i & 1], 0, 1, bconst, (lane & 1) != 0, acc);   // (kt = 0 < kt_end = 1: the k tile is always this wave's)
+  }
+  skinny_finish<NTW, WAVES, true, false>(a, acc, red, smem, bx, nblocks, mb, ks, lane, wave);
+}
 
 // LDS of one skinny workgroup: reduction buffer(s), the x copy, the deferred-zero table
 static size_t skinny_lds_bytes(int M, int G, int ntw, int waves, int kt_per_split, bool persistent, bool xlds, bool dz) {
@@ -2010,6 +2053,46 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         p.grid_x = (nblocks + rounds - 1) / rounds;
       }
     }
+    // [r05] 9..16 tokens where the four-tile fragment flavour runs and K / 128 splits into 8 waves x ksplit x T whole k tiles, T in {2, 4, 7, 8}:
+    // eight tiles per workgroup, straight-line (w4a16_frag8_kernel).  ksplit = the smallest of 1, 2, 4 that gives >= 256 workgroups.
+    // Forced by kernel id (SKINNY, 8 channel tiles); AUTO takes it where QUICK_AMD_FRAG8 says (default below).
+    {
+      static const int frag8_env = [] {
+        const char* e = getenv("QUICK_AMD_FRAG8");
+        return e ? atoi(e) : 1;
+      }();
+      const bool asked = family == QUICK_KERNEL_SKINNY && mt_req == 8;
+      const bool auto_ok = frag8_env != 0 && family == QUICK_KERNEL_AUTO && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k == 0 && p.mt == 4 && p.dz &&
+                           !p.xlds && (long)K * N >= 60L * 1000 * 1000;
+      if ((asked || auto_ok) && G == 128 && M >= 9 && M <= 16 && N % 128 == 0 && KT % 8 == 0 && (long)M * K * 2 < (1L << 31)) {
+        int best_ks = 0, best_t = 0;
+        for (int s2 = 1; s2 <= 4; s2 *= 2) {   // the forced slice count, else the first that gives >= 256 workgroups, else the last one that fits
+          if (grid_split_k > 0 && s2 != grid_split_k) continue;
+          if ((KT / 8) % s2 != 0) continue;
+          const int t = KT / 8 / s2;
+          if (t != 2 && t != 4 && t != 7 && t != 8) continue;
+          best_ks = s2;
+          best_t = t;
+          if ((N / 128) * s2 >= 256) break;
+        }
+        // (AUTO only where measured ahead: 8192 x 57344 one slice 62 -> 54 us, 28672 x 8192 four slices 29.5 -> 27.9, 8192 x 8192 four slices
+        // 12.9 -> 11.9; 8192 x 10240 -- 80 blocks -- two slices 17.2 against 15.3: stays with four tiles)
+        if (best_ks && !asked && (N / 128) * best_ks < 256) best_ks = 0;
+        if (best_ks && !asked && (N / 128) % 64 != 0) best_ks = 0;
+        if (best_ks) {
+          p.mt = 8;
+          p.waves = 8;
+          p.dz = true;
+          p.xlds = false;
+          p.frag8_t = best_t;
+          p.ksplit = best_ks;
+          p.kt_per_split = 8 * best_t;
+          p.grid_x = N / 128;
+          p.ntiles = (N / 128) * ((M + 15) / 16);
+          p.slab_floats = (size_t)8 * 256;
+        }
+      }
+    }
   }
   return p;
 }
@@ -2311,7 +2394,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   const Plan p = plan_for(M, K, N, G, kernel, grid_split_k, f.silu_mul != 0);
   if (f.silu_mul && (f.bias || f.residual)) return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual");
   if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
-  if (f.ln_w && p.kernel != QUICK_KERNEL_LEAN && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8))))
+  if (f.ln_w && p.kernel != QUICK_KERNEL_LEAN && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && !p.frag8_t && (p.xlds || (p.mt >= 2 && p.waves == 8))))
     return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
              (const half_t*)f.residual, f.silu_mul, (half_t*)y, nullptr, nullptr, M, K, N, G, std::max(1, G / 128), p.ksplit, p.kt_per_split, p.xcd_gm, nullptr, (const half_t*)f.ln_w, f.ln_eps};
@@ -2399,6 +2482,27 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     switch (p.mt) {
       case 1: launch_skinny<1>(p, a, L); break;
       case 2: launch_skinny<2>(p, a, L); break;
+      case 8: {
+        if (!p.frag8_t || f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "skinny: eight channel tiles per workgroup only in the straight-line fragment kernel, no RMSNorm prologue");
+        if (a.span) { g_span_unsupported = true; break; }
+        dim3 grid(p.grid_x, (M + 15) / 16, p.ksplit), block(512);
+        const unsigned lds = 8 * 8 * 1024;
+#define QA_FRAG8(TV)                                                                                               \
+  do {                                                                                                             \
+    auto kfn = w4a16_frag8_kernel<TV, true>;                                                                       \
+    static std::atomic<unsigned long long> attr_set{0};                                                            \
+    (void)lds_limit_once(attr_set, (const void*)kfn, (int)kLdsPerCu);                                              \
+    hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
+  } while (0)
+        switch (p.frag8_t) {
+          case 2: QA_FRAG8(2); break;
+          case 4: QA_FRAG8(4); break;
+          case 7: QA_FRAG8(7); break;
+          default: QA_FRAG8(8); break;
+        }
+#undef QA_FRAG8
+        break;
+      }
       default: launch_skinny<4>(p, a, L); break;
     }
   } else {
@@ -2469,7 +2573,7 @@ int quick_w4a16_can_fuse_rmsnorm(int M, int K, int N, int group_size) {
   // second pass over LDS, not a launch
   const Plan p = make_plan(M, K, N, group_size, QUICK_KERNEL_AUTO, 0);
   if (p.kernel == QUICK_KERNEL_LEAN) return p.lean_tmax > 0;   // x * weight in LDS on the way in, 1 / rms on the fp32 result
-  if (!(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && (p.xlds || (p.mt >= 2 && p.waves == 8)))) return 0;
+  if (!(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && !p.frag8_t && (p.xlds || (p.mt >= 2 && p.waves == 8)))) return 0;
   // The fragment flavour pays for the norm in registers (188 against 134, the weight multiply and the squares on every x fragment of every
   // channel block): on a very large layer that is more than a separate launch of quick_rmsnorm_f16.  Llama-2-70B at bs = 16, one-session
   // A/B (profiles/r05_decode70_ab.txt): gate_up (8192 x 57344) un-fused 1412 -> 1456 tok/s, every fragment launch un-fused 1426; Mistral-7B's

@@ -1188,6 +1188,44 @@ def test_forced_four_wave_id_with_half_a_256_channel_tile(qa, device, kid):
     assert rel_err(y.cpu().numpy(), want) <= TOL
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [9, 13, 16])
+@pytest.mark.parametrize("K,N,ks", [(8192, 1024, 1), (8192, 1024, 2), (8192, 512, 4), (4096, 2048, 1), (4096, 1024, 2), (2048, 1024, 1), (7168, 1024, 1), (28672, 256, 4)],
+                         ids=["T8", "T4x2", "T2x4", "T4", "T2x2", "T2", "T7", "T7x4"])
+def test_eight_tile_fragment_kernel_against_oracle(qa, device, M, K, N, ks):
+    """[r05] w4a16_frag8_kernel -- eight channel tiles per workgroup, straight-line, every wave exactly T k tiles -- forced by kernel id
+    (SKINNY, 8 tiles) over every T it is built for and 1 / 2 / 4 K slices: against the oracle into a NaN-poisoned output, three times
+    (the loop form of this instantiation failed from run to run), with bias + residual (fp32 adds, one rounding, as the four-tile kernel), and SiLU * mul."""
+    from quick_amd import kernels as K_
+    kid = K_.KERNEL_SKINNY | (8 << 4)
+    plan = K_.plan_describe(M, K, N, 128, kid, ks)
+    assert plan.startswith("skinny ntw=8 ") and f"ksplit={ks}" in plan, plan
+    x, iw, s, z = oracle.make_synthetic(M, K, N, 128, seed=M + K + N + ks)
+    want = oracle.w4a16_forward(x, iw, s, z, 128).astype(np.float32)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device)
+    ys = []
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=device)
+        ys.append(qa.gemm_forward(xd, *packed, kernel_id=kid, grid_split_k=ks, out=out))
+        assert rel_err(ys[-1].cpu().numpy(), want) <= TOL, plan
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2]), plan
+    y4 = qa.gemm_forward(xd, *packed, kernel_id=K_.KERNEL_SKINNY | (4 << 4) | (2 << 8))
+    assert rel_err(ys[0].cpu().numpy(), y4.float().cpu().numpy()) <= 1e-3
+    bias = torch.linspace(-1, 1, N, device=device).half()
+    res = torch.randn(M, N, device=device).half()
+    yb = qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=kid, grid_split_k=ks)   # (fp32 adds, one rounding: skinny_finish)
+    assert rel_err(yb.cpu().numpy(), want + bias.float().cpu().numpy() + res.float().cpu().numpy()) <= TOL, plan
+    assert torch.equal(yb, qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=K_.KERNEL_SKINNY | (4 << 4) | (2 << 8), grid_split_k=ks)) or \
+        rel_err(yb.cpu().numpy(), qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=K_.KERNEL_SKINNY | (4 << 4) | (2 << 8)).float().cpu().numpy()) <= 1e-3
+    ysm = qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kid, grid_split_k=ks)
+    yf = ys[0].float().view(M, N // 16, 2, 8)
+    ref = (torch.nn.functional.silu(yf[:, :, 0].half().float()).half().float() * yf[:, :, 1]).half().view(M, N // 2)
+    assert (ysm.float() - ref.float()).abs().max() <= 2e-3 * ref.float().abs().max() + 1e-3, plan
+    with pytest.raises(NotImplementedError):
+        qa.gemm_forward(xd, *packed, kernel_id=kid, grid_split_k=ks, rmsnorm_weight=torch.ones(K, dtype=torch.float16, device=device))
+
+
 XW_TILES = [(4, 2), (4, 1), (2, 1), (8, 2)]
 XW_IDS = ["128x256", "128x128", "64x128", "256x256"]
 

@@ -255,7 +255,12 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(16, 4096, 6144, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=2") and "deferred-zero-fragment" in plan(16, 4096, 6144, kernel_id=kernels.KERNEL_SKINNY)    # 384 blocks: one round of 192
     assert plan(6, 8192, 8192, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=2") and plan(4, 28672, 8192).startswith("skinny ntw=4")
     assert "deferred-zero-table" in plan(12, 4096, 22016, kernel_id=kernels.KERNEL_SKINNY) and plan(16, 4096, 22016, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4")
-    assert plan(16, 8192, 57344).startswith("skinny ntw=4")
+    # [r05] 9..16 tokens on the Llama-2-70B layers: the straight-line eight-tile fragment kernel where K / 128 = 8 waves x slices x {2, 4, 7, 8} and the
+    # blocks come in multiples of 64 (measured ahead there); 80 blocks (the fused qkv) stay with four tiles
+    assert plan(16, 8192, 57344).startswith("skinny ntw=8") and "grid=448x1x1 ksplit=1" in plan(16, 8192, 57344)
+    assert plan(16, 28672, 8192).startswith("skinny ntw=8") and "grid=64x1x4 ksplit=4" in plan(16, 28672, 8192)
+    assert plan(16, 8192, 8192).startswith("skinny ntw=8") and "ksplit=4" in plan(16, 8192, 8192) and plan(9, 8192, 57344).startswith("skinny ntw=8")
+    assert plan(16, 8192, 10240).startswith("skinny ntw=4") and plan(8, 8192, 57344).startswith("skinny ntw=1") and not plan(17, 8192, 57344).startswith("skinny ntw=8")
     # r03 audit: from five tokens no LDS copy of x outside the table flavour; one-tile launches with K = 4096 run sixteen waves
     assert plan(6, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=1 waves=16 x=l2 dequant=exact") and "waves=8 x=lds" in plan(4, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)
     assert plan(6, 4096, 12288).startswith("skinny ntw=4 waves=8 x=l2") and plan(10, 11008, 4096).startswith("skinny ntw=4 waves=8 x=l2")
