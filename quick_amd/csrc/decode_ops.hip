@@ -607,11 +607,12 @@ template <int GROUP, int UC>
 __global__ __launch_bounds__(256, 2) void decode_rope_attention_gqa_mfma_kernel(
     const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t, const half_t* __restrict__ sin_t,
     const long* __restrict__ pos, half_t* __restrict__ k_cache, half_t* __restrict__ v_cache, half_t* __restrict__ out,
-    int nh, int nkv, int L, float scale) {
+    int nh, int nkv, int L, float scale, int gsplit) {
   constexpr int D = 128;
   static_assert(GROUP >= 1 && GROUP <= 8, "query heads per KV head");
   __shared__ float part[4][GROUP][D + 2];  // per wave and query head: 128 output dims, running max, running sum
-  const int b = blockIdx.y, kvh = blockIdx.x, hbase = kvh * GROUP;
+  // gsplit workgroups share a KV head, GROUP query heads each (8 heads per KV head with few sequences: two workgroups of 4)
+  const int b = blockIdx.y, kvh = blockIdx.x / gsplit, hbase = kvh * (GROUP * gsplit) + (blockIdx.x % gsplit) * GROUP;
   const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));
   const int sub = lane & 15, rsel = lane >> 4;
   const half_t* row = qkv + (size_t)b * (nh + 2 * nkv) * D;
@@ -666,11 +667,11 @@ __global__ __launch_bounds__(256, 2) void decode_rope_attention_gqa_mfma_kernel(
         kh[s][j] = (half_t)((float)(half_t)((float)kraw[s][j] * c) + (float)(half_t)(sign * (float)kraw[s ^ 2][j] * sj));
       }
     }
-    if (wave == 0 && sub == 0) {  // append to the caches (position p is not requested by anyone in this launch)
+    if (wave == 0 && sub == 0 && blockIdx.x % gsplit == 0) {  // append to the caches (position p is not requested by anyone in this launch)
 #pragma unroll
       for (int s = 0; s < 4; ++s) *(half8_t*)(krow + (size_t)p * D + 32 * s + 8 * rsel) = kh[s];
     }
-    if (wave == 0 && rsel == 0) *(half8_t*)(vrow + (size_t)p * D + sub * 8) = vn;
+    if (wave == 0 && rsel == 0 && blockIdx.x % gsplit == 0) *(half8_t*)(vrow + (size_t)p * D + sub * 8) = vn;
   }
 
   const float qk_scale = scale * 1.44269504088896f;   // scores in the log2 domain
@@ -1047,14 +1048,16 @@ int quick_decode_rope_attention_f16(const void* qkv, const void* cos_table, cons
       const char* e = getenv("QUICK_AMD_ATTN_MFMA");
       return e ? atoi(e) : 1;
     }();
-#define QA_GQA_M(GROUP, UC)                                                                                          \
-  hipLaunchKernelGGL((decode_rope_attention_gqa_mfma_kernel<GROUP, UC>), dim3(n_kv_heads, batch), dim3(256), 0,        \
+#define QA_GQA_M(GROUP, UC, GSPLIT)                                                                                  \
+  hipLaunchKernelGGL((decode_rope_attention_gqa_mfma_kernel<GROUP, UC>), dim3(n_kv_heads * (GSPLIT), batch), dim3(256), 0, \
                      (hipStream_t)hip_stream, (const half_t*)qkv, (const half_t*)cos_table, (const half_t*)sin_table, \
-                     (const long*)pos, (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads, cache_len, scale)
+                     (const long*)pos, (half_t*)k_cache, (half_t*)v_cache, (half_t*)out, n_heads, n_kv_heads, cache_len, scale, GSPLIT)
     // (8 heads per KV head from 128 pairs -- Llama-2-70B at bs = 16, one workgroup per pair on half the CUs -- measured 1 % BEHIND the two
     // vector-ALU sweeps of 4 heads, profiles/r05_decode70_ab.txt)
-    if (mfma_on && group == 8 && pairs >= 256) QA_GQA_M(8, 1);
-    else if (mfma_on && group == 4 && pairs >= 256) QA_GQA_M(4, 1);   // (two chunks per set: 256 registers and a spill, 5-10 % behind)
+    if (mfma_on && group == 8 && pairs >= 256) QA_GQA_M(8, 1, 1);
+    else if (mfma_on && group == 8 && pairs * 2 >= 256) QA_GQA_M(4, 1, 2);   // (fewer sequences: two workgroups of 4 heads per KV head -- Llama-2-70B at
+                                                                             // bs = 16: 12.6 -> 11.4 us against the vector-ALU sweeps, 1617 -> 1658 tok/s)
+    else if (mfma_on && group == 4 && pairs >= 256) QA_GQA_M(4, 1, 1);   // (two chunks per set: 256 registers and a spill, 5-10 % behind)
     else if (group == 8 && pairs * 2 >= 256) QA_GQA_U(4, 2);
     else if (group == 4 && pairs >= 256) QA_GQA_U(4, 1);
     else if (group == 4 && pairs * 2 >= 256) QA_GQA_U(2, 2);  // fewer sequences: two workgroups of 2 heads per KV head

@@ -741,8 +741,8 @@ def test_rmsnorm_prologue_matches_two_launches(qa, device, M, K, N, G):
     assert rel_err(y1.cpu().numpy(), want) <= TOL
 
 
-@pytest.mark.parametrize("B,nh,nkv", [(2, 8, 8), (3, 8, 2), (32, 32, 32), (32, 32, 8), (64, 16, 8), (64, 64, 8)],
-                         ids=["mha-small", "gqa-per-head", "mha-1024-workgroups", "gqa4-shared", "gqa2-shared", "gqa8-shared"])
+@pytest.mark.parametrize("B,nh,nkv", [(2, 8, 8), (3, 8, 2), (32, 32, 32), (32, 32, 8), (64, 16, 8), (64, 64, 8), (16, 64, 8), (24, 32, 8)],
+                         ids=["mha-small", "gqa-per-head", "mha-1024-workgroups", "gqa4-shared", "gqa2-shared", "gqa8-shared", "gqa8-two-workgroups", "gqa4-two-workgroups"])
 @pytest.mark.parametrize("p", [0, 1, 5, 127, 128, 255, 256, 300, 319])
 def test_rope_attention_kernels_against_torch(qa, device, B, nh, nkv, p):
     """RoPE + KV append + single-query attention in one launch: the single-pass (online softmax) kernel with a workgroup
