@@ -121,7 +121,8 @@ int quick_w4a16_workspace_check(const void* workspace, size_t workspace_bytes, v
  * `kernel`: 0 = the library's planner (what every product path passes).  Otherwise, for tests and tuning, a
  * bit field -- every field 0 = "planner's choice within the family":
  *   bits 0-3    family, QUICK_KERNEL_*
- *   bits 4-7    SKINNY: channel tiles of 16 per workgroup (1, 2, 4); TILED: token tiles of 16 per workgroup (2, 4, 8);
+ *   bits 4-7    SKINNY: channel tiles of 16 per workgroup (1, 2, 4; 8 = [r05] the straight-line eight-tile fragment kernel where it is built --
+ *               9..16 tokens, G = 128, K / 128 = 8 waves x slices x {2, 4, 7, 8} k tiles, no RMSNorm prologue -- else 4); TILED: token tiles of 16 per workgroup (2, 4, 8);
  *               WIDE / XK / XW: token tiles of 32 per workgroup (WIDE 2, 4, 8; XK 2, 4; XW 2, 4, 8 -- 0 = 4; 8 = the 256 x 256 tile)
  *   bits 8-11   SKINNY / TILED / LEAN: waves per workgroup / 4; WIDE: 32-channel pairs per wave (1, 2); XK: K slices per tile (1, 2, 4, 8; 15 = half
  *               the planner's count); XW: K slices per tile (1, 2, 4 <= token tiles)
