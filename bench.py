@@ -169,8 +169,8 @@ def main():
     ap.add_argument("--sets", type=int, default=0, help="distinct weight sets cycled through (0 = enough for > 320 MiB)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 skinny, 2 tiled")
     ap.add_argument("--split-k", type=int, default=0, help="K slices across workgroups (0 = the planner's choice; tuning only)")
-    ap.add_argument("--layers", default="1x4096x12288,1x4096x22016,1x11008x4096",
-                    help="MxKxN shapes (Llama-2-7B fused qkv, gate_up, down at bs=1) timed kernel-only into 'decode_layers'; '' = none")
+    ap.add_argument("--layers", default="1x4096x12288,1x4096x22016,1x11008x4096,16x8192x57344",
+                    help="MxKxN shapes (Llama-2-7B fused qkv, gate_up, down at bs=1; Llama-2-70B gate_up at bs=16) timed kernel-only into 'decode_layers'; '' = none")
     ap.add_argument("--prefill-layers", default="4096x4096x4096,8192x4096x22016,8192x11008x4096,4096x28672x8192",
                     help="MxKxN prefill-sized launches (K = N = 4096; Llama-2-7B gate_up / down at 8192 tokens; Llama-2-70B down) into 'prefill_layers'; '' = none")
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="budget of the cpu_baseline leg (0 = skip)")

@@ -1316,8 +1316,9 @@ static thread_local bool g_span_unsupported = false;  // set by a launcher asked
 // results that -amdgpu-waitcnt-forcezero cured (hipcc's wait counts around guarded / replayed requests in a loop).  Here
 // every wave owns EXACTLY T k tiles (the planner only picks the kernel when K / 128 == 8 waves x ksplit x T), every request is unconditional,
 // nothing is replayed and no request's result dies unread: the form in which hipcc's counts are exact (as in the lean kernels).
-template <int T, bool NT>
+template <int T, bool NT, bool SPAN = false>
 __global__ __launch_bounds__(512) void w4a16_frag8_kernel(const GemmArgs a) {
+  if constexpr (SPAN) span_stamp(a.span, 0);
   constexpr int NTW = 8, WAVES = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   floatx4* red = (floatx4*)smem;  // [WAVES][NTW][64]
@@ -1349,6 +1350,7 @@ __global__ __launch_bounds__(512) void w4a16_frag8_kernel(const GemmArgs a) {
     skinny_compute_dzf<NTW, 0, 1, false>(c[i & 1], 0, 1, bconst, (lane & 1) != 0, acc);   // (kt = 0 < kt_end = 1: the k tile is always this wave's)
   }
   skinny_finish<NTW, WAVES, true, false>(a, acc, red, smem, bx, nblocks, mb, ks, lane, wave);
+  if constexpr (SPAN) span_stamp(a.span, 1);
 }
 
 // LDS of one skinny workgroup: reduction buffer(s), the x copy, the deferred-zero table
@@ -2484,15 +2486,21 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
       case 2: launch_skinny<2>(p, a, L); break;
       case 8: {
         if (!p.frag8_t || f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "skinny: eight channel tiles per workgroup only in the straight-line fragment kernel, no RMSNorm prologue");
-        if (a.span) { g_span_unsupported = true; break; }
         dim3 grid(p.grid_x, (M + 15) / 16, p.ksplit), block(512);
         const unsigned lds = 8 * 8 * 1024;
 #define QA_FRAG8(TV)                                                                                               \
   do {                                                                                                             \
-    auto kfn = w4a16_frag8_kernel<TV, true>;                                                                       \
-    static std::atomic<unsigned long long> attr_set{0};                                                            \
-    (void)lds_limit_once(attr_set, (const void*)kfn, (int)kLdsPerCu);                                              \
-    hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
+    if (a.span) { /* in-kernel span stamps (a measurement aid): the same kernel + two stamps */                    \
+      auto kfn = w4a16_frag8_kernel<TV, true, true>;                                                               \
+      static std::atomic<unsigned long long> attr_set_s{0};                                                        \
+      (void)lds_limit_once(attr_set_s, (const void*)kfn, (int)kLdsPerCu);                                          \
+      hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                   \
+    } else {                                                                                                       \
+      auto kfn = w4a16_frag8_kernel<TV, true>;                                                                     \
+      static std::atomic<unsigned long long> attr_set{0};                                                          \
+      (void)lds_limit_once(attr_set, (const void*)kfn, (int)kLdsPerCu);                                            \
+      hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                   \
+    }                                                                                                              \
   } while (0)
         switch (p.frag8_t) {
           case 2: QA_FRAG8(2); break;
