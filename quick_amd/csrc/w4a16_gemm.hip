@@ -2056,7 +2056,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       }
     }
     // [r05] 9..16 tokens where the four-tile fragment flavour runs and K / 128 splits into 8 waves x ksplit x T whole k tiles, T in {2, 4, 7, 8}:
-    // eight tiles per workgroup, straight-line (w4a16_frag8_kernel).  ksplit = the smallest of 1, 2, 4 that gives >= 256 workgroups.
+    // eight tiles per workgroup, straight-line (w4a16_frag8_kernel).  ksplit: one slice from 192 blocks, else the smallest of 2, 4 that gives >= 256 workgroups.
     // Forced by kernel id (SKINNY, 8 channel tiles); AUTO takes it where QUICK_AMD_FRAG8 says (default below).
     {
       static const int frag8_env = [] {
@@ -2075,12 +2075,13 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
           if (t != 2 && t != 4 && t != 7 && t != 8) continue;
           best_ks = s2;
           best_t = t;
-          if ((N / 128) * s2 >= 256) break;
+          if ((N / 128) * s2 >= (s2 == 1 ? 192 : 256)) break;   // (one slice from 192 blocks: a K split costs more than the idle CUs)
         }
         // (AUTO only where measured ahead: 8192 x 57344 one slice 62 -> 54 us, 28672 x 8192 four slices 29.5 -> 27.9, 8192 x 8192 four slices
         // 12.9 -> 11.9; 8192 x 10240 -- 80 blocks -- two slices 17.2 against 15.3: stays with four tiles)
-        if (best_ks && !asked && (N / 128) * best_ks < 256) best_ks = 0;
-        if (best_ks && !asked && (N / 128) % 64 != 0) best_ks = 0;
+        // ... and 8192 x 28672 -- 224 blocks, one slice -- 28.7 -> 23.5: one slice from 192 blocks, K slices only on whole multiples of 64 blocks)
+        // (128 blocks x two slices, 8192 x 16384: 16.4 -> 18.5 us, behind: K slices only where measured ahead, 64 blocks x four)
+        if (best_ks && !asked && !((best_ks == 1 && N / 128 >= 192) || (N / 128 == 64 && best_ks == 4))) best_ks = 0;
         if (best_ks) {
           p.mt = 8;
           p.waves = 8;

@@ -261,6 +261,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(16, 28672, 8192).startswith("skinny ntw=8") and "grid=64x1x4 ksplit=4" in plan(16, 28672, 8192)
     assert plan(16, 8192, 8192).startswith("skinny ntw=8") and "ksplit=4" in plan(16, 8192, 8192) and plan(9, 8192, 57344).startswith("skinny ntw=8")
     assert plan(16, 8192, 10240).startswith("skinny ntw=4") and plan(8, 8192, 57344).startswith("skinny ntw=1") and not plan(17, 8192, 57344).startswith("skinny ntw=8")
+    assert plan(16, 8192, 28672).startswith("skinny ntw=8") and "grid=224x1x1 ksplit=1" in plan(16, 8192, 28672) and plan(16, 8192, 16384).startswith("skinny ntw=4")   # (one slice from 192 blocks; 128 blocks x 2 slices measured behind)
     # r03 audit: from five tokens no LDS copy of x outside the table flavour; one-tile launches with K = 4096 run sixteen waves
     assert plan(6, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=1 waves=16 x=l2 dequant=exact") and "waves=8 x=lds" in plan(4, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)
     assert plan(6, 4096, 12288).startswith("skinny ntw=4 waves=8 x=l2") and plan(10, 11008, 4096).startswith("skinny ntw=4 waves=8 x=l2")
