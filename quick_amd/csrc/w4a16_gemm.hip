@@ -1310,9 +1310,9 @@ static constexpr size_t kLdsPerCu = 160 * 1024;  // gfx950
 static thread_local bool g_span_unsupported = false;  // set by a launcher asked for span stamps its kernel does not carry
 
 // [r05] EIGHT channel tiles per workgroup in the fragment deferred-zero flavour, as STRAIGHT-LINE code: 9..16 tokens on layers whose x (16 x K
-// fp16) does not fit LDS (K >= 8192: Llama-2-70B).  Why eight: a CU sustains ~48 KB of vector-memory requests in flight whatever their target,
-// and the x fragments of this flavour come from L2 once per workgroup and k tile -- as many bytes as the weights at four tiles, half as many at
-// eight (16 x 8192 x 57344: 62 -> 54 us).  Why straight-line: the chunk loop of w4a16_skinny_kernel instantiated for eight tiles gave wrong
+// fp16) does not fit LDS (K >= 8192: Llama-2-70B).  Why eight: the launch time of this flavour follows the bytes of its x fragments, which come from L2 once per workgroup and k tile
+// (64 B per token row and request: 16 cache lines per instruction) -- as many bytes as the weights at four tiles, half as many at eight (16 x 8192 x
+// 57344: 62 -> 50 us); queue depth and occupancy do not move it (profiles/r05_skinny_variants.txt).  Why straight-line: the chunk loop of w4a16_skinny_kernel instantiated for eight tiles gave wrong
 // results that -amdgpu-waitcnt-forcezero cured (hipcc's wait counts around guarded / replayed requests in a loop).  Here
 // every wave owns EXACTLY T k tiles (the planner only picks the kernel when K / 128 == 8 waves x ksplit x T), every request is unconditional,
 // nothing is replayed and no request's result dies unread: the form in which hipcc's counts are exact (as in the lean kernels).
