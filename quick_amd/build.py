@@ -23,14 +23,14 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libquick_amd.so")
 TOOLS_DIR = os.path.join(os.path.dirname(PKG), "tools", "bin")   # measurement builds live with the tools, not with the product
 TOOLS_LIB = os.path.join(TOOLS_DIR, "libquick_amd_tools.so")
-SOURCES = ["w4a16_gemm.hip", "w4a16_xk.hip", "w4a16_xw.hip", "w4a16_lean.hip", "w4a16_lean_a.hip", "w4a16_lean_b.hip", "w4a16_lean_c.hip", "repack.hip", "decode_ops.hip"]
-HEADERS = ["w4a16_common.hpp", "w4a16_args.hpp", "w4a16_wide.hpp", "w4a16_xk.hpp", "w4a16_xk_host.hpp", "w4a16_xw.hpp", "w4a16_xw_host.hpp", "w4a16_xw_loop.inc", "w4a16_lean.hpp", "w4a16_lean_host.hpp", "w4a16_lean_inst.hpp",
+SOURCES = ["w4a16_gemm.hip", "w4a16_xk.hip", "w4a16_xw.hip", "w4a16_xm.hip", "w4a16_lean.hip", "w4a16_lean_a.hip", "w4a16_lean_b.hip", "w4a16_lean_c.hip", "repack.hip", "decode_ops.hip"]
+HEADERS = ["w4a16_common.hpp", "w4a16_args.hpp", "w4a16_wide.hpp", "w4a16_xk.hpp", "w4a16_xk_host.hpp", "w4a16_xw.hpp", "w4a16_xw_host.hpp", "w4a16_xw_loop.inc", "w4a16_xm.hpp", "w4a16_xm_host.hpp", "w4a16_xm_loop.inc", "w4a16_lean.hpp", "w4a16_lean_host.hpp", "w4a16_lean_inst.hpp",
            os.path.join("..", "..", "include", "quick_amd.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"]
 # per-source extras: the lean small-M kernels take their leading arguments preloaded into SGPRs (w4a16_lean.hpp)
 _PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
-EXTRA_CFLAGS = {"w4a16_xw.hip": _PRELOAD, "w4a16_xk.hip": _PRELOAD, "w4a16_lean_a.hip": _PRELOAD, "w4a16_lean_b.hip": _PRELOAD, "w4a16_lean_c.hip": _PRELOAD}
+EXTRA_CFLAGS = {"w4a16_xw.hip": _PRELOAD, "w4a16_xm.hip": _PRELOAD, "w4a16_xk.hip": _PRELOAD, "w4a16_lean_a.hip": _PRELOAD, "w4a16_lean_b.hip": _PRELOAD, "w4a16_lean_c.hip": _PRELOAD}
 FLAGS = CFLAGS + ["-shared"]   # (what the library is built with, for the record)
 
 

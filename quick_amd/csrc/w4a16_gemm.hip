@@ -30,6 +30,7 @@
 #include "w4a16_xk_host.hpp"
 #include "w4a16_xw_host.hpp"
 #include "w4a16_lean_host.hpp"
+#include "w4a16_xm_host.hpp"
 namespace quick_amd {
 
 // ------------------------------------------------------------------------------------------------
@@ -1479,6 +1480,60 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       }
     }
   }
+  // [r06] mid-token kernels (w4a16_xm.hpp): one workgroup = 32 or 64 tokens x pr x 32 channels for all of K, eight waves splitting K, each with its
+  // own x ring and weight queue; x is fetched once per workgroup, in whole cache lines.  Forced: family XM, bits 4-7 = channel pairs per workgroup
+  // (1..3; 0 = choose), bits 8-9 = 1 / 2: 32- / 64-token tiles whatever the count.  What bounds these launches is the CU's vector memory path: it
+  // returns in issue order ACROSS waves, so x pieces (L2) queue behind weight requests (HBM) and the bytes a CU can have in flight (its x
+  // rings + weight queues) over the HBM latency is its rate.  Hence the rule, from the audit of every selection against the
+  // other families on 15 layer shapes x 8 token counts (profiles/r06_xm_audit.txt; QUICK_AMD_XM=0 switches it off for A/B):
+  //   * K <= 8192 (longer K: a workgroup's x alone is > 1 MB per CU -- the exchange-K kernels, whose K slices sit on different CUs, stay ahead);
+  //   * 17..32 tokens: the fewest channel pairs per workgroup that cover the layer in ONE round of workgroups (0.79-1.0 of the others' time);
+  //   * 33..64 tokens: two 32-token tiles x (1 or 2) pairs where that is one round -- N <= 4096 (0.89-0.91), N = 6144 .. 8192 (0.77-0.91): every CU
+  //     busy beats the halved dequantisation of a 64-token tile there; 64-token tiles x 3 pairs on layers of > 2 rounds of pairs up to 48 tokens
+  //     (4096 x 22016: 0.93-0.95); elsewhere the r03-r05 picks are level or ahead and stay.
+  {
+    const bool forced = family == QUICK_KERNEL_XM;
+    static const bool xm_on = [] {
+      const char* e = getenv("QUICK_AMD_XM");
+      return !(e && *e && atoi(e) == 0);
+    }();
+    const int tpg = G / 128;
+    const bool envelope = G % 128 == 0 && (tpg & (tpg - 1)) == 0 && (size_t)K * N / 2 < ((size_t)1 << 31) && (size_t)M * K * 2 < ((size_t)1 << 31);   // (a wave without a k tile adds zeros)
+    const int pairs = N / 32, cus = cu_count();
+    int mb = 0, pr = 0;
+    if (forced) {
+      const int tile_req = (kernel >> 8) & 3;   // 1 = 32-token tiles, 2 = 64-token tiles
+      mb = tile_req ? tile_req : (M <= 32 ? 1 : 2);
+      pr = mt_req ? std::max(1, std::min(3, mt_req)) : 1;
+      if (!mt_req)
+        while (pr < 3 && (long)((pairs + pr - 1) / pr) * ((M + mb * 32 - 1) / (mb * 32)) > cus) ++pr;
+    } else if (family == QUICK_KERNEL_AUTO && xm_on && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M > 16 && M <= 64 && KT >= 8 && KT <= 64) {
+      if (M <= 32) {
+        for (int c = 1; c <= 3 && !pr; ++c)
+          if ((pairs + c - 1) / c <= cus) pr = c;
+        mb = 1;
+      } else if (2 * pairs <= cus) {
+        mb = 1, pr = 1;
+      } else if (pairs <= cus && 4 * pairs >= 3 * cus) {
+        mb = 1, pr = 2;
+      } else if (M <= 48 && pairs > 2 * cus && (pairs + 2) / 3 <= cus) {
+        mb = 2, pr = 3;
+      }
+    }
+    if (forced || pr) {
+      const int mtiles = (M + mb * 32 - 1) / (mb * 32);
+      p.kernel = QUICK_KERNEL_XM;
+      p.ksplit = 1;
+      p.kt_per_split = KT;
+      p.wide_mb = mb;
+      p.wide_pairs = pr;
+      p.grid_x = (pairs + pr - 1) / pr;
+      p.ntiles = p.grid_x * mtiles;
+      p.waves = 8;
+      p.lean_tmax = envelope ? 1 : 0;   // (0 = no build for this shape: the launch answers UNSUPPORTED)
+      return p;
+    }
+  }
   // skinny: one workgroup per 16 tokens x 16..64 channels for all of K (x re-read per channel block, no cross-workgroup
   // reduction); tiled: 32..64 tokens x 128 channels through LDS.  Measured crossover [r01]: the tiled kernel wins from
   // M = 65, and from M = 17 once there are >= 64 tiles of 128 channels (N >= 8192) so that it needs no K split.
@@ -2386,7 +2441,7 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
                     void* workspace, size_t workspace_bytes, int M, int K, int N, int G, int kernel, int grid_split_k,
                     const Launch& L) {
   if (int rc = check_shapes(M, K, N, G)) return rc;
-  if ((kernel & 15) > QUICK_KERNEL_LEAN || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+  if ((kernel & 15) > QUICK_KERNEL_XM || kernel < 0) return fail(QUICK_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
 #ifndef QUICK_AMD_TOOLS
   if ((kernel >> 16) & 31)  // the timing-experiment builds (wrong results on purpose, phase stamps) are not in the product library
     return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: bits 16-20 select timing experiments that only a QUICK_AMD_TOOLS build contains", kernel);
@@ -2433,6 +2488,15 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
       if (abl == 32) g_span_unsupported = true;
       return fail(QUICK_ERR_UNSUPPORTED, "no lean build for K=%d G=%d waves=%d (G %% 128 == 0, waves <= K / 128 <= 16 waves, x + table within 160 KiB of LDS)", K, G, p.waves);
     }
+  } else if (p.kernel == QUICK_KERNEL_XM) {
+    if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
+    int abl = a.span ? 32 : 0;
+#ifdef QUICK_AMD_TOOLS
+    if (p.ablate == 16) abl = 64;  // phase stamps into the workspace (tools/xm_phases.py)
+    else if (p.ablate) return fail(QUICK_ERR_INVALID_ARGUMENT, "XM: timing-experiment bit 16 (stamps) only");
+#endif
+    if (!p.lean_tmax || !xm_launch(p.wide_mb, p.wide_pairs, abl, a, p.grid_x, p.ntiles / p.grid_x, L.st, L.start, L.stop))
+      return fail(QUICK_ERR_UNSUPPORTED, "no mid-token build for K=%d G=%d (G a power-of-two multiple of 128, 32-bit offsets)", K, G);
   } else if (p.kernel == QUICK_KERNEL_XW) {
     if (f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
     int abl = a.span ? 32 : 0;
@@ -2603,6 +2667,9 @@ int quick_w4a16_plan_describe(int M, int K, int N, int group_size, int kernel, i
   if (p.kernel == QUICK_KERNEL_LEAN)
     snprintf(text, text_bytes, "lean ntw=%d waves=%d tiles_per_wave<=%d grid=%dx%d lds=%u workspace=0", p.mt, p.waves, p.lean_tmax, p.grid_x, (M + 15) / 16,
              lean_lds_need(M, K, p.waves, p.mt, false));
+  else if (p.kernel == QUICK_KERNEL_XM)
+    snprintf(text, text_bytes, "xm tokens=%d channels=%d waves=8 grid=%dx%d lds=%u workspace=0", p.wide_mb * 32, p.wide_pairs * 32, p.grid_x, p.ntiles / p.grid_x,
+             xm_lds_need(p.wide_mb, p.wide_pairs));
   else if (p.kernel == QUICK_KERNEL_SKINNY)
     snprintf(text, text_bytes, "skinny ntw=%d waves=%d x=%s dequant=%s grid=%dx%dx%d ksplit=%d workspace=%zu", p.mt, p.waves,
              p.xlds ? "lds" : "l2", p.dz ? (p.xlds ? "deferred-zero-table" : "deferred-zero-fragment") : "exact", p.grid_x,

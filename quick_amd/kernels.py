@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 
-KERNEL_AUTO, KERNEL_SKINNY, KERNEL_TILED, KERNEL_WIDE, KERNEL_XK, KERNEL_XW, KERNEL_LEAN = 0, 1, 2, 3, 4, 5, 6
+KERNEL_AUTO, KERNEL_SKINNY, KERNEL_TILED, KERNEL_WIDE, KERNEL_XK, KERNEL_XW, KERNEL_LEAN, KERNEL_XM = 0, 1, 2, 3, 4, 5, 6, 7
 _OK, _INVALID, _WORKSPACE, _LAUNCH, _UNSUPPORTED = 0, 1, 2, 3, 4
 
 

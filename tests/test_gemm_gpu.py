@@ -105,7 +105,7 @@ SHAPES = [  # (M, K, N, G)
 ]
 
 
-TILED_MFMA32 = TILED | (1 << 13)      # experimental 32x32x16 flavour of the tiled kernel
+TILED_MFMA32 = TILED | (1 << 8)      # experimental 32x32x16 flavour of the tiled kernel
 TILED_16WAVES = TILED | (4 << 8)      # 4 x 4 waves per workgroup
 TILED_WIDE = TILED | (1 << 29)        # 64 x 256 workgroup tiles (the planner's choice once they cover the 256 CUs: large M)
 TILED_BIG = TILED | (1 << 27)         # 128 x 256 tiles run by four waves with 128 accumulators each (large M)
@@ -1550,3 +1550,107 @@ def test_lean_persistent_launches_equal_the_one_block_launches(qa, device, M, K,
     lnw = (torch.rand(K, device=device) + 0.5).half()
     for kw in (dict(bias=bias, residual=res), dict(silu_mul=True), dict(rmsnorm_weight=lnw, rmsnorm_eps=1e-5, residual=res)):
         assert torch.equal(qa.gemm_forward(xd, *packed, kernel_id=one, **kw), qa.gemm_forward(xd, *packed, kernel_id=per, **kw)), kw.keys()
+
+
+# ------------------------------------------------------------------------------------------------
+# [r06] mid-token kernels (w4a16_xm.hpp): 17..64 tokens, one workgroup per 32 / 64 tokens x 1..3 channel pairs, eight waves splitting K
+# ------------------------------------------------------------------------------------------------
+XM = 7
+
+
+def xm(pr, tile=0):
+    """pr channel pairs per workgroup; tile: 0 = by the token count, 64 / 32 = forced token tile"""
+    return XM | (pr << 4) | ((2 << 8) if tile == 64 else 0) | ((1 << 8) if tile == 32 else 0)
+
+
+XM_SHAPES = [(17, 1024, 256, 128), (33, 1024, 256, 128), (63, 1152, 384, 128), (64, 4096, 512, 128), (65, 1536, 256, 256), (127, 2048, 640, 128),
+             (20, 2176, 128, 128), (50, 11008, 256, 128), (32, 8192, 256, 128), (48, 1024, 1280, 512)]
+
+
+@pytest.mark.parametrize("tile", [32, 64])
+@pytest.mark.parametrize("pr", [1, 2, 3])
+@pytest.mark.parametrize("M,K,N,G", XM_SHAPES)
+def test_xm_family_against_oracle(qa, device, M, K, N, G, pr, tile):
+    """Every build of the mid-token kernel (32- / 64-token tiles x 1 / 2 / 3 channel pairs per workgroup): ragged token counts incl. the
+    verdict's 17 / 33 / 63 / 65 / 127 (two token tiles), k tiles that do not divide by the eight waves (9, 12, 17, 86), a ragged last
+    channel block (N / 32 not a multiple of the pairs), G = 256 / 512; against the oracle, three runs bit-identical, results into a
+    NaN-poisoned buffer (every element of y written, nothing next to it), bias + residual, SiLU * mul; the RMSNorm prologue is refused."""
+    from quick_amd import kernels as K_
+    kid = xm(pr, tile)
+    plan = K_.plan_describe(M, K, N, G, kid)
+    assert plan.startswith(f"xm tokens={tile} channels={32 * pr}"), plan
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M + K + N + G + pr)
+    want = oracle.w4a16_forward(x, iw, s, z, G).astype(np.float32)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device)
+    out = torch.full((M + 2, N), float("nan"), dtype=torch.float16, device=device)
+    y = qa.gemm_forward(xd, *packed, kernel_id=kid, out=out[1:M + 1])
+    assert rel_err(y.cpu().numpy(), want) <= TOL, plan
+    assert torch.isnan(out[0]).all() and torch.isnan(out[M + 1]).all() and not torch.isnan(out[1:M + 1]).any()
+    for _ in range(2):
+        assert torch.equal(y, qa.gemm_forward(xd, *packed, kernel_id=kid)), plan
+    bias = _dev(np.linspace(-1, 1, N).astype(np.float16), device)
+    res = torch.randn(M, N, device=device).half()
+    yb = qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=kid)
+    assert rel_err(yb.cpu().numpy(), want + bias.float().cpu().numpy() + res.float().cpu().numpy()) <= TOL, plan
+    gu = torch.from_numpy(want).half().view(M, N // 16, 2, 8)                  # gate / up interleaved by 8
+    ref = (torch.nn.functional.silu(gu[:, :, 0].float()).half() * gu[:, :, 1]).reshape(M, N // 2).float().numpy()
+    ya = qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kid)
+    assert tuple(ya.shape) == (M, N // 2) and rel_err(ya.cpu().numpy(), ref) <= 2 * TOL, plan
+    with pytest.raises(NotImplementedError):
+        qa.gemm_forward(xd, *packed, kernel_id=kid, rmsnorm_weight=torch.ones(K, dtype=torch.float16, device=device))
+
+
+@pytest.mark.parametrize("pr,tile", [(1, 32), (2, 32), (3, 64), (1, 64)])
+def test_xm_golden_fixtures_reference_pin_and_exact_dequantisation(qa, device, pin, pr, tile):
+    """The reference-made fixtures end to end (reference-format checkpoint -> HIP repack -> the mid-token kernels); the 4096 x 4096 pin of
+    the reference packer / CPU path at 64 tokens (the fixture's 16 rows repeated), also through the planner's own pick; and one-hot
+    activations: y[m] is then exactly one row of the dequantised matrix -- fp16((w - z) * s) bit for bit, the reference's per-weight arithmetic
+    (csrc/gemm_cuda_quick.cu:52-60), whatever wave, stage and register it travelled through."""
+    from quick_amd import kernels as K_
+    kid = xm(pr, tile)
+    for path in GOLD:
+        g = load_golden(path)
+        if int(g["G"]) % 128:
+            continue                                    # (k tiles fewer than the waves: some waves add zeros)
+        qw, qs, qz = qa.repack_cuda_to_mi355x(_dev(g["ref_qweight"], device), _dev(g["ref_qscales"], device), _dev(g["ref_qzeros"], device))
+        y = qa.gemm_forward(_dev(g["x"], device), qw, qs, qz, kernel_id=kid)
+        assert rel_err(y.cpu().numpy(), g["ref_y"]) <= TOL, path
+    g, iw, s, z = pin
+    packed = _pack_dev(iw, s, z, device)
+    ref = g["y_ref"].astype(np.float32)
+    M = 64
+    x = np.tile(g["x"], (M // g["x"].shape[0], 1))
+    assert K_.plan_describe(M, 4096, 4096, 128).startswith("xm tokens=32 channels=32")
+    for k in (kid, 0):
+        y = qa.gemm_forward(_dev(x, device), *packed, kernel_id=k).cpu().numpy().astype(np.float32)
+        for rep in (0, M // 16 - 1):
+            assert float(np.abs(y[g["y_rows"] + 16 * rep, g["y_cols"]] - ref).max()) <= TOL * float(np.abs(ref).max())
+        assert float(np.abs(np.abs(y).sum(0) - g["col_abs_sum"] * (M // 16)).max()) <= TOL * float(g["col_abs_sum"].max()) * (M // 16)
+    K, N, G = 2048, 384, 128
+    _, iw2, s2, z2 = oracle.make_synthetic(1, K, N, G, seed=77)
+    wd = oracle.dequantize(iw2, s2, z2, G)                      # fp16 [K, N]
+    rows = np.random.default_rng(5).choice(K, 48, replace=False)
+    xh = np.zeros((48, K), np.float16)
+    xh[np.arange(48), rows] = 1.0
+    y = qa.gemm_forward(_dev(xh, device), *_pack_dev(iw2, s2, z2, device), kernel_id=kid).cpu().numpy()
+    assert np.array_equal(y.view(np.uint16), wd[rows].astype(np.float16).view(np.uint16))
+
+
+def test_xm_planner_picks_against_oracle_on_layer_shapes(qa, device):
+    """What AUTO runs at 17..64 tokens on the decode layer shapes (sampled channels against the oracle): the mid-token kernels where the audit
+    has them ahead, the r03-r05 picks elsewhere -- every one right, and the picks are the ones profiles/r06_xm_audit.txt was measured with."""
+    from quick_amd import kernels as K_
+    G = 128
+    seen = set()
+    for (K, N) in ((4096, 4096), (4096, 12288), (4096, 22016), (4096, 6144), (8192, 8192), (11008, 4096)):
+        _, iw, s, z = oracle.make_synthetic(1, K, N, G, seed=K + N)
+        packed = _pack_dev(iw, s, z, device)
+        cols = np.random.default_rng(N).choice(N, 256, replace=False)
+        for M in (17, 32, 33, 48, 64):
+            x = (np.random.default_rng(M).standard_normal((M, K)) * 0.5).astype(np.float16)
+            want = oracle.w4a16_forward(x, iw[:, cols], s[:, cols], z[:, cols], G).astype(np.float32)
+            y = qa.gemm_forward(_dev(x, device), *packed)
+            assert rel_err(y.cpu().numpy()[:, cols], want) <= TOL, (M, K, N)
+            seen.add(K_.plan_describe(M, K, N, G).split()[0])
+    assert "xm" in seen and len(seen) >= 3

@@ -145,7 +145,7 @@ def test_product_library_has_no_timing_experiments():
     """Kernel-id bits 16-20 select ablation builds (wrong results on purpose) and phase stamps: a QUICK_AMD_TOOLS build only.
     The product library rejects them before any GPU work and exports no such kernels."""
     lib = _lib.load()
-    for kid in (2 | (1 << 16), 3 | (16 << 16), 4 | (4 << 16), 1 << 16, 4 | (1 << 12), 4 | (1 << 13)):   # (the last two: the loader-wave / sixteen-wave exchange-K flavours)
+    for kid in (2 | (1 << 16), 3 | (16 << 16), 4 | (4 << 16), 1 << 16, 4 | (1 << 12), 4 | (1 << 8)):   # (the last two: the loader-wave / sixteen-wave exchange-K flavours)
         rc = lib.quick_w4a16_gemm_f16_ex(None, None, None, None, None, None, None, 0, 512, 4096, 4096, 128, kid, 0, None)
         assert rc == 1 and "QUICK_AMD_TOOLS" in _lib.last_error(), (kid, rc, _lib.last_error())
     import subprocess
@@ -192,10 +192,10 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(1, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=1 waves=8 x=lds dequant=deferred-zero-table grid=256x1x1")   # (r01-r04 skinny rules: family forced; AUTO runs the lean kernels at 1..4 tokens since r05, below)
     assert "grid=464x1x1" in plan(1, 4096, 22016, kernel_id=kernels.KERNEL_SKINNY)          # 1376 blocks in 3 rounds of <= 464
     assert "dequant=exact" in plan(8, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)            # one block per workgroup: the table does not pay
-    assert plan(64, 4096, 4096).startswith("skinny ntw=4") and "deferred-zero-fragment" in plan(64, 4096, 4096)
+    assert plan(64, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4") and "deferred-zero-fragment" in plan(64, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)   # (r01-r05's pick; AUTO: the r06 mid-token kernels, below)
     assert plan(65, 4096, 4096).startswith("xk tokens=64") and "slices=4" in plan(65, 4096, 4096)   # r03: 32 exchange-K tiles x 4 K slices = one round
-    assert plan(32, 4096, 8192).startswith("skinny ntw=4")   # 256 workgroups of 64 channels x 16 tokens: one round, 32 stages each
-    assert plan(32, 4096, 12288).startswith("tiled")         # 384 of them would be two: the tiled kernel, no K split needed
+    assert plan(32, 4096, 8192, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4")   # 256 workgroups of 64 channels x 16 tokens: one round, 32 stages each
+    assert plan(32, 4096, 28672).startswith("tiled")         # (r01: where the skinny workgroups would be two rounds, the tiled kernel, no K split needed)
     # K split until the 256 CUs are covered; the workspace is what workspace_bytes_ex says
     p = plan(128, 4096, 4096, kernel_id=kernels.KERNEL_TILED)
     assert "tokens=32 channels=128" in p and "ksplit=2" in p
@@ -225,7 +225,17 @@ def test_plan_describe_pins_the_shape_heuristics():
         "xk tokens=64 channels=128 waves=8 ring=5 queue=4 grid=256 slices=1")                            # r03's bench line: one 64 x 128 tile per CU
     assert plan(64, 4096, 22016).startswith("xk tokens=64") and "slices=2" in plan(64, 4096, 12288)   # 172 / 96 tiles of 64 x 128 (below 96 tokens: r03's picks)
     assert plan(128, 4096, 4096).startswith("xw tokens=128 channels=128") and "grid=128 slices=4" in plan(128, 4096, 4096)   # r05 audit: one row of 128 x 128 tiles x four slices (r03-r04: xk 64-token tiles)
-    assert plan(64, 4096, 12288).startswith("xw tokens=64 channels=128") and plan(64, 4096, 6144).startswith("xk tokens=64")        # 33..95 tokens: 64 x 128 x two slices where that is 160..256 workgroups
+    assert plan(64, 4096, 12288).startswith("xw tokens=64 channels=128") and plan(64, 5120, 5120).startswith("xk tokens=64")        # 33..95 tokens: 64 x 128 x two slices where that is 160..256 workgroups
+    # [r06] the mid-token kernels (w4a16_xm.hpp), where the audit has them ahead (profiles/r06_xm_audit.txt): 17..32 tokens -- the fewest channel pairs
+    # per workgroup that cover the layer in one round; 33..64 tokens -- two 32-token tiles on layers of <= 8192 channels; K <= 8192
+    assert plan(64, 4096, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x2") and plan(33, 4096, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x2")
+    assert plan(17, 4096, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x1") and plan(16, 4096, 4096).startswith("lean")
+    assert plan(32, 4096, 12288).startswith("xm tokens=32 channels=64 waves=8 grid=192x1") and plan(24, 4096, 22016).startswith("xm tokens=32 channels=96 waves=8 grid=230x1")
+    assert plan(64, 4096, 6144).startswith("xm tokens=32 channels=64 waves=8 grid=96x2") and plan(64, 8192, 8192).startswith("xm tokens=32 channels=64 waves=8 grid=128x2")
+    assert plan(48, 4096, 22016).startswith("xm tokens=64 channels=96 waves=8 grid=230x1") and plan(64, 4096, 22016).startswith("xk")
+    assert not plan(64, 11008, 4096).startswith("xm") and not plan(32, 11008, 4096).startswith("xm") and not plan(65, 4096, 4096).startswith("xm")
+    assert not plan(64, 4096, 4096, G=64).startswith("xm") and not plan(64, 4608, 4096, G=384).startswith("xm")               # G a power-of-two multiple of 128
+    assert plan(40, 4096, 4096, kernel_id=kernels.KERNEL_XM | (3 << 4) | (2 << 8)).startswith("xm tokens=64 channels=96 waves=8 grid=43x1")   # forced: pairs, 64-token tiles; ragged last block
     # r04: the four-wave kernels with generated loops (w4a16_xw.hpp) from 160 tokens (96 on wide layers), picked by their own launch-time model
     assert plan(512, 4096, 4096).startswith("xw tokens=128 channels=128 waves=4 ring=4 queue=4 grid=256 slices=2")    # the bench line: 128 x 128 tiles, two K slices
     assert plan(256, 4096, 4096).startswith("xw tokens=64 channels=128 waves=4 ring=8 queue=8 grid=256 slices=2")
@@ -266,14 +276,14 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(6, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=1 waves=16 x=l2 dequant=exact") and "waves=8 x=lds" in plan(4, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)
     assert plan(6, 4096, 12288).startswith("skinny ntw=4 waves=8 x=l2") and plan(10, 11008, 4096).startswith("skinny ntw=4 waves=8 x=l2")
     # third audit (17..64 tokens, layer shapes the rules were not tuned on): the four-tile skinny kernel by its own geometry
-    assert plan(32, 4096, 6144).startswith("skinny ntw=4") and plan(32, 4096, 4096).startswith("skinny ntw=4")    # one round of workgroups, <= 64 stages each
-    assert plan(32, 5120, 5120).startswith("skinny ntw=4") and plan(64, 5120, 5120).startswith("xk tokens=64")    # 320 skinny workgroups would be two rounds; r03: 40 tiles x 4 slices
+    assert plan(32, 4096, 6144, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4") and plan(32, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4")    # one round of workgroups, <= 64 stages each (AUTO at 17..32 tokens: the r06 mid-token kernels)
+    assert plan(48, 5120, 5120).startswith("skinny ntw=4") and plan(64, 5120, 5120).startswith("xk tokens=64")    # 320 skinny workgroups would be two rounds; r03: 40 tiles x 4 slices
     assert plan(32, 13824, 5120).startswith("tiled") and "slices=8" in plan(48, 14336, 4096)                      # slices of > 64 stages; r03 from 33 tokens: 32 tiles x 8 slices of 14 stages
     assert "tokens=32 channels=128 waves=8 grid=192x1 ksplit=1" in plan(64, 4096, 12288, kernel_id=T)              # twice the tiles, nothing to reduce
     assert "tokens=64" in plan(48, 8192, 10240) and "slices=2" in plan(48, 8192, 10240)   # (r05: four-wave 64 x 128 tiles x two slices; r02-r04: wide tiles, three K slices)
     assert plan(64, 11008, 4096, kernel_id=T).startswith("tiled tokens=32") and "slices=8" in plan(48, 11008, 4096)
     assert plan(64, 28672, 8192).startswith("xk tokens=64") and "slices=4" in plan(64, 28672, 8192)               # long K slices fill the chip
-    assert "slices=4" in plan(48, 28672, 8192) and "slices=4" in plan(64, 8192, 8192) and "slices=4" in plan(64, 4096, 8192)
+    assert "slices=4" in plan(48, 28672, 8192) and "slices=4" in plan(64, 8192, 8192, kernel_id=kernels.KERNEL_XK | (2 << 4)) and "slices=4" in plan(64, 4096, 8192, kernel_id=kernels.KERNEL_XK | (2 << 4))
     assert "deferred-zero-table" in plan(3, 13824, 5120, kernel_id=kernels.KERNEL_SKINNY) and "dequant=exact" in plan(3, 18944, 3584, kernel_id=kernels.KERNEL_SKINNY)              # M = 3: the table from 256 channel blocks
     assert plan(8, 11008, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4") and plan(6, 11008, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=1")    # x too large for LDS: share the L2 fragments (r03 audit: among four tiles)
     # [r05] the lean small-M kernels: 1..4 tokens wherever a build exists (G % 128 == 0, k tiles between the waves and 8 / 12 per wave), up to 16
@@ -283,7 +293,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(1, 4096, 12288).startswith("lean ntw=1 waves=8") and plan(1, 4096, 22016).startswith("lean ntw=2 waves=8 tiles_per_wave<=4 grid=688x1")
     assert plan(1, 11008, 4096).startswith("lean ntw=1 waves=16 tiles_per_wave<=8") and plan(1, 8192, 8192).startswith("lean ntw=2 waves=16 tiles_per_wave<=4 grid=256x1")
     assert plan(1, 8192, 10240).startswith("lean ntw=1 waves=8 tiles_per_wave<=8") and plan(4, 4096, 22016).startswith("lean ntw=2")
-    assert plan(16, 4096, 4096).startswith("lean") and plan(8, 4096, 8192).startswith("lean") and plan(17, 4096, 4096).startswith("skinny")
+    assert plan(16, 4096, 4096).startswith("lean") and plan(8, 4096, 8192).startswith("lean") and plan(17, 4096, 4096).startswith("xm")
     assert plan(5, 4096, 12288).startswith("skinny") and plan(7, 4096, 22016).startswith("skinny")          # 5..7 tokens on wide layers: the r01-r04 kernels
     # 8..16 tokens on wide layers: one persistent workgroup per CU (x staged once; a one-block workgroup would fetch more bytes of x than of weights)
     assert plan(8, 4096, 22016).startswith("lean ntw=2 waves=8 tiles_per_wave<=4 grid=256x1") and plan(16, 4096, 22016).startswith("lean ntw=1 waves=8 tiles_per_wave<=4 grid=256x1")
@@ -539,3 +549,27 @@ def test_generated_k_loops_are_what_the_generator_writes(tmp_path):
     assert open(gen.OUT).read() == open(os.path.join(root, "quick_amd", "csrc", "w4a16_xw_loop.inc")).read()
     names = {c.name for c in gen.CONFIGS}
     assert names == {"82", "42", "41", "21"}
+
+
+def test_generated_mid_token_loops_are_what_the_generator_writes(tmp_path, monkeypatch):
+    """quick_amd/csrc/w4a16_xm_loop.inc (the per-wave K loops of the r06 mid-token kernels) is checked in as well: byte for byte what
+    tools/gen_xm_loop.py writes with its default switches.  The generator asserts the hazard distances itself and takes every counted
+    vmcnt from a walk over the dynamic instruction stream; here: every wait that protects an x piece or a weight tile is a counted one
+    (no vmcnt(0) drain inside a loop copy except where the walk says nothing is behind the piece), and the six tile shapes exist."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for k in ("XM_EXP", "XM_OUT", "XM_D", "XM_RS", "XM_TOUCH", "XM_BARRIER", "XM_WFIRST", "XM_W_NT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.syspath_prepend(os.path.join(root, "tools"))
+    spec = importlib.util.spec_from_file_location("gen_xm_loop", os.path.join(root, "tools", "gen_xm_loop.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    body, info = gen.generate()
+    assert body == open(os.path.join(root, "quick_amd", "csrc", "w4a16_xm_loop.inc")).read()
+    assert {c.name for c in gen.CONFIGS} == {"21", "22", "23", "11", "12", "13"}
+    for c in gen.CONFIGS:
+        pro, first, loop, counts = gen.resolve(c, 4 * c.D + 3)
+        for copy in loop:
+            waits = [i.text for i in copy if i.text.startswith("s_waitcnt vmcnt")]
+            assert len(waits) == 5 and all(int(w.split("(")[1].rstrip(")")) <= 63 for w in waits)
+        assert 16 * c.MB * c.PR <= c.AXF and c.VEND <= 128      # accumulators below the x fragments; the 512-thread workgroup's 128 VGPRs
