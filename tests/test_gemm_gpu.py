@@ -105,7 +105,7 @@ SHAPES = [  # (M, K, N, G)
 ]
 
 
-TILED_MFMA32 = TILED | (1 << 8)      # experimental 32x32x16 flavour of the tiled kernel
+TILED_MFMA32 = TILED | (1 << 13)      # experimental 32x32x16 flavour of the tiled kernel
 TILED_16WAVES = TILED | (4 << 8)      # 4 x 4 waves per workgroup
 TILED_WIDE = TILED | (1 << 29)        # 64 x 256 workgroup tiles (the planner's choice once they cover the 256 CUs: large M)
 TILED_BIG = TILED | (1 << 27)         # 128 x 256 tiles run by four waves with 128 accumulators each (large M)

@@ -145,7 +145,7 @@ def test_product_library_has_no_timing_experiments():
     """Kernel-id bits 16-20 select ablation builds (wrong results on purpose) and phase stamps: a QUICK_AMD_TOOLS build only.
     The product library rejects them before any GPU work and exports no such kernels."""
     lib = _lib.load()
-    for kid in (2 | (1 << 16), 3 | (16 << 16), 4 | (4 << 16), 1 << 16, 4 | (1 << 12), 4 | (1 << 8)):   # (the last two: the loader-wave / sixteen-wave exchange-K flavours)
+    for kid in (2 | (1 << 16), 3 | (16 << 16), 4 | (4 << 16), 1 << 16, 4 | (1 << 12), 4 | (1 << 13)):   # (the last two: the loader-wave / sixteen-wave exchange-K flavours)
         rc = lib.quick_w4a16_gemm_f16_ex(None, None, None, None, None, None, None, 0, 512, 4096, 4096, 128, kid, 0, None)
         assert rc == 1 and "QUICK_AMD_TOOLS" in _lib.last_error(), (kid, rc, _lib.last_error())
     import subprocess
