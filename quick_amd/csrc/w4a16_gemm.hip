@@ -1482,15 +1482,18 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   }
   // [r06] mid-token kernels (w4a16_xm.hpp): one workgroup = 32 or 64 tokens x pr x 32 channels for all of K, eight waves splitting K, each with its
   // own x ring and weight queue; x is fetched once per workgroup, in whole cache lines.  Forced: family XM, bits 4-7 = channel pairs per workgroup
-  // (1..3; 0 = choose), bits 8-9 = 1 / 2: 32- / 64-token tiles whatever the count.  What bounds these launches is the CU's vector memory path: it
-  // returns in issue order ACROSS waves, so x pieces (L2) queue behind weight requests (HBM) and the bytes a CU can have in flight (its x
-  // rings + weight queues) over the HBM latency is its rate.  Hence the rule, from the audit of every selection against the
-  // other families on 15 layer shapes x 8 token counts (profiles/r06_xm_audit.txt; QUICK_AMD_XM=0 switches it off for A/B):
-  //   * K <= 8192 (longer K: a workgroup's x alone is > 1 MB per CU -- the exchange-K kernels, whose K slices sit on different CUs, stay ahead);
-  //   * 17..32 tokens: the fewest channel pairs per workgroup that cover the layer in ONE round of workgroups (0.79-1.0 of the others' time);
-  //   * 33..64 tokens: two 32-token tiles x (1 or 2) pairs where that is one round -- N <= 4096 (0.89-0.91), N = 6144 .. 8192 (0.77-0.91): every CU
-  //     busy beats the halved dequantisation of a 64-token tile there; 64-token tiles x 3 pairs on layers of > 2 rounds of pairs up to 48 tokens
-  //     (4096 x 22016: 0.93-0.95); elsewhere the r03-r05 picks are level or ahead and stay.
+  // (1..3; 0 = choose), bits 8-9 = 1 / 2: 32- / 64-token tiles whatever the count.  A launch of these is launch ramp + the workgroup's x and
+  // weight streams one behind the other + the dequantisation + the waves' reduction, with little overlap (profiles/r06_xm_anatomy.txt),
+  // so what counts is ONE round of workgroups, few bytes of x per CU and every CU busy.  The rule, from the audit of every selection against
+  // the other families on 15 layer shapes x 8 token counts (profiles/r06_xm_audit.txt: geomean pick / best 1.0002, worst 1.013; QUICK_AMD_XM=0
+  // switches the family off for A/B; tools/xm_rule_eval.py restates the rule and replays it against an audit file):
+  //   * only layers that ONE round of workgroups covers with <= 3 channel pairs each (N = 27648 .. 57344: the exchange-K kernels stay);
+  //   * 17..32 tokens, K <= 8192: the fewest pairs per workgroup that make one round (0.72-0.97 of the others' time; longer K: the fragment kernels,
+  //     whose x is 16 tokens deep, stay ahead by 7-35 %);
+  //   * 33..64 tokens on layers of <= 128 pairs (N <= 4096): two 32-token tiles x one pair -- every CU busy beats the halved dequantisation --
+  //     up to K = 11008, and up to K = 14336 from 40 tokens (0.83-0.96);
+  //   * 33..64 tokens, wider layers, K <= 8192: two 32-token tiles x <= 2 pairs where that is one round (N = 5120 .. 8192: 0.82-0.93; layers that
+  //     leave > 30 % of the CUs idle only from 56 tokens), else 64-token tiles x the fewest pairs that make one round (N = 10240 .. 22016: 0.87-1.0).
   {
     const bool forced = family == QUICK_KERNEL_XM;
     static const bool xm_on = [] {
@@ -1500,6 +1503,11 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     const int tpg = G / 128;
     const bool envelope = G % 128 == 0 && (tpg & (tpg - 1)) == 0 && (size_t)K * N / 2 < ((size_t)1 << 31) && (size_t)M * K * 2 < ((size_t)1 << 31);   // (a wave without a k tile adds zeros)
     const int pairs = N / 32, cus = cu_count();
+    const auto one_round = [&](int mtiles) {   // fewest channel pairs per workgroup (1..3) that cover the layer in one round, or 0
+      for (int c = 1; c <= 3; ++c)
+        if ((pairs + c - 1) / c * mtiles <= cus) return c;
+      return 0;
+    };
     int mb = 0, pr = 0;
     if (forced) {
       const int tile_req = (kernel >> 8) & 3;   // 1 = 32-token tiles, 2 = 64-token tiles
@@ -1507,18 +1515,21 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       pr = mt_req ? std::max(1, std::min(3, mt_req)) : 1;
       if (!mt_req)
         while (pr < 3 && (long)((pairs + pr - 1) / pr) * ((M + mb * 32 - 1) / (mb * 32)) > cus) ++pr;
-    } else if (family == QUICK_KERNEL_AUTO && xm_on && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M > 16 && M <= 64 && KT >= 8 && KT <= 64) {
+    } else if (family == QUICK_KERNEL_AUTO && xm_on && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M > 16 && M <= 64 && KT >= 8) {
       if (M <= 32) {
-        for (int c = 1; c <= 3 && !pr; ++c)
-          if ((pairs + c - 1) / c <= cus) pr = c;
-        mb = 1;
+        if (KT <= 64 && (pr = one_round(1))) mb = 1;
       } else if (2 * pairs <= cus) {
-        mb = 1, pr = 1;
-      } else if (pairs <= cus && 4 * pairs >= 3 * cus) {
-        mb = 1, pr = 2;
-      } else if (M <= 48 && pairs > 2 * cus && (pairs + 2) / 3 <= cus) {
-        mb = 2, pr = 3;
+        if (KT <= 86 || (KT <= 112 && M >= 40)) mb = 1, pr = 1;
+      } else if (KT <= 64) {
+        const int p1 = one_round(2), p2 = one_round(1);
+        if (p1 && p1 <= 2) {
+          const int wgs = (pairs + p1 - 1) / p1 * 2;
+          if (10 * wgs >= 7 * cus || M >= 56) mb = 1, pr = p1;
+        } else if (p2) {
+          mb = 2, pr = p2;
+        }
       }
+      if (!mb) pr = 0;
     }
     if (forced || pr) {
       const int mtiles = (M + mb * 32 - 1) / (mb * 32);

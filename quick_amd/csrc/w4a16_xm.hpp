@@ -40,7 +40,10 @@ struct XmRest {
 
 // LDS of one workgroup: the eight rings (stages of MB x 8 KiB); the reduction buffer aliases them (32 KiB per 32 x 32 tile, at most
 // four tiles per pass)
-__host__ __device__ constexpr unsigned xm_ring_bytes(int mb) { return (unsigned)mb * 8192u; }   // per wave: one stage
+#ifndef QA_XM_RS
+#define QA_XM_RS 1   // stages of a wave's ring in the 32-token configurations (the generator's XM_RS: A/B builds set both)
+#endif
+__host__ __device__ constexpr unsigned xm_ring_bytes(int mb) { return (unsigned)mb * 8192u * (mb == 1 ? (unsigned)QA_XM_RS : 1u); }   // per wave: one stage (32 tokens: QA_XM_RS)
 __host__ __device__ constexpr unsigned xm_lds_bytes(int mb, int pr) {
   const unsigned ring = 8u * xm_ring_bytes(mb);
   const unsigned units = (unsigned)(mb * pr);

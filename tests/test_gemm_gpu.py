@@ -1643,7 +1643,7 @@ def test_xm_planner_picks_against_oracle_on_layer_shapes(qa, device):
     from quick_amd import kernels as K_
     G = 128
     seen = set()
-    for (K, N) in ((4096, 4096), (4096, 12288), (4096, 22016), (4096, 6144), (8192, 8192), (11008, 4096)):
+    for (K, N) in ((4096, 4096), (4096, 12288), (4096, 22016), (4096, 6144), (8192, 8192), (11008, 4096), (5120, 5120), (4096, 28672)):
         _, iw, s, z = oracle.make_synthetic(1, K, N, G, seed=K + N)
         packed = _pack_dev(iw, s, z, device)
         cols = np.random.default_rng(N).choice(N, 256, replace=False)

@@ -203,7 +203,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     p = plan(128, 4096, 4096)
     # (what workspace_bytes_ex asks for also covers the launch a SiLU * mul epilogue falls back to where the exchange-K plan cannot carry it)
     assert "slices=4" in p and int(p.rsplit("workspace=", 1)[1]) == 65536 + (16 << 20) <= _lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, 0, 0)
-    assert plan(64, 8192, 10240).startswith("xw tokens=64 channels=128") and "grid=160 slices=2" in plan(64, 8192, 10240)   # r05 audit: 80 tiles of 64 x 128 x two slices (r02-r04: wide tiles, three K slices)
+    assert plan(64, 8192, 10240).startswith("xm tokens=64 channels=64 waves=8 grid=160x1")   # r06's mid-token kernels (r05 audit: 80 tiles of 64 x 128 x two exchange slices, level with it; r02-r04: wide tiles, three K slices)
     assert "grid=80x3 ksplit=3" in plan(64, 8192, 10240, kernel_id=kernels.KERNEL_TILED)
     # r01's tiled kernel (kernel_id TILED; the planner's own choice for G < 128): 256-channel tiles by how they quantise onto 256 CUs
     T = kernels.KERNEL_TILED
@@ -223,17 +223,23 @@ def test_plan_describe_pins_the_shape_heuristics():
     X = kernels.KERNEL_XK
     assert plan(512, 4096, 4096, kernel_id=X).startswith("xk tokens=128") and plan(512, 4096, 4096, kernel_id=X | (2 << 4)).startswith(
         "xk tokens=64 channels=128 waves=8 ring=5 queue=4 grid=256 slices=1")                            # r03's bench line: one 64 x 128 tile per CU
-    assert plan(64, 4096, 22016).startswith("xk tokens=64") and "slices=2" in plan(64, 4096, 12288)   # 172 / 96 tiles of 64 x 128 (below 96 tokens: r03's picks)
+    assert plan(64, 4096, 22016, kernel_id=X).startswith("xk tokens=64") and "slices=2" in plan(64, 4096, 12288, kernel_id=X)   # 172 / 96 tiles of 64 x 128 (r03's picks there; AUTO up to 64 tokens: r06's mid-token kernels, below)
     assert plan(128, 4096, 4096).startswith("xw tokens=128 channels=128") and "grid=128 slices=4" in plan(128, 4096, 4096)   # r05 audit: one row of 128 x 128 tiles x four slices (r03-r04: xk 64-token tiles)
-    assert plan(64, 4096, 12288).startswith("xw tokens=64 channels=128") and plan(64, 5120, 5120).startswith("xk tokens=64")        # 33..95 tokens: 64 x 128 x two slices where that is 160..256 workgroups
+    assert plan(80, 5120, 5120).startswith("xw tokens=64 channels=128") and plan(48, 5120, 5120).startswith("skinny ntw=4")        # 33..64 tokens where the mid-token kernels are not ahead: the r03-r05 picks
     # [r06] the mid-token kernels (w4a16_xm.hpp), where the audit has them ahead (profiles/r06_xm_audit.txt): 17..32 tokens -- the fewest channel pairs
     # per workgroup that cover the layer in one round; 33..64 tokens -- two 32-token tiles on layers of <= 8192 channels; K <= 8192
     assert plan(64, 4096, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x2") and plan(33, 4096, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x2")
     assert plan(17, 4096, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x1") and plan(16, 4096, 4096).startswith("lean")
     assert plan(32, 4096, 12288).startswith("xm tokens=32 channels=64 waves=8 grid=192x1") and plan(24, 4096, 22016).startswith("xm tokens=32 channels=96 waves=8 grid=230x1")
     assert plan(64, 4096, 6144).startswith("xm tokens=32 channels=64 waves=8 grid=96x2") and plan(64, 8192, 8192).startswith("xm tokens=32 channels=64 waves=8 grid=128x2")
-    assert plan(48, 4096, 22016).startswith("xm tokens=64 channels=96 waves=8 grid=230x1") and plan(64, 4096, 22016).startswith("xk")
-    assert not plan(64, 11008, 4096).startswith("xm") and not plan(32, 11008, 4096).startswith("xm") and not plan(65, 4096, 4096).startswith("xm")
+    assert plan(48, 4096, 22016).startswith("xm tokens=64 channels=96 waves=8 grid=230x1") and plan(64, 4096, 22016).startswith("xm tokens=64 channels=96 waves=8 grid=230x1")
+    assert plan(64, 4096, 12288).startswith("xm tokens=64 channels=64 waves=8 grid=192x1") and plan(33, 5120, 15360).startswith("xm tokens=64 channels=64 waves=8 grid=240x1")
+    # longer K: two 32-token tiles x one pair on the <= 4096-wide layers from 33 tokens (K = 14336: from 40); the fragment kernels up to 32 tokens
+    assert plan(64, 11008, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x2") and plan(33, 11008, 4096).startswith("xm") and not plan(32, 11008, 4096).startswith("xm")
+    assert plan(40, 14336, 4096).startswith("xm tokens=32 channels=32") and not plan(39, 14336, 4096).startswith("xm") and not plan(64, 13824, 5120).startswith("xm")
+    # layers one round does not cover with three pairs per workgroup, and layers that leave > 30 % of the CUs idle below 56 tokens: the r03-r05 picks
+    assert not plan(64, 4096, 28672).startswith("xm") and not plan(24, 8192, 57344).startswith("xm") and not plan(64, 28672, 8192).startswith("xm")
+    assert not plan(48, 5120, 5120).startswith("xm") and plan(56, 5120, 5120).startswith("xm tokens=32 channels=64 waves=8 grid=80x2") and not plan(65, 4096, 4096).startswith("xm")
     assert not plan(64, 4096, 4096, G=64).startswith("xm") and not plan(64, 4608, 4096, G=384).startswith("xm")               # G a power-of-two multiple of 128
     assert plan(40, 4096, 4096, kernel_id=kernels.KERNEL_XM | (3 << 4) | (2 << 8)).startswith("xm tokens=64 channels=96 waves=8 grid=43x1")   # forced: pairs, 64-token tiles; ragged last block
     # r04: the four-wave kernels with generated loops (w4a16_xw.hpp) from 160 tokens (96 on wide layers), picked by their own launch-time model
@@ -277,11 +283,11 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(6, 4096, 12288).startswith("skinny ntw=4 waves=8 x=l2") and plan(10, 11008, 4096).startswith("skinny ntw=4 waves=8 x=l2")
     # third audit (17..64 tokens, layer shapes the rules were not tuned on): the four-tile skinny kernel by its own geometry
     assert plan(32, 4096, 6144, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4") and plan(32, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4")    # one round of workgroups, <= 64 stages each (AUTO at 17..32 tokens: the r06 mid-token kernels)
-    assert plan(48, 5120, 5120).startswith("skinny ntw=4") and plan(64, 5120, 5120).startswith("xk tokens=64")    # 320 skinny workgroups would be two rounds; r03: 40 tiles x 4 slices
-    assert plan(32, 13824, 5120).startswith("tiled") and "slices=8" in plan(48, 14336, 4096)                      # slices of > 64 stages; r03 from 33 tokens: 32 tiles x 8 slices of 14 stages
+    assert plan(48, 5120, 5120).startswith("skinny ntw=4") and plan(55, 5120, 5120).startswith("xk tokens=64")    # 320 skinny workgroups would be two rounds; r03: 40 tiles x 4 slices (from 56 tokens: r06's mid-token kernels)
+    assert plan(32, 13824, 5120).startswith("tiled") and "slices=8" in plan(39, 14336, 4096)                      # slices of > 64 stages; r03 from 33 tokens: 32 tiles x 8 slices of 14 stages (from 40 tokens: r06's mid-token kernels)
     assert "tokens=32 channels=128 waves=8 grid=192x1 ksplit=1" in plan(64, 4096, 12288, kernel_id=T)              # twice the tiles, nothing to reduce
-    assert "tokens=64" in plan(48, 8192, 10240) and "slices=2" in plan(48, 8192, 10240)   # (r05: four-wave 64 x 128 tiles x two slices; r02-r04: wide tiles, three K slices)
-    assert plan(64, 11008, 4096, kernel_id=T).startswith("tiled tokens=32") and "slices=8" in plan(48, 11008, 4096)
+    assert plan(48, 8192, 10240).startswith("xm tokens=64 channels=64 waves=8 grid=160x1")   # (r06; r05: four-wave 64 x 128 tiles x two slices; r02-r04: wide tiles, three K slices)
+    assert plan(64, 11008, 4096, kernel_id=T).startswith("tiled tokens=32") and "slices=8" in plan(48, 11008, 4096, kernel_id=X)
     assert plan(64, 28672, 8192).startswith("xk tokens=64") and "slices=4" in plan(64, 28672, 8192)               # long K slices fill the chip
     assert "slices=4" in plan(48, 28672, 8192) and "slices=4" in plan(64, 8192, 8192, kernel_id=kernels.KERNEL_XK | (2 << 4)) and "slices=4" in plan(64, 4096, 8192, kernel_id=kernels.KERNEL_XK | (2 << 4))
     assert "deferred-zero-table" in plan(3, 13824, 5120, kernel_id=kernels.KERNEL_SKINNY) and "dequant=exact" in plan(3, 18944, 3584, kernel_id=kernels.KERNEL_SKINNY)              # M = 3: the table from 256 channel blocks
@@ -558,7 +564,7 @@ def test_generated_mid_token_loops_are_what_the_generator_writes(tmp_path, monke
     (no vmcnt(0) drain inside a loop copy except where the walk says nothing is behind the piece), and the six tile shapes exist."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for k in ("XM_EXP", "XM_OUT", "XM_D", "XM_RS", "XM_TOUCH", "XM_BARRIER", "XM_WFIRST", "XM_W_NT"):
+    for k in ("XM_EXP", "XM_OUT", "XM_D", "XM_RS", "XM_TOUCH", "XM_BARRIER", "XM_WFIRST", "XM_W_NT", "XM_JITQ", "XM_SBAR", "XM_BURST"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.syspath_prepend(os.path.join(root, "tools"))
     spec = importlib.util.spec_from_file_location("gen_xm_loop", os.path.join(root, "tools", "gen_xm_loop.py"))

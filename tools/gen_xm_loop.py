@@ -15,7 +15,8 @@ A STAGE is one k tile (128 k = 8 k16 steps), a QUARTER two k16 steps (32 k: 64 b
          workgroup where these reach 116-136 (tools/x_dma_bw.hip) -- into the wave's ring of two half-stage slots.  Half h is refilled with the
          pieces of stage s + 1 during quarter 2 h + 1 of stage s (its last fragments were read at the head of quarter 2 h), ONE instruction
          every few MFMAs -- a burst holds the wave at the vector-memory issue
-  W      PR x (lo, hi dwordx4 + the (scale, zero) word), HBM -> VGPR queue of D stages; W(s + D) leaves at the end of stage s
+  W      PR x (lo, hi dwordx4 + the (scale, zero) word), HBM -> VGPR queue of D stages; one pair: W(s + D) leaves at the end of stage s; two
+         and three pairs: W(s + 1) leaves in quarter 1 of stage s behind that quarter's x pieces (Cfg.jitq)
   reads  MB x 2 ds_read_b128 per quarter, one quarter ahead, double-buffered, into the last accumulator registers (MFMA B operands)
   math   8 PR dequantisation chains (13 VALU, exact form: fp16((w - z) s) as the reference's dequantize_s4_to_fp16x2_fused + sub + mul),
          each feeding MB v_mfma_f32_32x32x16_f16; chain n + 1 is interleaved with the MFMAs of chain n
@@ -58,6 +59,10 @@ BARRIER = os.environ.get("XM_BARRIER", "0") != "0"   # prologue barrier between 
 WFIRST = os.environ.get("XM_WFIRST", "1") != "0"     # W(0) in front of x(0) in the prologue (A/B switch)
 DQ = os.environ.get("XM_D", "")                      # queue depths of the six configurations, e.g. 2,2,2,2,2,2 (A/B switch)
 W_NT = " nt" if os.environ.get("XM_W_NT", "1") != "0" else ""   # the weights are read once: streaming cache policy (as the lean kernels)
+JITQ_ENV = os.environ.get("XM_JITQ", "")                # "q": every configuration requests W(s + 1) in quarter q of stage s; "-1": none does (A/B switch; default: Cfg.jitq)
+SBAR = os.environ.get("XM_SBAR", "")                   # quarters at whose head every stage has a workgroup barrier (e.g. "0" or "1,3"): phase-locks the waves' requests (A/B switch;
+                                                       # only for shapes whose waves own equally many k tiles)
+BURST = os.environ.get("XM_BURST", "0") != "0"         # x pieces of a half in one burst at the head of its quarter instead of one every few MFMAs (A/B switch)
 EXP = int(os.environ.get("XM_EXP", "0"))   # timing experiments (wrong results; never checked in): 1 no MFMAs, 2 no vector memory, 4 no dequantisation,
                                             # 8 no fragment reads, 16 no weight loads, 32 no x pieces (16 / 32: and no counted waits)
 
@@ -73,9 +78,17 @@ def need(tag):
 
 
 class Cfg:
-    def __init__(self, MB, PR, D, VBASE=24, RS=1):
+    def __init__(self, MB, PR, D, VBASE=24, RS=1, jitq=-1):
+        # jitq >= 0: W(s + 1) leaves in quarter jitq of stage s, right behind that quarter's x pieces, into a queue of two slots -- instead of
+        # W(s + D) at the end of stage s.  A wave's loads return in issue order, so an x piece waits for every weight request in front of it:
+        # weights requested D stages ahead hold back x that is needed half a stage ahead.  Measured (profiles/r06_xm_anatomy.txt): 3-9 % off the
+        # launches of two and three channel pairs, level or 2-5 % slower with one pair (its whole weight set is in flight from the prologue).
+        if JITQ_ENV:
+            jitq = int(JITQ_ENV)
+        if jitq >= 0 and not DQ:
+            D = 2
         assert MB in (1, 2) and PR in (1, 2, 3) and D >= 2 and RS in (1, 2) and D % RS == 0
-        self.MB, self.PR, self.D, self.VBASE, self.RS = MB, PR, D, VBASE, RS   # RS: stages of the wave's x ring
+        self.MB, self.PR, self.D, self.VBASE, self.RS, self.jitq = MB, PR, D, VBASE, RS, jitq   # RS: stages of the wave's x ring
         self.NX = 4 * MB                    # LDS-DMA instructions per half stage (8 rows x 128 B each)
         self.LW = 3 * PR                    # weight-side loads per stage
         self.HB = MB * 4096                 # bytes of a half-stage slot
@@ -242,6 +255,15 @@ class Cfg:
                 out.append(need(("x", sa, (q + 1) // 2) if q < 3 else ("x", sa + 1, 0)))
                 out += self.x_reads((q + 1) % 4, (q + 1) % 2, rs if q < 3 else (rs + 1) % RS)
                 pend = self.x_dma(q // 2, ("x", sa + RS, q // 2), rs) if q % 2 == 1 else []
+                if SBAR and str(q) in SBAR.split(","):
+                    out.append(I("s_barrier", "wait"))
+                if BURST and pend:
+                    for m0w, ld in pend:
+                        out += [m0w, I("s_nop 0", "salu"), ld]
+                    pend = []
+                if q == self.jitq:
+                    out += self.w_offsets(1)
+                    pend += [(I("s_nop 0", "salu"), ld) for ld in self.w_loads((d + 1) % self.D, ("w", sa + 1))]
                 npend = len(pend)
                 mi = 0
             nxt = chains[n + 1] if n + 1 < N else []
@@ -268,8 +290,9 @@ class Cfg:
                 out.append(I("s_waitcnt lgkmcnt(0)", "wait"))
         # W(sa + D) into this stage's queue slot (behind the x pieces of quarter 3: the weights' trip to HBM does not sit in front of them in the
         # in-order queue), then the counter
-        out += self.w_offsets(self.D)
-        out += self.w_loads(d, ("w", sa + self.D))
+        if self.jitq < 0:
+            out += self.w_offsets(self.D)
+            out += self.w_loads(d, ("w", sa + self.D))
         out.append(I(f"s_add_u32 {s(S_S)}, {s(S_S)}, 1", "salu"))
         if stamp is not None:
             out.append(I(f"s_memrealtime {sr(S_STAMP + 4 + 2 * stamp, 2)}", "salu"))
@@ -318,7 +341,7 @@ class Cfg:
                 pro.append(ld)
                 if j + 1 < 2 * self.PR:
                     pro.append(I(f"s_add_u32 {s(S_KT)}, {s(S_KT)}, {s(S_G)}", "salu"))
-        for d in range(1 if WFIRST else 0, D):
+        for d in range(1 if WFIRST else 0, D if self.jitq < 0 else 1):
             pro += self.w_offsets(d)
             pro += self.w_loads(d, ("w", d))
         pro += [need(("x", 0, 0))]
@@ -438,7 +461,8 @@ def run_macro(c):
 _RS = int(os.environ.get("XM_RS", "1"))   # ring stages of the 32-token configurations (A/B switch; two measured level with one: the second stage's pieces
                                           # sit in front of the weights in the in-order queue and the first tile starts later by what the loop gains)
 _D = [int(x) for x in DQ.split(",")] if DQ else [4, 4, 2, 4, 4, 2]
-CONFIGS = [Cfg(2, 1, _D[0]), Cfg(2, 2, _D[1]), Cfg(2, 3, _D[2], VBASE=16), Cfg(1, 1, _D[3], RS=_RS), Cfg(1, 2, _D[4], RS=_RS), Cfg(1, 3, _D[5], VBASE=16, RS=_RS)]
+CONFIGS = [Cfg(2, 1, _D[0]), Cfg(2, 2, _D[1], jitq=1), Cfg(2, 3, _D[2], VBASE=16, jitq=1), Cfg(1, 1, _D[3], RS=_RS), Cfg(1, 2, _D[4], RS=_RS, jitq=1),
+           Cfg(1, 3, _D[5], VBASE=16, RS=_RS, jitq=1)]
 
 
 def generate():
