@@ -963,244 +963,6 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_tiled_kernel(const GemmArg
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
 
-template <int BMT, int TN, int WK>
-__device__ __forceinline__ void tiled32_store_x(const TiledCtx<BMT, TN, WK>& c, char* buf, int lane, const u32x4 (&xr)[BMT]) {
-  const int r16 = lane & 15, q = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < BMT; ++i) {
-    const int f = c.wave * BMT + i;  // wave-uniform: (k-tile, k32 step t, 16-token tile a)
-    const int kt = f / (4 * BMT), t = (f / BMT) & 3, a16 = f % BMT;
-    const int frag = (kt * 8 + 2 * t + (q >> 1)) * (BMT / 2) + (a16 >> 1);
-    *(u32x4*)(buf + frag * 1024 + (16 * (a16 & 1) + r16 + 32 * (q & 1)) * 16) = xr[i];
-  }
-}
-
-template <int BMT, int TN, int WK, int GM>
-__device__ __forceinline__ void tiled32_compute(const TiledCtx<BMT, TN, WK>& c, const char* sb, int s, const u32x4 (&w)[TN],
-                                                const uint32_t (&gs)[TN][groups_per_tile<GM>()],
-                                                floatx16 (&acc)[TN / 2][BMT / 2], int lane) {
-  constexpr int NG = groups_per_tile<GM>();
-  if (c.kt_lo + WK * s + c.wk >= c.kt_hi) {  // wave-uniform: a ragged last stage has no tile for this wave
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {  // "use" the loads so that both paths leave the same ones pending (see the K loop)
-      asm volatile("" ::"v"(w[j]));
-#pragma unroll
-      for (int i = 0; i < NG; ++i) asm volatile("" ::"v"(gs[j][i]));
-    }
-    return;
-  }
-  // after the lane shuffle, lanes 16-31 and 48-63 hold the second tile of a pair: pick that tile's constants there
-  const bool second = (lane >> 4) & 1;
-  GroupQ grp[TN / 2][NG];
-#pragma unroll
-  for (int p = 0; p < TN / 2; ++p)
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      const GroupRaw r{second ? gs[2 * p + 1][i] : gs[2 * p][i]};
-      grp[p][i] = make_group(r);
-    }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    uint32_t araw[TN / 2][2];
-#pragma unroll
-    for (int p = 0; p < TN / 2; ++p) {
-      const u32x2v s1 = __builtin_amdgcn_permlane16_swap(w[2 * p][t], w[2 * p + 1][t], false, false);
-      const u32x2v s2 = __builtin_amdgcn_permlane32_swap(s1[0], s1[1], false, false);
-      araw[p][0] = s2[0];
-      araw[p][1] = s2[1];
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      half8_t bf[BMT / 2];
-#pragma unroll
-      for (int m2 = 0; m2 < BMT / 2; ++m2) bf[m2] = *(const half8_t*)(sb + ((2 * t + kk) * (BMT / 2) + m2) * 1024);
-#pragma unroll
-      for (int p = 0; p < TN / 2; ++p) {
-        const half8_t af = dequant8(araw[p][kk], grp[p][group_slot<GM>(t)]);
-#pragma unroll
-        for (int m2 = 0; m2 < BMT / 2; ++m2)
-          acc[p][m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[m2], acc[p][m2], 0, 0, 0);
-      }
-    }
-  }
-}
-
-template <int BMT, int TN, int WK, int GM>
-__global__ __launch_bounds__(256 * WK) void w4a16_tiled32_kernel(const GemmArgs a) {
-  static_assert(TN % 2 == 0 && BMT % 2 == 0, "32x32 tiles pair up 16-channel and 16-token tiles");
-  constexpr int NG = groups_per_tile<GM>();
-  constexpr int FRAGS = 4 * WK * BMT;
-  constexpr int STAGE_BYTES = FRAGS * 1024;
-  static_assert((WK - 1) * 4 * TN * BMT * 1024 <= 2 * STAGE_BYTES, "epilogue exchange must fit in the stage buffers");
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * STAGE_BYTES
-
-  const int lane = threadIdx.x & 63;
-  const int wave = uniform(threadIdx.x >> 6);
-  const int wn = wave & 3, wk = wave >> 2;
-  const int n16 = lane & 15, q = lane >> 4;
-  const int NB = a.N / (64 * TN);
-  int nb = blockIdx.x % NB, mb = blockIdx.x / NB;
-  if (a.xcd_gm > 0) {
-    // Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it).  Give every XCD a compact
-    // rectangle of tiles so that its private L2 fetches few distinct x rows AND few distinct weight columns.
-    const int MB = gridDim.x / NB, gn = 8 / a.xcd_gm;
-    const int mcnt = MB / a.xcd_gm, ncnt = NB / gn;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    mb = (xcd / gn) * mcnt + idx / ncnt;
-    nb = (xcd % gn) * ncnt + idx % ncnt;
-  }
-  const int ks = blockIdx.y;
-  const int KT = a.K >> 7;
-  TiledCtx<BMT, TN, WK> c;
-  c.kt_lo = ks * a.kt_per_split;
-  c.kt_hi = min(KT, c.kt_lo + a.kt_per_split);
-  c.wave = wave;
-  c.wk = wk;
-  const int nstage = (c.kt_hi - c.kt_lo + WK - 1) / WK;
-  const int m0 = mb * BMT * 16;
-  const int nt0 = (nb * 4 + wn) * TN;
-
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    c.wp[j] = a.QW + (size_t)(nt0 + j) * KT * 64 + lane;
-    c.ncol[j] = (nt0 + j) * 16 + n16;
-  }
-#pragma unroll
-  for (int i = 0; i < BMT; ++i) {
-    const int f = wave * BMT + i, t = (f / BMT) & 3, mt = f % BMT;
-    c.xkt[i] = f / (4 * BMT);
-    const int row = min(m0 + mt * 16 + n16, a.M - 1);
-    c.xsrc[i] = a.X + (size_t)row * a.K + 32 * t + 8 * q;
-  }
-
-  floatx16 acc[TN / 2][BMT / 2];
-#pragma unroll
-  for (int p = 0; p < TN / 2; ++p)
-#pragma unroll
-    for (int m2 = 0; m2 < BMT / 2; ++m2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[p][m2][r] = 0.f;
-
-  u32x4 xr[BMT];
-  u32x4 w[2][TN];
-  uint32_t gs[2][TN][NG];
-  const int rd = wk * (4 * BMT * 1024) + lane * 16;
-
-  if (nstage > 0) {
-    tiled_load_w<BMT, TN, WK, GM, 4>(c, a, 0, w[0], gs[0]);
-    tiled_load_x<BMT, TN, WK, 4>(c, 0, xr);
-    tiled_load_w<BMT, TN, WK, GM, 4>(c, a, 1, w[1], gs[1]);
-    tiled32_store_x<BMT, TN, WK>(c, smem, lane, xr);
-    tiled_load_x<BMT, TN, WK, 4>(c, 1, xr);
-  }
-  __syncthreads();
-
-  for (int s0 = 0; s0 < nstage; s0 += 2) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int s = s0 + u;
-      if (s >= nstage) goto k_loop_done;
-      char* const cur = smem + u * STAGE_BYTES;
-      char* const nxt = smem + (u ^ 1) * STAGE_BYTES;
-      tiled32_store_x<BMT, TN, WK>(c, nxt, lane, xr);
-      tiled_load_x<BMT, TN, WK, 4>(c, s + 2, xr);
-      tiled32_compute<BMT, TN, WK, GM>(c, cur + rd, s, w[u], gs[u], acc, lane);
-      tiled_load_w<BMT, TN, WK, GM, 4>(c, a, s + 2, w[u], gs[u]);
-      __syncthreads();
-    }
-  }
-k_loop_done:
-
-  // per-lane accumulator chunk (p, m2, r4): channels nt0*16 + p*32 + 8*r4 + 4*(lane/32) .. +3 of token m0 + m2*32 + lane%32
-  constexpr int CH = (TN / 2) * (BMT / 2) * 4;  // floatx4 chunks per lane
-  floatx4* ex = (floatx4*)smem;                 // [wk-1][wn][chunk][lane]
-  auto chunk = [&](int p, int m2, int r4) {
-    return floatx4{acc[p][m2][4 * r4], acc[p][m2][4 * r4 + 1], acc[p][m2][4 * r4 + 2], acc[p][m2][4 * r4 + 3]};
-  };
-  if (wk > 0) {
-#pragma unroll
-    for (int p = 0; p < TN / 2; ++p)
-#pragma unroll
-      for (int m2 = 0; m2 < BMT / 2; ++m2)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4)
-          ex[(((wk - 1) * 4 + wn) * CH + (p * (BMT / 2) + m2) * 4 + r4) * 64 + lane] = chunk(p, m2, r4);
-  }
-  __syncthreads();
-  floatx4 v[TN / 2][BMT / 2][4];
-  if (wk == 0) {
-#pragma unroll
-    for (int p = 0; p < TN / 2; ++p)
-#pragma unroll
-      for (int m2 = 0; m2 < BMT / 2; ++m2)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          v[p][m2][r4] = chunk(p, m2, r4);
-#pragma unroll
-          for (int k = 1; k < WK; ++k) v[p][m2][r4] += ex[(((k - 1) * 4 + wn) * CH + (p * (BMT / 2) + m2) * 4 + r4) * 64 + lane];
-        }
-  }
-  if (a.ksplit > 1) {
-    constexpr unsigned SLAB_BYTES = 4 * TN * BMT * 1024;
-    const __amdgpu_buffer_rsrc_t rs =
-        slab_rsrc(a.slabs + (size_t)blockIdx.x * a.ksplit * (SLAB_BYTES / 4), a.ksplit * SLAB_BYTES);
-    const unsigned my = (wn * CH * 64 + lane) * 16;
-    if (wk == 0) {
-#pragma unroll
-      for (int p = 0; p < TN / 2; ++p)
-#pragma unroll
-        for (int m2 = 0; m2 < BMT / 2; ++m2)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4)
-            slab_store(rs, ks * SLAB_BYTES + my + ((p * (BMT / 2) + m2) * 4 + r4) * 1024, v[p][m2][r4]);
-    }
-    if (!splitk_arrive(a.counters + blockIdx.x, a.ksplit, (unsigned*)smem)) return;
-    if (wk == 0) {
-      floatx4 own[TN / 2][BMT / 2][4];
-#pragma unroll
-      for (int p = 0; p < TN / 2; ++p)
-#pragma unroll
-        for (int m2 = 0; m2 < BMT / 2; ++m2)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) own[p][m2][r4] = v[p][m2][r4];
-      for (int o = 0; o < a.ksplit; ++o) {
-#pragma unroll
-        for (int p = 0; p < TN / 2; ++p)
-#pragma unroll
-          for (int m2 = 0; m2 < BMT / 2; ++m2)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-              const floatx4 part = o == ks ? own[p][m2][r4]
-                                           : slab_load(rs, o * SLAB_BYTES + my + ((p * (BMT / 2) + m2) * 4 + r4) * 1024);
-              v[p][m2][r4] = o == 0 ? part : v[p][m2][r4] + part;
-            }
-      }
-    }
-  }
-  if (wk == 0) {
-    const int tok = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int p = 0; p < TN / 2; ++p)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int nc = (nt0 + 2 * p) * 16 + 8 * r4 + 4 * half;
-        half4_t b = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-        if (a.bias) b = *(const half4_t*)(a.bias + nc);
-#pragma unroll
-        for (int m2 = 0; m2 < BMT / 2; ++m2) {
-          const int m = m0 + m2 * 32 + tok;
-          if (m < a.M) {
-            half4_t res = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-            if (a.residual) res = *(const half4_t*)(a.residual + (size_t)m * a.N + nc);
-            half4_t o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (half_t)(v[p][m2][r4][r] + (float)b[r] + (float)res[r]);
-            *(half4_t*)(a.Y + (size_t)m * a.N + nc) = o;
-          }
-        }
-      }
-  }
-}
 
 // empty kernel with the GEMM's launch shape: what the dispatch-duration clock reads with no work at all
 __global__ __launch_bounds__(512) void w4a16_empty_kernel(unsigned* sink) {
@@ -1278,7 +1040,6 @@ struct Plan {
   int xcd_gm;  // tiled: rows of the XCD grid over the tile grid (0 = plain order)
   bool wn2;    // tiled: 2 x 4 wave grid (kernel bit 15)
   int tch;     // tiled: channels per workgroup tile, 128 or 256
-  bool mfma32; // tiled: v_mfma_f32_32x32x16_f16 flavour (kernel bit 13; measured slower than 16x16x32 in r01)
   int xk_nbuf, xk_wd;  // exchange-K: x ring slots, weight queue depth (wide_mb = token tiles of 32, ksplit = slices that exchange)
   bool xk_loader;      // exchange-K: the twelve-wave flavour (four loader waves; kernel bit 12)
   int xk_kq;           // exchange-K: K groups of waves per workgroup, 2 (eight waves) or 4 (sixteen; kernel bit 13)
@@ -1396,13 +1157,15 @@ static int cu_count() {
 //   15 tiled: 2 x 4 wave grid              16-20 tiled: ablation / phase stamps 21 skinny: flip the persistence default
 //   22-24 skinny: persistent slots per CU  25 skinny: exact dequantisation      26 skinny: force the table deferred-zero path
 //   27 tiled: force 128 x 256 four-wave tiles 28 skinny: no fragment deferred-zero   29 / 30 tiled: force / forbid 256-channel tiles
-static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, bool allow_xk = true) {
+static int group_mode(int G) { return G == 128 ? 0 : (G % 128 == 0 ? 1 : (G == 64 ? 2 : (G == 32 ? 3 : 4))); }
+
+// with_ln: the launch carries an RMSNorm prologue -- AUTO keeps to the kernels that have one (no mid-token, no eight-tile fragment launch)
+static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, bool allow_xk = true, bool with_ln = false) {
   Plan p{};
   const int KT = K / 128;
   const int family = kernel & 15, mt_req = (kernel >> 4) & 15, waves_req = ((kernel >> 8) & 15) * 4;
   const bool no_xlds = (kernel >> 12) & 1;
   p.ablate = (kernel >> 16) & 31;
-  p.mfma32 = ((kernel >> 13) & 1) && p.ablate == 0;
   p.wn2 = (kernel >> 15) & 1;
   // [r05] lean small-M kernels (w4a16_lean.hpp): one workgroup per 16 tokens x (ntw x 16) channels, `waves` waves split K and request all
   // their k tiles up front.  Forced: family LEAN, bits 8-11 waves / 4 (1, 2, 4; 0 = choose), bits 4-7 channel tiles per workgroup (1, 2;
@@ -1487,7 +1250,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   // so what counts is ONE round of workgroups, few bytes of x per CU and every CU busy.  The rule, from the audit of every selection against
   // the other families on 15 layer shapes x 8 token counts (profiles/r06_xm_audit.txt: geomean pick / best 1.0002, worst 1.013; QUICK_AMD_XM=0
   // switches the family off for A/B; tools/xm_rule_eval.py restates the rule and replays it against an audit file):
-  //   * only layers that ONE round of workgroups covers with <= 3 channel pairs each (N = 27648 .. 57344: the exchange-K kernels stay);
+  //   * K >= 4096 (the audit's layers), and only layers that ONE round of workgroups covers with <= 3 channel pairs each (N = 27648 .. 57344: the
+  //     exchange-K kernels stay);
   //   * 17..32 tokens, K <= 8192: the fewest pairs per workgroup that make one round (0.72-0.97 of the others' time; longer K: the fragment kernels,
   //     whose x is 16 tokens deep, stay ahead by 7-35 %);
   //   * 33..64 tokens on layers of <= 128 pairs (N <= 4096): two 32-token tiles x one pair -- every CU busy beats the halved dequantisation --
@@ -1515,7 +1279,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       pr = mt_req ? std::max(1, std::min(3, mt_req)) : 1;
       if (!mt_req)
         while (pr < 3 && (long)((pairs + pr - 1) / pr) * ((M + mb * 32 - 1) / (mb * 32)) > cus) ++pr;
-    } else if (family == QUICK_KERNEL_AUTO && xm_on && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M > 16 && M <= 64 && KT >= 8) {
+    } else if (family == QUICK_KERNEL_AUTO && xm_on && !with_ln && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M > 16 && M <= 64 && KT >= 32) {   // (K >= 4096: what the audit measured)
       if (M <= 32) {
         if (KT <= 64 && (pr = one_round(1))) mb = 1;
       } else if (2 * pairs <= cus) {
@@ -1736,7 +1500,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // [r04] where the r02 model's pick is the 256 x 256 tile with ONE K slice, the four-wave kernel with the generated 256 x 256 loop runs it
     // instead: 0.935-0.965 of the hipcc-scheduled kernel's time on 28 prefill shapes of 1024..8192 tokens in one session, bit-identical
     // results (scripts/archive/r04_gpu_xw82.sh, profiles/r04_xw256_sweep.jsonl; 4096^3 117.3 -> 111.6 us, 8192 x 4096 x 22016 1232 -> 1170).
-    // QUICK_AMD_XW256=0 keeps r02's kernel (the A/B switch).
+    // QUICK_AMD_XW256=0 keeps r02's kernel (the A/B switch; since r06 that kernel is only in QUICK_AMD_TOOLS builds -- it spills 92 bytes per lane --
+    // and the product answers the switch with 128 x 256 tiles).
     if (best > 0 && wide_mb == 8 && !xw_auto_mb && !xk_auto_mb && N % 256 == 0 && (G / 128 & (G / 128 - 1)) == 0 && KT >= 2 &&
         wide_split((long)((M + 255) / 256) * (N / 256)) == 1 &&
         (size_t)M * (size_t)K * 2 < ((size_t)1 << 32) && (size_t)M * (size_t)N * 2 < ((size_t)1 << 32)) {
@@ -1901,6 +1666,10 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     if (mb != 2 && mb != 4 && mb != 8) mb = M > 128 ? 8 : (M > 64 ? 4 : 2);
     if (pairs != 1 && pairs != 2) pairs = 2;
     if (N % (pairs * 128) != 0) pairs = 1;
+#ifndef QUICK_AMD_TOOLS
+    if (mb == 8 && pairs == 2) mb = 4;   // [r06] no register-spilling kernel in the product: where the generated 256 x 256 loop cannot take a launch (K split, 64-bit offsets,
+                                         // G not a power-of-two multiple of 128) 128 x 256 tiles run instead of r02's hipcc-scheduled 256 x 256 tile
+#endif
     p.wide_mb = mb;
     p.wide_pairs = pairs;
     // bit 12: no ring (the double-buffered kernel at every tile size); bits 22-24: ring slots (0 = as many as fit, up to 6);
@@ -2006,7 +1775,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // N = 4096, 256 x 12288, 128 x 22016, M = 384..512 at K = N = 8192); just above a multiple of 256 the second, nearly
     // empty round loses (192 x 22016: 80 against 70 us; 512 x 11008: 84 against 75) [r01 sweep, one session].
     // Kernel bit 29 forces them, bit 30 forbids them.
-    const bool wide_ok = p.mt == 4 && p.waves == 8 && !p.wn2 && !p.mfma32 && !p.ablate && N % 256 == 0 && !mt_req && !model_tiled_mt;
+    const bool wide_ok = p.mt == 4 && p.waves == 8 && !p.wn2 && !p.ablate && N % 256 == 0 && !mt_req && !model_tiled_mt;
     const long wtiles = (long)(N / 256) * ((M + 63) / 64);
     const long nfull = 2 * wtiles / 512, nrem = 2 * wtiles % 512;
     const double narrow_cost = 1.65 * nfull + (nrem == 0 ? 0.0 : (nrem <= 256 ? 1.0 : 1.65));
@@ -2130,7 +1899,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         return e ? atoi(e) : 1;
       }();
       const bool asked = family == QUICK_KERNEL_SKINNY && mt_req == 8;
-      const bool auto_ok = frag8_env != 0 && family == QUICK_KERNEL_AUTO && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k == 0 && p.mt == 4 && p.dz &&
+      const bool auto_ok = frag8_env != 0 && !with_ln && family == QUICK_KERNEL_AUTO && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k == 0 && p.mt == 4 && p.dz &&
                            !p.xlds && (long)K * N >= 60L * 1000 * 1000;
       if ((asked || auto_ok) && G == 128 && M >= 9 && M <= 16 && N % 128 == 0 && KT % 8 == 0 && (long)M * K * 2 < (1L << 31)) {
         int best_ks = 0, best_t = 0;
@@ -2163,6 +1932,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       }
     }
   }
+  // [r06] sixteen waves (128 registers per lane): one-tile workgroups, and the table flavour only with <= 2 units per k tile -- the other builds
+  // spilled registers and were never the planner's own pick; a forced request runs eight waves
+  if (p.kernel == QUICK_KERNEL_SKINNY && p.waves == 16 && (p.mt != 1 || (p.dz && group_mode(G) > 2))) p.waves = 8;
   return p;
 }
 
@@ -2185,13 +1957,12 @@ static size_t workspace_need(const Plan& p) {
 static bool xk_takes_silu(const Plan& p) { return (p.wide_mb / 2 * 16) % (16 * p.ksplit) == 0; }
 // The planner does not see the epilogue; where it picks an exchange-K launch that cannot carry SiLU * mul, the launch falls back to
 // the plan without those kernels.  The workspace must serve either.
-static Plan plan_for(int M, int K, int N, int G, int kernel, int grid_split_k, bool silu) {
-  Plan p = make_plan(M, K, N, G, kernel, grid_split_k);
+static Plan plan_for(int M, int K, int N, int G, int kernel, int grid_split_k, bool silu, bool with_ln = false) {
+  Plan p = make_plan(M, K, N, G, kernel, grid_split_k, true, with_ln);
   if (silu && (kernel & 15) == QUICK_KERNEL_AUTO && p.kernel == QUICK_KERNEL_XK && !xk_takes_silu(p)) p = make_plan(M, K, N, G, kernel, grid_split_k, false);
   return p;
 }
 
-static int group_mode(int G) { return G == 128 ? 0 : (G % 128 == 0 ? 1 : (G == 64 ? 2 : (G == 32 ? 3 : 4))); }
 
 template <int NTW, int WAVES, bool XLDS, bool DZ, bool LN = false>
 static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) {
@@ -2233,8 +2004,9 @@ static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) 
       case 0: QA_SKINNY(0); break;
       case 1: QA_SKINNY(1); break;
       case 2: QA_SKINNY(2); break;
-      case 3: QA_SKINNY(3); break;
-      default: QA_SKINNY(4); break;
+      // (sixteen waves of the table flavour with > 2 units per k tile: no build -- it spilled; make_plan hands such a request eight waves)
+      case 3: if constexpr (!(WAVES == 16 && DZ)) QA_SKINNY(3); break;
+      default: if constexpr (!(WAVES == 16 && DZ)) QA_SKINNY(4); break;
     }
   }
 #undef QA_SKINNY
@@ -2258,13 +2030,14 @@ static void launch_skinny(const Plan& p, const GemmArgs& a, const Launch& L) {
       return;
     }
   }
+  // (sixteen waves: one-tile workgroups only -- make_plan never asks for more, and with 128 registers per lane the two- and four-tile builds spilled)
   if (p.xlds) {
     if (p.waves == 4) launch_skinny_gm<NTW, 4, true, false>(p, a, L);
-    else if (p.waves == 16) launch_skinny_gm<NTW, 16, true, false>(p, a, L);
+    else if (NTW == 1 && p.waves == 16) launch_skinny_gm<1, 16, true, false>(p, a, L);
     else launch_skinny_gm<NTW, 8, true, false>(p, a, L);
   } else {
     if (p.waves == 4) launch_skinny_gm<NTW, 4, false, false>(p, a, L);
-    else if (p.waves == 16) launch_skinny_gm<NTW, 16, false, false>(p, a, L);
+    else if (NTW == 1 && p.waves == 16) launch_skinny_gm<1, 16, false, false>(p, a, L);
     else launch_skinny_gm<NTW, 8, false, false>(p, a, L);
   }
 }
@@ -2304,24 +2077,6 @@ static void launch_tiled(const Plan& p, const GemmArgs& a, const Launch& L) {
     }
   }
 #endif
-  if constexpr (WN == 4 && TCH == 128) if (p.mfma32) {
-#define QA_TILED32_K(GMV)                                                                                          \
-  do {                                                                                                             \
-    auto kfn = w4a16_tiled32_kernel<BMT, TN, WK, GMV>;                                                             \
-    static std::atomic<unsigned long long> attr_set{0};                                                                \
-    (void)lds_limit_once(attr_set, (const void*)kfn, (int)lds);                                                    \
-    hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);                                     \
-  } while (0)
-    switch (group_mode(a.G)) {
-      case 0: QA_TILED32_K(0); break;
-      case 1: QA_TILED32_K(1); break;
-      case 2: QA_TILED32_K(2); break;
-      case 3: QA_TILED32_K(3); break;
-      default: QA_TILED32_K(4); break;
-    }
-#undef QA_TILED32_K
-    return;
-  }
   switch (group_mode(a.G)) {
     case 0: QA_TILED_K(0, 0); break;
     case 1: QA_TILED_K(1, 0); break;
@@ -2459,10 +2214,11 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
   if ((kernel & 15) == QUICK_KERNEL_XK && ((kernel >> 12) & 3))  // the twelve-wave (loader waves, bit 12) and sixteen-wave (bit 13) flavours: measured level with the eight-wave one, DESIGN.md 5.9
     return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: the loader-wave / sixteen-wave flavours of the exchange-K kernels are only in a QUICK_AMD_TOOLS build", kernel);
 #endif
+  if ((kernel & 15) == QUICK_KERNEL_TILED && ((kernel >> 13) & 1))  // r01's 32x32x16 flavour of the tiled kernel (measured behind the 16x16x32 one, spilled registers): retired in r06
+    return fail(QUICK_ERR_INVALID_ARGUMENT, "kernel id %d: the 32x32x16 flavour of the tiled kernel (bit 13) was retired in r06", kernel);
   if (!x || !qweight || !scales || !qzeros || !y) return fail(QUICK_ERR_INVALID_ARGUMENT, "null tensor pointer");
-  const Plan p = plan_for(M, K, N, G, kernel, grid_split_k, f.silu_mul != 0);
+  const Plan p = plan_for(M, K, N, G, kernel, grid_split_k, f.silu_mul != 0, f.ln_w != nullptr);
   if (f.silu_mul && (f.bias || f.residual)) return fail(QUICK_ERR_INVALID_ARGUMENT, "silu_mul excludes bias and residual");
-  if (f.silu_mul && p.mfma32) return fail(QUICK_ERR_UNSUPPORTED, "silu_mul epilogue: 16x16 kernels only");
   if (f.ln_w && p.kernel != QUICK_KERNEL_LEAN && !(p.kernel == QUICK_KERNEL_SKINNY && p.dz && p.ksplit == 1 && !p.frag8_t && (p.xlds || (p.mt >= 2 && p.waves == 8))))
     return fail(QUICK_ERR_UNSUPPORTED, "RMSNorm prologue: only on the deferred-zero path (see quick_w4a16_can_fuse_rmsnorm)");
   GemmArgs a{(const half_t*)x, (const u32x4*)qweight, (const half_t*)scales, (const uint32_t*)qzeros, (const half_t*)f.bias,
@@ -2554,7 +2310,11 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
       case 41: launch_wide<4, 1>(p, a, L); break;
       case 42: launch_wide<4, 2>(p, a, L); break;
       case 81: launch_wide<8, 1>(p, a, L); break;
-      default: launch_wide<8, 2>(p, a, L); break;
+#ifdef QUICK_AMD_TOOLS
+      default: launch_wide<8, 2>(p, a, L); break;   // r02's hipcc-scheduled 256 x 256 tile (92 bytes of scratch): the A/B partner of the generated loop, tools builds only
+#else
+      default: return fail(QUICK_ERR_UNSUPPORTED, "the hipcc-scheduled 256 x 256 tile is only in a QUICK_AMD_TOOLS build (the product runs the generated loop, w4a16_xw.hpp, or 128 x 256 tiles)");
+#endif
     }
   } else if (p.kernel == QUICK_KERNEL_SKINNY) {
     switch (p.mt) {

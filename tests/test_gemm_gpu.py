@@ -105,7 +105,7 @@ SHAPES = [  # (M, K, N, G)
 ]
 
 
-TILED_MFMA32 = TILED | (1 << 13)      # experimental 32x32x16 flavour of the tiled kernel
+TILED_MFMA32 = TILED | (1 << 13)      # r01's experimental 32x32x16 flavour of the tiled kernel: retired in r06 (INVALID_ARGUMENT, test_retired_kernel_ids)
 TILED_16WAVES = TILED | (4 << 8)      # 4 x 4 waves per workgroup
 TILED_WIDE = TILED | (1 << 29)        # 64 x 256 workgroup tiles (the planner's choice once they cover the 256 CUs: large M)
 TILED_BIG = TILED | (1 << 27)         # 128 x 256 tiles run by four waves with 128 accumulators each (large M)
@@ -124,13 +124,32 @@ WIDE_IDS = ([WIDE] + [wide(mb, pairs) for mb in (2, 4, 8) for pairs in (1, 2)] +
             + [wide(2, 1) | WIDE_8WAVES, wide(2, 2) | WIDE_8WAVES, wide(4, 1) | WIDE_8WAVES, wide(2, 1) | WIDE_8WAVES | (3 << 22)])
 
 
-@pytest.mark.parametrize("kernel_id", [0, SKINNY_DZ, SKINNY_EXACT, TILED, TILED_MFMA32, TILED_16WAVES, TILED_WIDE, TILED_BIG] + WIDE_IDS)
+@pytest.mark.parametrize("kernel_id", [0, SKINNY_DZ, SKINNY_EXACT, TILED, TILED_16WAVES, TILED_WIDE, TILED_BIG] + WIDE_IDS)
 @pytest.mark.parametrize("M,K,N,G", SHAPES)
 def test_synthetic_sweep(qa, device, M, K, N, G, kernel_id):
     x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=M * 7 + K + N + G)
     want = oracle.w4a16_forward(x, iw, s, z, G)
     y = qa.gemm_forward(_dev(x, device), *_pack_dev(iw, s, z, device), kernel_id=kernel_id)
     assert rel_err(y.cpu().numpy(), want) <= TOL
+
+
+def test_retired_kernel_ids(qa, device):
+    """[r06] Instantiations that spilled registers left the product library (tests/test_module_cpu.py::test_no_kernel_of_the_library_spills_registers):
+    r01's 32x32x16 flavour of the tiled kernel answers INVALID_ARGUMENT; a forced 256 x 256 tile of r02's hipcc-scheduled kernel and forced
+    sixteen-wave skinny launches with several tiles run their nearest build (128 x 256 tiles / eight waves) -- with the right result."""
+    from quick_amd import kernels as K_
+    M, K, N, G = 300, 1024, 512, 128
+    x, iw, s, z = oracle.make_synthetic(M, K, N, G, seed=77)
+    want = oracle.w4a16_forward(x, iw, s, z, G)
+    packed = _pack_dev(iw, s, z, device)
+    with pytest.raises((RuntimeError, ValueError), match="retired"):
+        qa.gemm_forward(_dev(x, device), *packed, kernel_id=TILED_MFMA32)
+    assert K_.plan_describe(M, K, N, G, wide(8, 2)).startswith("wide tokens=128 channels=256")
+    assert rel_err(qa.gemm_forward(_dev(x, device), *packed, kernel_id=wide(8, 2)).cpu().numpy(), want) <= TOL
+    for ntw in (2, 4):
+        kid = SKINNY_EXACT | (ntw << 4) | (4 << 8)    # sixteen waves asked for
+        assert f"ntw={ntw} waves=8" in K_.plan_describe(16, K, N, G, kid), K_.plan_describe(16, K, N, G, kid)
+        assert rel_err(qa.gemm_forward(_dev(x[:16], device), *packed, kernel_id=kid).cpu().numpy(), want[:16]) <= TOL
 
 
 # ------------------------------------------------------------------------------------------------

@@ -254,7 +254,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(1024, 28672, 8192).startswith("xw tokens=128 channels=256 waves=4 ring=4 queue=4 grid=256 slices=1")   # (r02: 128 tiles of 256 x 256 x 2 K slices; 256 one-slice tiles of 128 x 256 are 10 % ahead)
     os.environ["QUICK_AMD_XW256"] = "0"
     try:
-        assert plan(4096, 4096, 4096).startswith("wide tokens=256 channels=256")                       # (the A/B switch)
+        assert plan(4096, 4096, 4096).startswith("wide tokens=128 channels=256")                       # (the A/B switch; r06: the product library no longer carries r02's hipcc-scheduled 256 x 256 tile -- it spilled -- only tools builds do)
     finally:
         del os.environ["QUICK_AMD_XW256"]
     assert plan(4096, 4096, 4096).startswith("xw tokens=256 channels=256 waves=4 ring=2 queue=2 grid=256 slices=1")
@@ -262,7 +262,8 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(512, 4096, 4096, kernel_id=kernels.KERNEL_XW).startswith("xw tokens=128 channels=256") and "slices=4" in plan(512, 4096, 4096, kernel_id=kernels.KERNEL_XW)
     assert not plan(512, 4608, 4096, G=384).startswith("xw") and not plan(512, 4608, 4096, G=384, kernel_id=kernels.KERNEL_XW).startswith("xw")  # G / 128 must be a power of two
     W = kernels.KERNEL_WIDE
-    assert "tokens=256 channels=256" in plan(4096, 8192, 8192, kernel_id=W | (8 << 4) | (2 << 8))      # explicit tile
+    assert "tokens=256 channels=128" in plan(4096, 8192, 8192, kernel_id=W | (8 << 4) | (1 << 8))      # explicit tile
+    assert "tokens=128 channels=256" in plan(4096, 8192, 8192, kernel_id=W | (8 << 4) | (2 << 8))      # (r06: the hipcc-scheduled 256 x 256 tile left the product library -- 128 x 256 tiles answer)
     assert "waves=8 ring=6" in plan(512, 4096, 4096, kernel_id=W | (2 << 4) | (1 << 8) | (1 << 15))   # eight-wave ring
     assert "ring=0" in plan(512, 4096, 4096, kernel_id=W | (2 << 4) | (1 << 8) | (1 << 12))           # double-buffered instead
     # r02 planner audit (profiles/r02_planner_audit*.jsonl): the rules it added
@@ -540,6 +541,39 @@ def test_no_kernel_of_the_library_traps(tmp_path):
         assert "s_trap" not in text, o.name
         mfma += text.count("v_mfma_f32_32x32x16_f16")
     assert mfma > 1000     # (the disassembly really is the GEMM kernels)
+
+
+def test_no_kernel_of_the_library_spills_registers(tmp_path):
+    """[r06, VERDICT r05 #6] The kernels' design is register-resident (the counterpart of the reference's compute_gemm, csrc/gemm_cuda_quick.cu:20-455:
+    weights HBM -> registers -> matrix core, nothing through memory on the way).  r01-r05 shipped instantiations that spilled to scratch memory
+    (sixteen-wave skinny builds with two and four tiles, r01's 32x32x16 tiled flavour, r02's hipcc-scheduled 256 x 256 tile); r06 retired them or
+    moved them to tools builds.  Every kernel descriptor of the shipped gfx950 code objects -- the GEMM families the planner can reach AND the
+    forced-id ones, the repack and decode kernels -- declares a private segment of 0 bytes, and the disassembly has no scratch_ instruction."""
+    import re
+    import shutil
+    import subprocess
+    from quick_amd import _lib
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("no llvm-objdump / llvm-readelf here")
+    lib = tmp_path / "lib.so"
+    shutil.copy(_lib.LIB, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], capture_output=True, text=True, check=True)
+    objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
+    assert objs, list(tmp_path.iterdir())
+    kernels_seen, spilling = 0, []
+    for o in objs:
+        notes = subprocess.run([readelf, "--notes", str(o)], capture_output=True, text=True, check=True).stdout
+        for block in notes.split("- .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block)
+            priv = re.search(r"\.private_segment_fixed_size:\s+(\d+)", block)
+            assert name and priv, block[:200]
+            kernels_seen += 1
+            if int(priv.group(1)) > 0:
+                spilling.append((name.group(1), int(priv.group(1))))
+        text = subprocess.run([objdump, "-d", str(o)], capture_output=True, text=True, check=True).stdout
+        assert not re.search(r"\bscratch_(load|store)", text), o.name
+    assert kernels_seen > 300 and not spilling, spilling
 
 
 def test_generated_k_loops_are_what_the_generator_writes(tmp_path):

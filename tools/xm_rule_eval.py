@@ -28,7 +28,7 @@ def one_round(pairs, mt):
 def rule(M, K, N):
     """-> (mb, pr) or None: the rule of make_plan (w4a16_gemm.hip), restated"""
     pairs, KT = N // 32, K // 128
-    if KT < 8 or M <= 16 or M > 64:
+    if KT < 32 or M <= 16 or M > 64:
         return None
     if M <= 32:
         pr = one_round(pairs, 1)
