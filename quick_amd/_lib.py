@@ -74,5 +74,16 @@ def load():
     return _lib
 
 
+def load_other(path):
+    """A second library with the same C ABI (tests: the -amdgpu-waitcnt-forcezero build of the product sources, quick_amd.build.FORCEZERO_LIB)."""
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -m quick_amd.build --forcezero`")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
 def last_error():
     return load().quick_amd_last_error().decode()

@@ -1,6 +1,6 @@
 """Builds libquick_amd.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
 
-    python -m quick_amd.build [--force] [--tools]
+    python -m quick_amd.build [--force] [--tools | --forcezero]
 
 The shared object lands in quick_amd/lib/ (git-ignored, but it travels to the GPU box with the
 working-tree snapshot).  Cross-compiles without a GPU.  Every translation unit is compiled to its own
@@ -9,6 +9,11 @@ object (in parallel, rebuilt only when it or a header changed) and the objects a
 --tools builds tools/bin/libquick_amd_tools.so instead: the same library plus the timing-experiment
 kernels (ablations with wrong results, phase stamps) that tools/*.py ask for through kernel-id bits 16-20
 (-DQUICK_AMD_TOOLS).  The product library contains none of them.
+
+--forcezero builds quick_amd/lib/libquick_amd_forcezero.so: the product sources with `-mllvm -amdgpu-waitcnt-forcezero` (hipcc waits for every
+counter in front of every instruction of the code IT schedules; the generated asm loops are what they are).  Not a product: the comparison
+partner of tests/test_gemm_gpu.py::test_hipcc_scheduled_kernels_equal_their_forcezero_build -- twice, in r04 and r05, a build computed wrong results
+that this flag cured, so every round's GPU suite demands bit-equal outputs from both libraries.
 """
 import hashlib
 import os
@@ -23,6 +28,7 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libquick_amd.so")
 TOOLS_DIR = os.path.join(os.path.dirname(PKG), "tools", "bin")   # measurement builds live with the tools, not with the product
 TOOLS_LIB = os.path.join(TOOLS_DIR, "libquick_amd_tools.so")
+FORCEZERO_LIB = os.path.join(LIBDIR, "libquick_amd_forcezero.so")
 SOURCES = ["w4a16_gemm.hip", "w4a16_xk.hip", "w4a16_xw.hip", "w4a16_xm.hip", "w4a16_lean.hip", "w4a16_lean_a.hip", "w4a16_lean_b.hip", "w4a16_lean_c.hip", "repack.hip", "decode_ops.hip"]
 HEADERS = ["w4a16_common.hpp", "w4a16_args.hpp", "w4a16_wide.hpp", "w4a16_xk.hpp", "w4a16_xk_host.hpp", "w4a16_xw.hpp", "w4a16_xw_host.hpp", "w4a16_xw_loop.inc", "w4a16_xm.hpp", "w4a16_xm_host.hpp", "w4a16_xm_loop.inc", "w4a16_lean.hpp", "w4a16_lean_host.hpp", "w4a16_lean_inst.hpp",
            os.path.join("..", "..", "include", "quick_amd.h")]
@@ -50,8 +56,8 @@ def _sha(paths, extra=""):
     return h.hexdigest()
 
 
-def _digest(tools=False):
-    return _sha([os.path.join(CSRC, f) for f in SOURCES + HEADERS], " ".join(FLAGS) + repr(sorted(EXTRA_CFLAGS.items())) + (" tools" if tools else ""))
+def _digest(tools=False, forcezero=False):
+    return _sha([os.path.join(CSRC, f) for f in SOURCES + HEADERS], " ".join(FLAGS) + repr(sorted(EXTRA_CFLAGS.items())) + (" tools" if tools else "") + (" forcezero" if forcezero else ""))
 
 
 def _compile(src, obj, flags, verbose):
@@ -63,16 +69,17 @@ def _compile(src, obj, flags, verbose):
         raise RuntimeError("hipcc failed on %s:\n%s%s" % (src, r.stdout, r.stderr))
 
 
-def build(force=False, verbose=False, tools=False):
+def build(force=False, verbose=False, tools=False, forcezero=False):
+    assert not (tools and forcezero)
     os.makedirs(TOOLS_DIR if tools else LIBDIR, exist_ok=True)
-    lib = TOOLS_LIB if tools else LIB
+    lib = TOOLS_LIB if tools else (FORCEZERO_LIB if forcezero else LIB)
     stamp = lib + ".sha256"
-    dig = _digest(tools)
+    dig = _digest(tools, forcezero)
     if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return lib
-    objdir = os.path.join(TOOLS_DIR, "obj_tools") if tools else os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(TOOLS_DIR, "obj_tools") if tools else os.path.join(LIBDIR, "obj_forcezero" if forcezero else "obj")
     os.makedirs(objdir, exist_ok=True)
-    flags = CFLAGS + (["-DQUICK_AMD_TOOLS"] if tools else [])
+    flags = CFLAGS + (["-DQUICK_AMD_TOOLS"] if tools else []) + (["-mllvm", "-amdgpu-waitcnt-forcezero"] if forcezero else [])
     hdr = [os.path.join(CSRC, h) for h in HEADERS]
     jobs, objs = [], []
     for src in SOURCES:
@@ -100,4 +107,4 @@ def build(force=False, verbose=False, tools=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, tools="--tools" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, tools="--tools" in sys.argv, forcezero="--forcezero" in sys.argv))

@@ -37,14 +37,34 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ half2_t as_h2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
 __device__ __forceinline__ uint32_t as_u32(half2_t h) { return __builtin_bit_cast(uint32_t, h); }
 
-// (a & mask) | orv in ONE VALU op.  gfx950 VOP3 takes no literals, so hipcc splits the C expression
-// into v_and + v_or (two literal-carrying VOP2s); feeding the mask from an SGPR and the magic
-// number from a VGPR lets v_and_or_b32 encode.  The AMD counterpart of the `lop3` in the
-// reference's dequantize_s4_to_fp16x2_fused (csrc/dequantize_quick.cuh:37-51).
+// (a & mask) | orv in ONE VALU op.  gfx950 VOP3 takes no literals, so hipcc splits the C expression into v_and + v_or (two literal-carrying VOP2s)
+// when it can see the constants; with the mask in an SGPR and the magic number in a VGPR whose values it cannot see it selects v_and_or_b32 -- the AMD
+// counterpart of the `lop3` in the reference's dequantize_s4_to_fp16x2_fused (csrc/dequantize_quick.cuh:37-51).
+// [r06] r01-r05 wrote the instruction itself as inline asm.  An instruction inside an asm statement is invisible to hipcc's hazard recognizer: gfx950
+// does not interlock the matrix core against the vector ALU (measured table: tools/mfma_hazard_lint.py, profiles/r06_mfma_hazards.txt), hipcc pads
+// those pairs only for instructions it knows to be VALU, and a build whose register allocation put such an asm next to the wrong MFMA computed tiles
+// wrong (the unconditional-request chunk loop of r05, DESIGN.md 9.6: cured by this form, by a trailing s_nop inside the asm, and by
+// -amdgpu-waitcnt-forcezero; not by any wait on memory).  Now the two EMPTY asm statements only hide the constants' values; the instruction is hipcc's
+// own, with its hazards seen.  QA_ANDOR_ASM=1 (A/B builds) restores the asm form.
 __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t orv) {
+#if defined(QA_ANDOR_ASM) && QA_ANDOR_ASM == 1
   uint32_t r;
   asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(orv));
   return r;
+#elif defined(QA_ANDOR_ASM) && QA_ANDOR_ASM == 2   // (... with a wait state behind it: cures the r05 build; ... == 3, in front of it: does not)
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3\n\ts_nop 0" : "=v"(r) : "v"(a), "s"(mask), "v"(orv));
+  return r;
+#elif defined(QA_ANDOR_ASM) && QA_ANDOR_ASM == 3
+  uint32_t r;
+  asm("s_nop 0\n\tv_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(orv));
+  return r;
+#else
+  uint32_t m = mask, o = orv;
+  asm("" : "+s"(m));
+  asm("" : "+v"(o));
+  return (a & m) | o;
+#endif
 }
 
 // Per-(group, output channel) dequantisation constants held by a lane.

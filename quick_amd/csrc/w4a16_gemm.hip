@@ -498,17 +498,30 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_skinny_kernel(const GemmArgs
     // been through the parity suite in this exact form since r01.
     if (kt_begin < kt_end) skinny_load<NTW, GM, U, XLDS, LN, NT>(cA, kt_begin, kt_end - 1, bufs, cb, xp, a, gp);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef QA_EXP_SKINNY_UNCOND   // (A/B builds only: the unconditional requests of profiles/r05_skinny_variants.txt -- wrong results in the four-tile build)
+#define QA_SKINNY_IF(c)
+#else
+#define QA_SKINNY_IF(c) if (c)
+#endif
+#ifndef QA_EXP_SKINNY_WAIT
+#define QA_EXP_SKINNY_WAIT 0   // (A/B builds: full waits at chosen points of the loop, to bisect which request the ISA's own waits do not cover)
+#endif
+#define QA_SKINNY_FULLWAIT(bit) do { if constexpr ((QA_EXP_SKINNY_WAIT >> (bit)) & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); } while (0)
+    QA_SKINNY_FULLWAIT(2);
     for (int kt = kt_begin; kt < kt_end; kt += 2 * U) {
-      if (kt + U < kt_end) skinny_load<NTW, GM, U, XLDS, LN, NT>(cB, kt + U, kt_end - 1, bufs, cb, xp, a, gp);
+      QA_SKINNY_IF(kt + U < kt_end) skinny_load<NTW, GM, U, XLDS, LN, NT>(cB, kt + U, kt_end - 1, bufs, cb, xp, a, gp);
       __builtin_amdgcn_sched_barrier(0);
+      QA_SKINNY_FULLWAIT(0);
       if constexpr (DZ) skinny_compute_dzf<NTW, GM, U, LN>(cA, kt, kt_end, bconst, (lane & 1) != 0, acc, &ssq);
       else skinny_compute<NTW, GM, U, XLDS>(cA, kt, kt_end, nullptr, acc);
       if (kt + U >= kt_end) break;
-      if (kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS, LN, NT>(cA, kt + 2 * U, kt_end - 1, bufs, cb, xp, a, gp);
+      QA_SKINNY_IF(kt + 2 * U < kt_end) skinny_load<NTW, GM, U, XLDS, LN, NT>(cA, kt + 2 * U, kt_end - 1, bufs, cb, xp, a, gp);
       __builtin_amdgcn_sched_barrier(0);
+      QA_SKINNY_FULLWAIT(1);
       if constexpr (DZ) skinny_compute_dzf<NTW, GM, U, LN>(cB, kt + U, kt_end, bconst, (lane & 1) != 0, acc, &ssq);
       else skinny_compute<NTW, GM, U, XLDS>(cB, kt + U, kt_end, nullptr, acc);
     }
+    QA_SKINNY_FULLWAIT(3);
     skinny_finish<NTW, WAVES, DZ, LN>(a, acc, red, smem, bx, nblocks, mb, ks, lane, wave, ssq);
     if constexpr (SPAN) span_stamp(a.span, 1);
     return;
