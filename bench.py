@@ -71,16 +71,18 @@ def pmc_traffic(M, K, N, G, kernel, plan):
     the plan's family word, and its SHA-256 goes into the JSON; a stale or foreign file yields traffic = null, not a number."""
     import glob
     import hashlib
-    if (K, N, G, kernel) != (4096, 4096, 128, 0):
+    if (G, kernel) != (128, 0):
         return None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_m{M}_*.txt")))
+    # K = N = 4096 (the BASELINE sweep): r*_pmc_m<M>_<family>.txt; other layer shapes [r06]: r*_pmc_<M>x<K>x<N>_<family>.txt
+    files = sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_m{M}_*.txt"))) if (K, N) == (4096, 4096) else []
+    files = sorted(files + glob.glob(os.path.join(here, "profiles", f"r*_pmc_{M}x{K}x{N}_*.txt")), key=os.path.basename)
     if not files:
         return None, None
     text = open(files[-1]).read()
     family = plan.split()[0]                                   # "skinny" | "tiled" | "wide" | "xk"
     heads = [l for l in text.splitlines() if l.startswith("== ")]
-    if not heads or not any(f"w4a16_{family}" in h or (family == "wide" and "w4a16_ring" in h) for h in heads):
+    if not heads or not any(f"w4a16_{family}" in h or (family == "wide" and "w4a16_ring" in h) or (family == "skinny" and "w4a16_frag8" in h) for h in heads):
         return None, {"file": "profiles/" + os.path.basename(files[-1]), "rejected": f"profiled kernel is not the planner's ({family})"}
     vals = {}
     for line in text.splitlines():
@@ -426,13 +428,36 @@ def main():
             s_us = float(np.median(np.asarray(kus[:40])[5:])) if rc == 0 else None
             nb = algorithmic_bytes(Ml, Kl, Nl, G)
             ach = nb / (k_us * 1e-6) / 1e9
-            out["decode_layers"].append({"M": Ml, "K": Kl, "N": Nl, "kernel_us": k_us, "weight_sets_cycled": ns,
-                                         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                      "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": nb, "kernel_us_inkernel": s_us,
-                                                      "frac_inkernel": nb / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS if s_us else None}})
+            lplan = kernels.plan_describe(Ml, Kl, Nl, G, args.kernel)
+            lroof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": nb,
+                     "kernel_us_inkernel": s_us, "frac_inkernel": nb / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS if s_us else None, "plan": lplan}
+            # [r06] HBM traffic of this shape's launch from its committed counter pass (profiles/r*_pmc_<M>x<K>x<N>_*.txt), accepted only if it is about the planner's kernel
+            ltraffic, lsrc = pmc_traffic(Ml, Kl, Nl, G, args.kernel, lplan)
+            lroof.update({"traffic": ltraffic if lsrc and "rejected" not in lsrc else None, "traffic_source": lsrc, "traffic_measured_in_this_run": False})
+            if lsrc and "rejected" not in lsrc:
+                lroof.update(pmc_issue_mix(Ml, Kl, Nl, G, args.kernel, lsrc))
+            out["decode_layers"].append({"M": Ml, "K": Kl, "N": Nl, "kernel_us": k_us, "weight_sets_cycled": ns, "plan": lplan, "roofline": lroof})
             log(f"layer M={Ml} K={Kl} N={Nl}: kernel {k_us:7.2f} us  {ach:7.1f} GB/s = {100 * ach / HBM_PEAK_GBS:.1f}% of HBM peak"
                 + (f"; in-kernel span {s_us:.2f} us = {100 * nb / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS:.1f}%" if s_us else ""))
             del lsets, larr
+
+    # ---- [r06] what a one-token launch is made of: kernel time = fixed + bytes / rate over the M = 1 rows (the sweep's 4096 x 4096 and the decode layers),
+    #      least squares on the dispatch clock and on the in-kernel span
+    if world == 1 and out.get("decode_layers"):
+        pts = [(r["roofline"]["algorithmic_bytes"], r["kernel_us"], r["roofline"].get("kernel_us_inkernel")) for r in out["decode_layers"] if r["M"] == 1]
+        if 1 in results:
+            pts.append((results[1]["roofline"]["algorithmic_bytes"], results[1]["roofline"]["kernel_us"], results[1]["roofline"].get("kernel_us_inkernel")))
+        if len(pts) >= 3:
+            model = {"rows": len(pts), "what": "kernel_us = fixed_us + algorithmic bytes / rate, least squares over the M = 1 rows (sweep + decode_layers)"}
+            for name, col in (("dispatch_clock", 1), ("inkernel_span", 2)):
+                p2 = [(b, t[col - 1]) for b, *t in pts if t[col - 1]]
+                if len(p2) >= 3:
+                    A = np.array([[1.0, b] for b, _ in p2])
+                    coef, *_ = np.linalg.lstsq(A, np.array([t for _, t in p2]), rcond=None)
+                    model[name] = {"fixed_us": float(coef[0]), "marginal_TBps": float(1e-6 / coef[1]) if coef[1] > 0 else None,
+                                   "residual_us_max": float(np.abs(A @ coef - np.array([t for _, t in p2])).max())}
+            out["small_m_model"] = model
+            log(f"small-M model: {model}")
 
     # ---- prefill-sized launches (compute-bound end of the path), kernel duration only, MFMA roofline
     if world == 1 and args.prefill_layers:

@@ -1197,7 +1197,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     }();
     const bool envelope = G % 128 == 0 && (size_t)K * N / 2 < ((size_t)1 << 31) && (size_t)M * K * 2 < ((size_t)1 << 31);
     if (forced || (family == QUICK_KERNEL_AUTO && lean_on && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M <= 16)) {
-      const bool one_block_ok = forced || M <= 4 || N / 16 <= 512;
+      // [r06 audit, profiles/r06_lean_rule_audit.txt] 5 / 6 tokens on the 768 blocks of 4096 x 12288: 8.5 -> 6.9 / 7.6 us
+      const bool one_block_ok = forced || M <= 4 || N / 16 <= 512 || (M <= 6 && N / 16 <= 768 && KT <= 32);
       int bw = 0, bt = 0, bn = 0;
       double bcost = 0;
       for (const auto& b : builds) {
@@ -1206,6 +1207,11 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         if (forced && ((waves_req && waves != waves_req) || (mt_req && ntw != mt_req))) continue;
         if (KT < waves || (KT + waves - 1) / waves > tmax || (N / 16) % ntw != 0) continue;
         if (lean_lds_need(M, K, waves, ntw, true) > kLdsPerCu) continue;
+        // [r06 audit of this rule for K > 4096 (tools/lean_rule_audit.py, profiles/r06_lean_rule_audit.txt)] from five tokens a long K makes x
+        // most of a workgroup's LDS (115-140 KB: one workgroup per CU): a launch that needs a second round of such workgroups loses to the
+        // r01-r04 fragment kernels (12 x 5120 x 5120 10.1 against 8.1 us, 8 x 8192 x 8192 12.0 / 10.0, 6 x 11008 x 8192 15.5 / 13.5), one that fits
+        // a single round wins (5..8 x 8192 x 4096 5.9-6.5 / 7.0-7.6, 5..8 x 5120 x 5120 5.4-5.8 / 7.3-7.6) -- so: all workgroups co-resident
+        if (!forced && M >= 5 && KT > 32 && (long)(N / 16 / ntw) * mblocks > (long)std::max(1u, (unsigned)kLdsPerCu / lean_lds_need(M, K, waves, ntw, true)) * cu_count()) continue;
         // what the fullest CU streams: rounds of workgroups x bytes per workgroup; two tiles per workgroup share the head (0.85, measured);
         // sixteen waves with <= 4 tiles each and twelve tiles per wave cost
         const long wgs = (long)(N / 16 / ntw) * mblocks;
@@ -1985,10 +1991,12 @@ static void launch_skinny_gm(const Plan& p, const GemmArgs& a, const Launch& L) 
     constexpr bool stamped = !LN && ((WAVES == 8 && ((NTW == 1 && XLDS && DZ) || (NTW == 1 && !XLDS && !DZ) || (NTW == 4 && !XLDS && DZ))) ||
                                      (WAVES == 16 && NTW == 1 && ((XLDS && DZ) || (!XLDS && !DZ))));
     if constexpr (stamped) {
-      if (group_mode(a.G) == 0) {
+      if (group_mode(a.G) == 0) {   // [r06, ADVICE r05] the stamped build of the kernel the product runs: nt weight requests with one token block
         auto kfn = w4a16_skinny_kernel<NTW, WAVES, 0, XLDS, DZ, LN, true>;
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
-        hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)lds, L.st, L.start, L.stop, 0, a);
+        auto kfn_nt = w4a16_skinny_kernel<NTW, WAVES, 0, XLDS, DZ, LN, true, true>;
+        (void)hipFuncSetAttribute((const void*)(a.M <= 16 ? kfn_nt : kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+        if (a.M <= 16) hipExtLaunchKernelGGL(kfn_nt, grid, block, (unsigned)lds, L.st, L.start, L.stop, 0, a);
+        else hipExtLaunchKernelGGL(kfn, grid, block, (unsigned)lds, L.st, L.start, L.stop, 0, a);
         return;
       }
     }
@@ -2566,6 +2574,11 @@ int quick_amd_dispatch_floor(int iters, float* kernel_us, void* hip_stream) {
 int quick_w4a16_workspace_check(const void* workspace, size_t workspace_bytes, void* hip_stream) {
   if (!workspace || workspace_bytes == 0) return QUICK_OK;
   hipStream_t st = (hipStream_t)hip_stream;
+  // [r06, ADVICE r05] the scan allocates, copies back and synchronises: none of that is legal while the stream is being captured into a graph --
+  // say so instead of invalidating the capture (QUICK_AMD_CHECK_WORKSPACE=1 reaches here from every split launch)
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail(QUICK_ERR_INVALID_ARGUMENT, "quick_w4a16_workspace_check synchronises the stream and cannot run while it is being captured into a hipGraph (unset QUICK_AMD_CHECK_WORKSPACE for captured launches)");
   const size_t guarded = std::min(workspace_bytes, (size_t)kMaxSplitTiles * 4 + kXkZoneBytesHost) & ~(size_t)15;
   unsigned* first = nullptr;
   if (hipMalloc(&first, sizeof(unsigned)) != hipSuccess) return fail(QUICK_ERR_LAUNCH, "hipMalloc failed");
@@ -2574,7 +2587,8 @@ int quick_w4a16_workspace_check(const void* workspace, size_t workspace_bytes, v
   if (hipMemsetAsync(first, 0xff, sizeof(unsigned), st) != hipSuccess) rc = fail(QUICK_ERR_LAUNCH, "memset failed");
   if (rc == QUICK_OK) {
     hipLaunchKernelGGL(w4a16_workspace_scan_kernel, dim3(1024), dim3(256), 0, st, (const u32x4*)workspace, (unsigned)(guarded / 16), first);
-    if (hipMemcpyAsync(&host, first, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    if (hipGetLastError() != hipSuccess) rc = fail(QUICK_ERR_LAUNCH, "workspace scan kernel did not launch");
+    if (rc == QUICK_OK) if (hipMemcpyAsync(&host, first, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       rc = fail(QUICK_ERR_LAUNCH, "workspace scan failed: %s", hipGetErrorString(hipGetLastError()));
   }
   (void)hipFree(first);

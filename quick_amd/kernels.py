@@ -142,11 +142,12 @@ def workspace_check(device=None):
     """Verify that this stream's workspace is all-zero where the library expects it (quick_w4a16_workspace_check: synchronises).
     Raises RuntimeError naming the first dirty byte -- and zeroes the buffer again -- otherwise."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    ws = _WORKSPACES.get((device.index, _stream()))
-    if ws is None:
-        return True
-    with torch.cuda.device(device):
-        rc = _lib.load().quick_w4a16_workspace_check(ws.data_ptr(), ws.numel(), _stream())
+    with torch.cuda.device(device):      # (the stream is THAT device's current stream: key and call both, ADVICE r05)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        ws = _WORKSPACES.get((device.index, stream))
+        if ws is None:
+            return True
+        rc = _lib.load().quick_w4a16_workspace_check(ws.data_ptr(), ws.numel(), stream)
     if rc != _OK:
         ws.zero_()
         _raise(rc)

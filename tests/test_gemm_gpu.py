@@ -183,7 +183,7 @@ def test_hipcc_scheduled_kernels_equal_their_forcezero_build(qa, device):
         ran += 1
         assert not torch.isnan(y1).any() and torch.equal(y1, y2), (M, K, N, G, kid, K_.plan_describe(M, K, N, G, kid))
     assert ran >= 100, ran
-    assert not ws.any()          # (both libraries hand the exchange zone back zeroed)
+    assert not ws[:65536 + (16 << 20)].any()          # (both libraries hand the arrival counters and the exchange zone back zeroed; the fp32 slabs behind them are scratch)
 
 
 def test_retired_kernel_ids(qa, device):

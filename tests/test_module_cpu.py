@@ -282,7 +282,10 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(16, 8192, 28672).startswith("skinny ntw=8") and "grid=224x1x1 ksplit=1" in plan(16, 8192, 28672) and plan(16, 8192, 16384).startswith("skinny ntw=4")   # (one slice from 192 blocks; 128 blocks x 2 slices measured behind)
     # r03 audit: from five tokens no LDS copy of x outside the table flavour; one-tile launches with K = 4096 run sixteen waves
     assert plan(6, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=1 waves=16 x=l2 dequant=exact") and "waves=8 x=lds" in plan(4, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)
-    assert plan(6, 4096, 12288).startswith("skinny ntw=4 waves=8 x=l2") and plan(10, 11008, 4096).startswith("skinny ntw=4 waves=8 x=l2")
+    assert plan(7, 4096, 12288).startswith("skinny ntw=4 waves=8 x=l2") and plan(10, 11008, 4096).startswith("skinny ntw=4 waves=8 x=l2")
+    # [r06 audit of the lean rule, profiles/r06_lean_rule_audit.txt] 5 / 6 tokens on 768 channel blocks: lean; a long K only where every workgroup is co-resident
+    assert plan(6, 4096, 12288).startswith("lean ntw=1 waves=8") and plan(8, 8192, 4096).startswith("lean ntw=1 waves=8 tiles_per_wave<=8 grid=256x1")
+    assert plan(8, 8192, 8192).startswith("skinny ntw=2") and plan(12, 5120, 5120).startswith("skinny ntw=4") and plan(6, 11008, 8192).startswith("skinny ntw=2") and plan(5, 8192, 8192).startswith("lean ntw=2 waves=16")
     # third audit (17..64 tokens, layer shapes the rules were not tuned on): the four-tile skinny kernel by its own geometry
     assert plan(32, 4096, 6144, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4") and plan(32, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4")    # one round of workgroups, <= 64 stages each (AUTO at 17..32 tokens: the r06 mid-token kernels)
     assert plan(48, 5120, 5120).startswith("skinny ntw=4") and plan(55, 5120, 5120).startswith("xk tokens=64")    # 320 skinny workgroups would be two rounds; r03: 40 tiles x 4 slices (from 56 tokens: r06's mid-token kernels)
@@ -302,7 +305,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(1, 11008, 4096).startswith("lean ntw=1 waves=16 tiles_per_wave<=8") and plan(1, 8192, 8192).startswith("lean ntw=2 waves=16 tiles_per_wave<=4 grid=256x1")
     assert plan(1, 8192, 10240).startswith("lean ntw=1 waves=8 tiles_per_wave<=8") and plan(4, 4096, 22016).startswith("lean ntw=2")
     assert plan(16, 4096, 4096).startswith("lean") and plan(8, 4096, 8192).startswith("lean") and plan(17, 4096, 4096).startswith("xm")
-    assert plan(5, 4096, 12288).startswith("skinny") and plan(7, 4096, 22016).startswith("skinny")          # 5..7 tokens on wide layers: the r01-r04 kernels
+    assert plan(7, 4096, 12288).startswith("skinny") and plan(5, 4096, 22016).startswith("skinny") and plan(7, 4096, 22016).startswith("skinny")   # 5..7 tokens on wide layers: the r01-r04 kernels (r06: 5 / 6 tokens up to 768 blocks are lean)
     # 8..16 tokens on wide layers: one persistent workgroup per CU (x staged once; a one-block workgroup would fetch more bytes of x than of weights)
     assert plan(8, 4096, 22016).startswith("lean ntw=2 waves=8 tiles_per_wave<=4 grid=256x1") and plan(16, 4096, 22016).startswith("lean ntw=1 waves=8 tiles_per_wave<=4 grid=256x1")
     assert plan(16, 4096, 12288).startswith("lean ntw=1") and "grid=256x1" in plan(16, 4096, 12288) and plan(16, 8192, 57344).startswith("skinny")   # (x of 16 x 8192 does not fit LDS)
