@@ -14,6 +14,16 @@ namespace quick_amd {
 template <int WAVES, int TMAX, int NTW, int ABL>
 bool lean_build(const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, hipEvent_t start, hipEvent_t stop);
 
+#ifdef QA_EXP_LEAN_OVERLAP
+thread_local LeanOverlapExp g_lean_overlap{};
+}  // namespace quick_amd
+// experiment entry point: the next lean launch of this thread waits for `wait_sig` to reach (its own run number + 1) * wait_per_exec before it asks for x,
+// counts its own runs in `my_cnt`, and adds one arrival per storing wave to `signal` behind its rows.  Null pointers switch each part off.
+extern "C" void quick_amd_exp_lean_overlap(const unsigned* wait_sig, unsigned wait_per_exec, unsigned* my_cnt, unsigned* signal, int any_order) {
+  quick_amd::g_lean_overlap = quick_amd::LeanOverlapExp{wait_sig, my_cnt, wait_per_exec, signal, any_order};
+}
+namespace quick_amd {
+#endif
 unsigned lean_lds_need(int M, int K, int waves, int ntw, bool ln, bool persist) { return lean_lds_bytes(std::min(M, 16), K, waves, ntw, ln, persist); }
 
 template <int ABL>

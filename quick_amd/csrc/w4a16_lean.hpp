@@ -52,11 +52,25 @@ struct LeanRest {
   float ln_eps;
   unsigned long long* span;
   unsigned long long* dbg;
+#ifdef QA_EXP_LEAN_OVERLAP   // (experiment builds only, DESIGN.md 9.2 / profiles/r06_launch_overlap.txt: a launch that starts BEFORE its predecessor has finished)
+  const unsigned* wait_sig;  // the predecessor's arrival word: this launch requests its weights at entry and asks for x only once the word says the predecessor's rows are in memory
+  unsigned* my_cnt;          // this launch's own exit counter (how many times it has run = which value of the arrival word to wait for)
+  unsigned wait_per_exec;    // arrivals the predecessor adds per run
+  unsigned my_per_exec;      // exits this launch adds per run
+  unsigned* signal;          // this launch's arrival word for ITS successor (every storing wave adds one behind its rows)
+#endif
 };
 
 // 64 lanes x 16 bytes: global (descriptor base + voff + soff) -> LDS (lds_addr + 16 * lane), exec-masked lanes write nothing.
 // s_nop 4: the operands may come straight from a v_readfirstlane (VALU writes SGPR -> VMEM reads it: 5 wait states).
-__device__ __forceinline__ void lean_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+__device__ __forceinline__ void lean_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr, bool coherent = false) {
+#ifdef QA_EXP_LEAN_OVERLAP
+  if (coherent) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc0 sc1 lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return;
+  }
+#endif
+  (void)coherent;
   asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc),
                "s"(soff)
                : "memory");
@@ -110,6 +124,12 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
   const unsigned pitch = (unsigned)aK * 2u + 16u;
   const int nseg = (T + 3) >> 2;
 
+#ifdef QA_EXP_LEAN_OVERLAP
+  const bool defer = rest.wait_sig != nullptr;
+#else
+  constexpr bool defer = false;
+#endif
+  const auto issue_x = [&]() __attribute__((always_inline)) {
   // ---- 1. x (and the norm weight) of this wave's K range: LDS-DMA, first in the memory queue ----
   {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)aX, 0, (unsigned)aM * (unsigned)aK * 2u, 0x00020000);
@@ -119,12 +139,14 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
       const unsigned kbyte = (unsigned)(kb * 128 + 512 * s) * 2u;
       if (lane < 16 * (T - 4 * s)) {  // lanes past the wave's range write nothing (the neighbour wave owns those bytes)
         for (int tk = 0; tk < rows; ++tk)
-          lean_dma16(xr, (unsigned)lane * 16u, (unsigned)(row0 + tk) * (unsigned)aK * 2u + kbyte, lds_base + x_off + (unsigned)tk * pitch + kbyte);
+          lean_dma16(xr, (unsigned)lane * 16u, (unsigned)(row0 + tk) * (unsigned)aK * 2u + kbyte, lds_base + x_off + (unsigned)tk * pitch + kbyte, defer);
         if (ln) lean_dma16(lr, (unsigned)lane * 16u, kbyte, lds_base + lnw_off + kbyte);
       }
     }
   }
 
+  };
+  if (!defer) issue_x();
   if constexpr (STAMP) ts[10] = __builtin_amdgcn_s_memrealtime();
 
   // ---- 2. the group words of four tiles per request (lane (n16, q): tile kb + 4 i + q -- with G = 128 one contiguous 256 bytes), then
@@ -157,7 +179,21 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
   };
   request(nb);
   if constexpr (STAMP) ts[1] = __builtin_amdgcn_s_memrealtime();
-
+#ifdef QA_EXP_LEAN_OVERLAP
+  if (defer) {
+    // the weights are on their way; x is the predecessor's output: wait for its arrival word (bounded: a launch that cannot see it goes on and computes
+    // on whatever is there -- wrong numbers, never a hang), then make the rows visible (acquire at agent scope: the other XCDs' L2 lines of an x read
+    // in an earlier step are stale) and ask for x
+    const unsigned run = __hip_atomic_load(rest.my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / rest.my_per_exec;
+    const unsigned target = (run + 1u) * rest.wait_per_exec;
+    for (int spin = 0; spin < (1 << 16); ++spin) {
+      if ((int)(__hip_atomic_load(rest.wait_sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    issue_x();   // (sc1 requests: lean_dma16 below)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // x is the YOUNGEST request here: everything has landed
+  } else
+#endif
   // ---- 3. x has landed (it is older than every other request) ----
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LSET) : "memory");
   if constexpr (STAMP) ts[2] = __builtin_amdgcn_s_memrealtime();
@@ -354,6 +390,12 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
           if (4 * q + r < rows) {
             float v = sum[r] + bv;
             if (rest.residual) v += (float)rest.residual[(size_t)m * aN + n];
+#ifdef QA_EXP_LEAN_OVERLAP
+            if (rest.signal != nullptr) {   // rows written THROUGH to memory (sc1): the successor on another XCD asks for them with sc1 loads, no cache-wide fence on either side
+              const half_t hv = (half_t)v;
+              asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(rest.Y + (size_t)m * aN + n), "v"((unsigned)__builtin_bit_cast(unsigned short, hv)) : "memory");
+            } else
+#endif
             rest.Y[(size_t)m * aN + n] = (half_t)v;
           }
         }
@@ -369,6 +411,15 @@ __global__ __launch_bounds__(WAVES * 64) void w4a16_lean_kernel(const half_t* __
   } else {
     compute_and_finish(szr, wq, nb, 0);
   }
+#ifdef QA_EXP_LEAN_OVERLAP
+  if (rest.signal != nullptr || rest.my_cnt != nullptr) {
+    if (wave < NTW) {   // (the waves that stored rows: one-block launches)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the written-through rows are acknowledged: in memory before the word
+      if (lane == 0 && rest.signal != nullptr) __hip_atomic_fetch_add(rest.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0 && rest.my_cnt != nullptr) __hip_atomic_fetch_add(rest.my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
   if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ts[9] = __builtin_amdgcn_s_memrealtime();

@@ -10,6 +10,17 @@ namespace quick_amd {
 // (1, 2), abl: 0, 32 (in-kernel span stamps) or, tools builds, 64 (phase stamps into a.dbg); grid_x = N / 16 / ntw workgroups along the
 // channels, grid_y token blocks of 16.  false: no build for this configuration / group size.
 bool lean_launch(int waves, int tmax, int ntw, int abl, const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, hipEvent_t start, hipEvent_t stop);
+#ifdef QA_EXP_LEAN_OVERLAP
+// experiment builds: what the NEXT lean launch of this thread is told about its neighbours (consumed and cleared by that launch)
+struct LeanOverlapExp {
+  const unsigned* wait_sig;
+  unsigned* my_cnt;
+  unsigned wait_per_exec;
+  unsigned* signal;
+  int any_order;
+};
+extern thread_local LeanOverlapExp g_lean_overlap;
+#endif
 // dynamic LDS of one workgroup
 unsigned lean_lds_need(int M, int K, int waves, int ntw, bool ln, bool persist = false);
 

@@ -19,7 +19,14 @@ static bool lean_go(const GemmArgs& a, int grid_x, int grid_y, hipStream_t st, h
   const unsigned lds = lean_lds_need(a.M, a.K, WAVES, NTW, a.ln_w != nullptr, NSETS > 1);
   LeanRest rest{};
   rest.Y = a.Y; rest.bias = a.bias; rest.residual = a.residual; rest.silu_mul = a.silu_mul; rest.ln_eps = a.ln_eps; rest.span = a.span; rest.dbg = a.dbg;
-  hipExtLaunchKernelGGL(kfn, dim3(grid_x, grid_y), dim3(WAVES * 64), lds, st, start, stop, 0, a.X, a.QW, a.S, a.ln_w, a.K, a.N, a.M, (unsigned)(a.K / a.G), grid_x,
+  unsigned launch_flags = 0;
+#ifdef QA_EXP_LEAN_OVERLAP
+  rest.wait_sig = g_lean_overlap.wait_sig; rest.my_cnt = g_lean_overlap.my_cnt; rest.wait_per_exec = g_lean_overlap.wait_per_exec; rest.signal = g_lean_overlap.signal;
+  rest.my_per_exec = (unsigned)(grid_x * grid_y);
+  if (g_lean_overlap.any_order) launch_flags = hipExtAnyOrderLaunch;   // no barrier in front of this launch's packet: it is dispatched BEHIND its predecessor of the same stream and runs beside it
+  g_lean_overlap = LeanOverlapExp{};
+#endif
+  hipExtLaunchKernelGGL(kfn, dim3(grid_x, grid_y), dim3(WAVES * 64), lds, st, start, stop, launch_flags, a.X, a.QW, a.S, a.ln_w, a.K, a.N, a.M, (unsigned)(a.K / a.G), grid_x,
                         (unsigned)a.tpg, rest);
   return true;
 }

@@ -803,7 +803,9 @@ def test_rmsnorm_prologue_matches_two_launches(qa, device, M, K, N, G):
     xd = _dev(x, device) * 3
     lnw = (torch.rand(K, device=device) + 0.5).half()
     res = torch.randn(M, N, device=device).half()
-    assert K_.can_fuse_rmsnorm(M, K, N, G)
+    # (17..64 tokens [r06]: AUTO's pick is a mid-token kernel, which has no prologue -- can_fuse says "not worth fusing" and the decode loop norms in
+    # its own launch; a caller that asks for the prologue anyway is served by the fragment kernel, checked here)
+    assert K_.can_fuse_rmsnorm(M, K, N, G) or (16 < M <= 64 and K_.plan_describe(M, K, N, G).startswith("xm"))
     y1 = qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw, rmsnorm_eps=1e-5, residual=res)
     y2 = qa.gemm_forward(K_.rmsnorm(xd, lnw, 1e-5), *packed, residual=res)
     assert rel_err(y1.cpu().numpy(), y2.cpu().numpy()) <= 1e-3
