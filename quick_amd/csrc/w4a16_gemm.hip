@@ -1267,14 +1267,15 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   // (1..3; 0 = choose), bits 8-9 = 1 / 2: 32- / 64-token tiles whatever the count.  A launch of these is launch ramp + the workgroup's x and
   // weight streams one behind the other + the dequantisation + the waves' reduction, with little overlap (profiles/r06_xm_anatomy.txt),
   // so what counts is ONE round of workgroups, few bytes of x per CU and every CU busy.  The rule, from the audit of every selection against
-  // the other families on 15 layer shapes x 8 token counts (profiles/r06_xm_audit.txt: geomean pick / best 1.0002, worst 1.013; QUICK_AMD_XM=0
+  // the other families on 15 layer shapes x 8 token counts, three boxes (profiles/r06_xm_audit.txt: pick / best geomean 1.0006-1.005, worst 1.04 on two boxes; QUICK_AMD_XM=0
   // switches the family off for A/B; tools/xm_rule_eval.py restates the rule and replays it against an audit file):
   //   * K >= 4096 (the audit's layers), and only layers that ONE round of workgroups covers with <= 3 channel pairs each (N = 27648 .. 57344: the
   //     exchange-K kernels stay);
   //   * 17..32 tokens, K <= 8192: the fewest pairs per workgroup that make one round (0.72-0.97 of the others' time; longer K: the fragment kernels,
   //     whose x is 16 tokens deep, stay ahead by 7-35 %);
-  //   * 33..64 tokens on layers of <= 128 pairs (N <= 4096): two 32-token tiles x one pair -- every CU busy beats the halved dequantisation --
-  //     up to K = 11008, and up to K = 14336 from 40 tokens (0.83-0.96);
+  //   * 33..64 tokens on layers of <= 128 pairs (N <= 4096): two 32-token tiles x one pair -- every CU busy beats the halved dequantisation -- up to
+  //     K = 8192, and up to 48 tokens at K = 11008 (0.83-1.0 of the exchange launch it replaces, whose time follows the box: three boxes,
+  //     profiles/r06_xm_audit.txt; 56 / 64 tokens there and K = 14336 were ahead on one box and 4-16 % behind on two: not taken);
   //   * 33..64 tokens, wider layers, K <= 8192: two 32-token tiles x <= 2 pairs where that is one round (N = 5120 .. 8192: 0.82-0.93; layers that
   //     leave > 30 % of the CUs idle only from 56 tokens), else 64-token tiles x the fewest pairs that make one round (N = 10240 .. 22016: 0.87-1.0).
   {
@@ -1302,7 +1303,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       if (M <= 32) {
         if (KT <= 64 && (pr = one_round(1))) mb = 1;
       } else if (2 * pairs <= cus) {
-        if (KT <= 86 || (KT <= 112 && M >= 40)) mb = 1, pr = 1;
+        if (KT <= 64 || (KT <= 86 && M <= 48)) mb = 1, pr = 1;   // (K = 11008 at 56 / 64 tokens: 4-7 % behind the exchange launch on two boxes of three, 13 % ahead on the third; K = 14336: ahead on the audit's first box only, 7-16 % behind the eight-slice exchange launch on two more -- not taken)
       } else if (KT <= 64) {
         const int p1 = one_round(2), p2 = one_round(1);
         if (p1 && p1 <= 2) {

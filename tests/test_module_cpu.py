@@ -235,9 +235,10 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(64, 4096, 6144).startswith("xm tokens=32 channels=64 waves=8 grid=96x2") and plan(64, 8192, 8192).startswith("xm tokens=32 channels=64 waves=8 grid=128x2")
     assert plan(48, 4096, 22016).startswith("xm tokens=64 channels=96 waves=8 grid=230x1") and plan(64, 4096, 22016).startswith("xm tokens=64 channels=96 waves=8 grid=230x1")
     assert plan(64, 4096, 12288).startswith("xm tokens=64 channels=64 waves=8 grid=192x1") and plan(33, 5120, 15360).startswith("xm tokens=64 channels=64 waves=8 grid=240x1")
-    # longer K: two 32-token tiles x one pair on the <= 4096-wide layers from 33 tokens (K = 14336: from 40); the fragment kernels up to 32 tokens
-    assert plan(64, 11008, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x2") and plan(33, 11008, 4096).startswith("xm") and not plan(32, 11008, 4096).startswith("xm")
-    assert plan(40, 14336, 4096).startswith("xm tokens=32 channels=32") and not plan(39, 14336, 4096).startswith("xm") and not plan(64, 13824, 5120).startswith("xm")
+    # longer K: two 32-token tiles x one pair on the <= 4096-wide layers from 33 tokens up to K = 11008 (there: up to 48 tokens); the fragment kernels up to 32 tokens
+    assert plan(48, 11008, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x2") and plan(33, 11008, 4096).startswith("xm") and not plan(32, 11008, 4096).startswith("xm")
+    assert not plan(56, 11008, 4096).startswith("xm") and not plan(64, 11008, 4096).startswith("xm")   # (the exchange launch is level or ahead there on two boxes of three)
+    assert not plan(40, 14336, 4096).startswith("xm") and not plan(64, 14336, 4096).startswith("xm") and not plan(64, 13824, 5120).startswith("xm")
     # layers one round does not cover with three pairs per workgroup, and layers that leave > 30 % of the CUs idle below 56 tokens: the r03-r05 picks
     assert not plan(64, 4096, 28672).startswith("xm") and not plan(24, 8192, 57344).startswith("xm") and not plan(64, 28672, 8192).startswith("xm")
     assert not plan(48, 5120, 5120).startswith("xm") and plan(56, 5120, 5120).startswith("xm tokens=32 channels=64 waves=8 grid=80x2") and not plan(65, 4096, 4096).startswith("xm")
@@ -289,7 +290,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     # third audit (17..64 tokens, layer shapes the rules were not tuned on): the four-tile skinny kernel by its own geometry
     assert plan(32, 4096, 6144, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4") and plan(32, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4")    # one round of workgroups, <= 64 stages each (AUTO at 17..32 tokens: the r06 mid-token kernels)
     assert plan(48, 5120, 5120).startswith("skinny ntw=4") and plan(55, 5120, 5120).startswith("xk tokens=64")    # 320 skinny workgroups would be two rounds; r03: 40 tiles x 4 slices (from 56 tokens: r06's mid-token kernels)
-    assert plan(32, 13824, 5120).startswith("tiled") and "slices=8" in plan(39, 14336, 4096)                      # slices of > 64 stages; r03 from 33 tokens: 32 tiles x 8 slices of 14 stages (from 40 tokens: r06's mid-token kernels)
+    assert plan(32, 13824, 5120).startswith("tiled") and "slices=8" in plan(48, 14336, 4096)                      # slices of > 64 stages; r03 from 33 tokens: 32 tiles x 8 slices of 14 stages
     assert "tokens=32 channels=128 waves=8 grid=192x1 ksplit=1" in plan(64, 4096, 12288, kernel_id=T)              # twice the tiles, nothing to reduce
     assert plan(48, 8192, 10240).startswith("xm tokens=64 channels=64 waves=8 grid=160x1")   # (r06; r05: four-wave 64 x 128 tiles x two slices; r02-r04: wide tiles, three K slices)
     assert plan(64, 11008, 4096, kernel_id=T).startswith("tiled tokens=32") and "slices=8" in plan(48, 11008, 4096, kernel_id=X)

@@ -16,9 +16,10 @@ def load(path):
 def short(plan):
     m = re.match(r"(\w+) (?:tokens=(\d+) channels=(\d+)|ntw=(\d+) waves=(\d+))", plan)
     s = re.search(r"(slices|ksplit)=(\d+)", plan)
+    tail = f"{s.group(1)}={s.group(2)}" if s else "slices=1"      # (the mid-token kernels: all of K in one workgroup)
     if m.group(2):
-        return f"{m.group(1)} tokens={m.group(2)} channels={m.group(3):<11s} {s.group(1)}={s.group(2)}"
-    return f"{m.group(1)} ntw={m.group(4)} waves={m.group(5):<15s} {s.group(1)}={s.group(2)}"
+        return f"{m.group(1)} tokens={m.group(2)} channels={m.group(3):<11s} {tail}"
+    return f"{m.group(1)} ntw={m.group(4)} waves={m.group(5):<15s} {tail}"
 
 files = [load(p) for p in sys.argv[1:]]
 rows = []
@@ -39,7 +40,7 @@ for shape in files[0]:
     g = float(np.median(gaps))
     rows.append((shape, line, g, gaps))
 gs = np.array([r[2] for r in rows])
-print(f"# r05 planner audit on the final tree: AUTO (min over its samples) against forced launches of every family, {len(rows)} shapes, {len(files)} session(s)")
+print(f"# planner audit: AUTO (min over its samples) against forced launches of every family, {len(rows)} shapes, {len(files)} session(s)")
 print(f"# geometric mean auto / best = {np.exp(np.mean(np.log(gs))):.4f}; worst {gs.max():.3f}; shapes with a gap > 3 %: {(gs > 1.03).sum()}, > 5 %: {(gs > 1.05).sum()}")
 for shape, (plan, auto, bn, bt), g, gaps in rows:
     extra = ("  [" + " ".join(f"{x:.3f}" for x in gaps) + "]") if len(gaps) > 1 else ""

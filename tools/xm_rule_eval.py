@@ -34,7 +34,7 @@ def rule(M, K, N):
         pr = one_round(pairs, 1)
         return (1, pr) if pr and KT <= 64 else None
     if 2 * pairs <= CUS:                                  # two 32-token tiles x one pair: every CU busy beats the halved dequantisation
-        return (1, 1) if KT <= 86 or (KT <= 112 and M >= 40) else None
+        return (1, 1) if KT <= 64 or (KT <= 86 and M <= 48) else None
     if KT > 64:
         return None
     p1, p2 = one_round(pairs, 2), one_round(pairs, 1)
