@@ -126,11 +126,13 @@ int quick_w4a16_workspace_check(const void* workspace, size_t workspace_bytes, v
  *   bits 0-3    family, QUICK_KERNEL_*
  *   bits 4-7    SKINNY: channel tiles of 16 per workgroup (1, 2, 4; 8 = [r05] the straight-line eight-tile fragment kernel where it is built --
  *               9..16 tokens, G = 128, K / 128 = 8 waves x slices x {2, 4, 7, 8} k tiles, no RMSNorm prologue -- else 4); TILED: token tiles of 16 per workgroup (2, 4, 8);
- *               WIDE / XK / XW: token tiles of 32 per workgroup (WIDE 2, 4, 8; XK 2, 4; XW 2, 4, 8 -- 0 = 4; 8 = the 256 x 256 tile)
- *   bits 8-11   SKINNY / TILED / LEAN: waves per workgroup / 4; WIDE: 32-channel pairs per wave (1, 2); XK: K slices per tile (1, 2, 4, 8; 15 = half
+ *               WIDE / XK / XW: token tiles of 32 per workgroup (WIDE 2, 4, 8; XK 2, 4; XW 2, 4, 8 -- 0 = 4; 8 = the 256 x 256 tile; [r06] WIDE 8 x 2 pairs runs
+ *               128 x 256 tiles: r02's hipcc-scheduled 256 x 256 tile spilled registers and lives on in tools builds only);
+ *               XM: 32-channel pairs per workgroup (1..3; 0 = the fewest that cover the layer in one round)
+ *   bits 8-11   SKINNY / TILED / LEAN: waves per workgroup / 4 ([r06] SKINNY: sixteen waves only with one channel tile per workgroup); XM (bits 8-9): 1 = 32-token tiles, 2 = 64-token tiles; WIDE: 32-channel pairs per wave (1, 2); XK: K slices per tile (1, 2, 4, 8; 15 = half
  *               the planner's count); XW: K slices per tile (1, 2, 4 <= token tiles)
  *   bit 12      SKINNY: no LDS copy of x; WIDE: the double-buffered kernel at every tile size (no ring); XW: 128-channel tiles (implied by 2 token tiles)
- *   bit 13      TILED: 32x32x16 MFMA flavour         bit 14  TILED / WIDE / XK: plain (not XCD-aware) tile order
+ *   bit 13      TILED: retired in r06 (r01's 32x32x16 flavour: QUICK_ERR_INVALID_ARGUMENT)         bit 14  TILED / WIDE / XK: plain (not XCD-aware) tile order
  *   bit 15      TILED: 2 x 4 wave grid; WIDE: eight waves per workgroup (ring kernel)
  *   bits 16-20  timing experiments (wrong results on purpose, phase stamps): only in a QUICK_AMD_TOOLS build of the library
  *               (`python -m quick_amd.build --tools`); the product library answers QUICK_ERR_INVALID_ARGUMENT
