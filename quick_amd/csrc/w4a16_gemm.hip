@@ -1276,6 +1276,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
   //   * 33..64 tokens on layers of <= 128 pairs (N <= 4096): two 32-token tiles x one pair -- every CU busy beats the halved dequantisation -- up to
   //     K = 8192, and up to 48 tokens at K = 11008 (0.83-1.0 of the exchange launch it replaces, whose time follows the box: three boxes,
   //     profiles/r06_xm_audit.txt; 56 / 64 tokens there and K = 14336 were ahead on one box and 4-16 % behind on two: not taken);
+  //   * 65..128 tokens: the rule and its audit sit at the branch below;
   //   * 33..64 tokens, wider layers, K <= 8192: two 32-token tiles x <= 2 pairs where that is one round (N = 5120 .. 8192: 0.82-0.93; layers that
   //     leave > 30 % of the CUs idle only from 56 tokens), else 64-token tiles x the fewest pairs that make one round (N = 10240 .. 22016: 0.87-1.0).
   {
@@ -1299,8 +1300,19 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       pr = mt_req ? std::max(1, std::min(3, mt_req)) : 1;
       if (!mt_req)
         while (pr < 3 && (long)((pairs + pr - 1) / pr) * ((M + mb * 32 - 1) / (mb * 32)) > cus) ++pr;
-    } else if (family == QUICK_KERNEL_AUTO && xm_on && !with_ln && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M > 16 && M <= 64 && KT >= 32) {   // (K >= 4096: what the audit measured)
-      if (M <= 32) {
+    } else if (family == QUICK_KERNEL_AUTO && xm_on && !with_ln && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M > 16 && M <= 128 && KT >= 32) {   // (K >= 4096: what the audit measured)
+      if (M > 64) {
+        // [r06, profiles/r06_xm_audit_65_128.txt, three boxes] 65..128 tokens against the four-slice exchange launches that ran them:
+        //   * three or four 32-token tiles x the fewest pairs that make ONE round where that is <= 2 pairs (N <= 5120; K <= 8192: 0.70-0.88, 80 x 4096 x 4096
+        //     11.8 -> 8.9 us, 128 x: 10.7 -> 9.0-9.7; K = 11008 up to 80 tokens: 0.85-0.90) or, up to 96 tokens, 3 pairs (4096 x 6144: 0.86-0.97);
+        //   * else two 64-token tiles x <= 2 pairs on K = 4096 layers that this fills to >= 80 % (4096 x 8192: 0.67-0.91), and up to 95 tokens x <= 3 pairs
+        //     with K <= 8192 (80 x 4096 x 12288 19.5-20.9 -> 16.2-17.2 us, 80 x 8192 x 10240 31.7-32.6 -> 28.4-29.1: the exchange-K 64-token tiles those counts fall to);
+        //   * wider layers, longer K, more tokens: level or behind the four-wave / exchange-K picks -- they stay.
+        const int p1 = one_round((M + 31) / 32), p2 = one_round(2);
+        if (p1 && p1 <= 2 && (KT <= 64 || (KT <= 86 && M <= 80))) mb = 1, pr = p1;
+        else if (p1 == 3 && M <= 96 && KT <= 64) mb = 1, pr = 3;
+        else if (p2 && 10 * ((pairs + p2 - 1) / p2 * 2) >= 8 * cus && ((p2 <= 2 && KT <= 32) || (M <= 95 && KT <= 64))) mb = 2, pr = p2;
+      } else if (M <= 32) {
         if (KT <= 64 && (pr = one_round(1))) mb = 1;
       } else if (2 * pairs <= cus) {
         if (KT <= 64 || (KT <= 86 && M <= 48)) mb = 1, pr = 1;   // (K = 11008 at 56 / 64 tokens: 4-7 % behind the exchange launch on two boxes of three, 13 % ahead on the third; K = 14336: ahead on the audit's first box only, 7-16 % behind the eight-slice exchange launch on two more -- not taken)

@@ -805,7 +805,7 @@ def test_rmsnorm_prologue_matches_two_launches(qa, device, M, K, N, G):
     res = torch.randn(M, N, device=device).half()
     # (17..64 tokens [r06]: AUTO's pick is a mid-token kernel, which has no prologue -- can_fuse says "not worth fusing" and the decode loop norms in
     # its own launch; a caller that asks for the prologue anyway is served by the fragment kernel, checked here)
-    assert K_.can_fuse_rmsnorm(M, K, N, G) or (16 < M <= 64 and K_.plan_describe(M, K, N, G).startswith("xm"))
+    assert K_.can_fuse_rmsnorm(M, K, N, G) or (16 < M <= 128 and K_.plan_describe(M, K, N, G).startswith("xm"))
     y1 = qa.gemm_forward(xd, *packed, rmsnorm_weight=lnw, rmsnorm_eps=1e-5, residual=res)
     y2 = qa.gemm_forward(K_.rmsnorm(xd, lnw, 1e-5), *packed, residual=res)
     assert rel_err(y1.cpu().numpy(), y2.cpu().numpy()) <= 1e-3
@@ -1627,7 +1627,7 @@ def test_lean_persistent_launches_equal_the_one_block_launches(qa, device, M, K,
 
 
 # ------------------------------------------------------------------------------------------------
-# [r06] mid-token kernels (w4a16_xm.hpp): 17..64 tokens, one workgroup per 32 / 64 tokens x 1..3 channel pairs, eight waves splitting K
+# [r06] mid-token kernels (w4a16_xm.hpp): 17..128 tokens, one workgroup per 32 / 64 tokens x 1..3 channel pairs, eight waves splitting K
 # ------------------------------------------------------------------------------------------------
 XM = 7
 
@@ -1712,19 +1712,20 @@ def test_xm_golden_fixtures_reference_pin_and_exact_dequantisation(qa, device, p
 
 
 def test_xm_planner_picks_against_oracle_on_layer_shapes(qa, device):
-    """What AUTO runs at 17..64 tokens on the decode layer shapes (sampled channels against the oracle): the mid-token kernels where the audit
-    has them ahead, the r03-r05 picks elsewhere -- every one right, and the picks are the ones profiles/r06_xm_audit.txt was measured with."""
+    """What AUTO runs at 17..128 tokens on the decode layer shapes (sampled channels against the oracle): the mid-token kernels where the audits
+    have them ahead, the r03-r05 picks elsewhere -- every one right, and the picks are the ones profiles/r06_xm_audit.txt and
+    r06_xm_audit_65_128.txt were measured with."""
     from quick_amd import kernels as K_
     G = 128
     seen = set()
-    for (K, N) in ((4096, 4096), (4096, 12288), (4096, 22016), (4096, 6144), (8192, 8192), (11008, 4096), (5120, 5120), (4096, 28672)):
+    for (K, N) in ((4096, 4096), (4096, 12288), (4096, 22016), (4096, 6144), (8192, 8192), (11008, 4096), (5120, 5120), (4096, 28672), (4096, 8192), (8192, 4096)):
         _, iw, s, z = oracle.make_synthetic(1, K, N, G, seed=K + N)
         packed = _pack_dev(iw, s, z, device)
         cols = np.random.default_rng(N).choice(N, 256, replace=False)
-        for M in (17, 32, 33, 48, 64):
+        for M in (17, 32, 33, 48, 64, 65, 80, 95, 96, 113, 128):
             x = (np.random.default_rng(M).standard_normal((M, K)) * 0.5).astype(np.float16)
             want = oracle.w4a16_forward(x, iw[:, cols], s[:, cols], z[:, cols], G).astype(np.float32)
             y = qa.gemm_forward(_dev(x, device), *packed)
             assert rel_err(y.cpu().numpy()[:, cols], want) <= TOL, (M, K, N)
-            seen.add(K_.plan_describe(M, K, N, G).split()[0])
-    assert "xm" in seen and len(seen) >= 3
+            seen.add(K_.plan_describe(M, K, N, G).split()[0] + (" 65+" if M > 64 else ""))
+    assert "xm" in seen and "xm 65+" in seen and len(seen) >= 5

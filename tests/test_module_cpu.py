@@ -171,7 +171,7 @@ def test_exchange_cus_override_keeps_k_slices_on_one_cu():
     code = ("from quick_amd import kernels; print(kernels.plan_describe(65, 4096, 4096, 128)); "
             "print(kernels.plan_describe(512, 4096, 4096, 128, kernel_id=4 | (4 << 4) | (2 << 8)))")
     def run(env):
-        e = dict(os.environ, **env)
+        e = dict(os.environ, QUICK_AMD_XM="0", **env)     # (the exchange families' pick: r06's mid-token kernels own this shape by default)
         return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=e).stdout.strip().splitlines()[-2:]
     auto, forced = run({})
     assert "slices=4" in auto and "slices=2" in forced
@@ -194,16 +194,16 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "grid=464x1x1" in plan(1, 4096, 22016, kernel_id=kernels.KERNEL_SKINNY)          # 1376 blocks in 3 rounds of <= 464
     assert "dequant=exact" in plan(8, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)            # one block per workgroup: the table does not pay
     assert plan(64, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4") and "deferred-zero-fragment" in plan(64, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)   # (r01-r05's pick; AUTO: the r06 mid-token kernels, below)
-    assert plan(65, 4096, 4096).startswith("xk tokens=64") and "slices=4" in plan(65, 4096, 4096)   # r03: 32 exchange-K tiles x 4 K slices = one round
+    assert plan(65, 14336, 4096).startswith("xk tokens=64") and "slices=4" in plan(65, 14336, 4096)   # r03: 64 exchange-K tiles x 4 K slices = one round (K = 4096 there until r06 gave 65..128 tokens x K <= 8192 to the mid-token kernels)
     assert plan(32, 4096, 8192, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4")   # 256 workgroups of 64 channels x 16 tokens: one round, 32 stages each
     assert plan(32, 4096, 28672).startswith("tiled")         # (r01: where the skinny workgroups would be two rounds, the tiled kernel, no K split needed)
     # K split until the 256 CUs are covered; the workspace is what workspace_bytes_ex says
     p = plan(128, 4096, 4096, kernel_id=kernels.KERNEL_TILED)
     assert "tokens=32 channels=128" in p and "ksplit=2" in p
     assert p.endswith(f"workspace={_lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, kernels.KERNEL_TILED, 0)}")
-    p = plan(128, 4096, 4096)
+    p = plan(128, 11008, 4096)
     # (what workspace_bytes_ex asks for also covers the launch a SiLU * mul epilogue falls back to where the exchange-K plan cannot carry it)
-    assert "slices=4" in p and int(p.rsplit("workspace=", 1)[1]) == 65536 + (16 << 20) <= _lib.load().quick_w4a16_workspace_bytes_ex(128, 4096, 4096, 128, 0, 0)
+    assert "slices=4" in p and int(p.rsplit("workspace=", 1)[1]) == 65536 + (16 << 20) <= _lib.load().quick_w4a16_workspace_bytes_ex(128, 11008, 4096, 128, 0, 0)
     assert plan(64, 8192, 10240).startswith("xm tokens=64 channels=64 waves=8 grid=160x1")   # r06's mid-token kernels (r05 audit: 80 tiles of 64 x 128 x two exchange slices, level with it; r02-r04: wide tiles, three K slices)
     assert "grid=80x3 ksplit=3" in plan(64, 8192, 10240, kernel_id=kernels.KERNEL_TILED)
     # r01's tiled kernel (kernel_id TILED; the planner's own choice for G < 128): 256-channel tiles by how they quantise onto 256 CUs
@@ -225,8 +225,8 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(512, 4096, 4096, kernel_id=X).startswith("xk tokens=128") and plan(512, 4096, 4096, kernel_id=X | (2 << 4)).startswith(
         "xk tokens=64 channels=128 waves=8 ring=5 queue=4 grid=256 slices=1")                            # r03's bench line: one 64 x 128 tile per CU
     assert plan(64, 4096, 22016, kernel_id=X).startswith("xk tokens=64") and "slices=2" in plan(64, 4096, 12288, kernel_id=X)   # 172 / 96 tiles of 64 x 128 (r03's picks there; AUTO up to 64 tokens: r06's mid-token kernels, below)
-    assert plan(128, 4096, 4096).startswith("xw tokens=128 channels=128") and "grid=128 slices=4" in plan(128, 4096, 4096)   # r05 audit: one row of 128 x 128 tiles x four slices (r03-r04: xk 64-token tiles)
-    assert plan(80, 5120, 5120).startswith("xw tokens=64 channels=128") and plan(48, 5120, 5120).startswith("skinny ntw=4")        # 33..64 tokens where the mid-token kernels are not ahead: the r03-r05 picks
+    assert plan(128, 11008, 4096).startswith("xw tokens=128 channels=128") and "grid=128 slices=4" in plan(128, 11008, 4096)   # r05 audit: one row of 128 x 128 tiles x four slices (r03-r04: xk 64-token tiles; K = 4096: r06's mid-token kernels, below)
+    assert plan(80, 13824, 5120).startswith("xw tokens=64 channels=128") and plan(48, 5120, 5120).startswith("skinny ntw=4")        # 33..64 tokens where the mid-token kernels are not ahead: the r03-r05 picks
     # [r06] the mid-token kernels (w4a16_xm.hpp), where the audit has them ahead (profiles/r06_xm_audit.txt): 17..32 tokens -- the fewest channel pairs
     # per workgroup that cover the layer in one round; 33..64 tokens -- two 32-token tiles on layers of <= 8192 channels; K <= 8192
     assert plan(64, 4096, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x2") and plan(33, 4096, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x2")
@@ -241,7 +241,16 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert not plan(40, 14336, 4096).startswith("xm") and not plan(64, 14336, 4096).startswith("xm") and not plan(64, 13824, 5120).startswith("xm")
     # layers one round does not cover with three pairs per workgroup, and layers that leave > 30 % of the CUs idle below 56 tokens: the r03-r05 picks
     assert not plan(64, 4096, 28672).startswith("xm") and not plan(24, 8192, 57344).startswith("xm") and not plan(64, 28672, 8192).startswith("xm")
-    assert not plan(48, 5120, 5120).startswith("xm") and plan(56, 5120, 5120).startswith("xm tokens=32 channels=64 waves=8 grid=80x2") and not plan(65, 4096, 4096).startswith("xm")
+    assert not plan(48, 5120, 5120).startswith("xm") and plan(56, 5120, 5120).startswith("xm tokens=32 channels=64 waves=8 grid=80x2")
+    # 65..128 tokens (profiles/r06_xm_audit_65_128.txt, three boxes): 32-token tiles x the fewest pairs that make one round on narrow layers with K <= 8192
+    # (K = 11008 up to 80 tokens), 64-token tiles on wide ones up to 95 tokens (two pairs and K = 4096: up to 128); the four-slice exchange launches elsewhere
+    assert plan(65, 4096, 4096).startswith("xm tokens=32 channels=64 waves=8 grid=64x3") and plan(128, 4096, 4096).startswith("xm tokens=32 channels=64 waves=8 grid=64x4")
+    assert plan(80, 11008, 4096).startswith("xm tokens=32 channels=64") and not plan(96, 11008, 4096).startswith("xm") and not plan(65, 14336, 4096).startswith("xm")
+    assert plan(96, 5120, 5120).startswith("xm tokens=32 channels=64 waves=8 grid=80x3") and not plan(112, 5120, 5120).startswith("xm")
+    assert plan(96, 4096, 6144).startswith("xm tokens=32 channels=96 waves=8 grid=64x3") and not plan(128, 4096, 6144).startswith("xm")
+    assert plan(128, 4096, 8192).startswith("xm tokens=64 channels=64 waves=8 grid=128x2") and plan(80, 8192, 8192).startswith("xm tokens=64 channels=64") and not plan(96, 8192, 8192).startswith("xm")
+    assert plan(95, 4096, 12288).startswith("xm tokens=64 channels=96 waves=8 grid=128x2") and not plan(96, 4096, 12288).startswith("xm") and plan(95, 8192, 10240).startswith("xm tokens=64 channels=96")
+    assert not plan(65, 4096, 22016).startswith("xm") and not plan(65, 4096, 28672).startswith("xm") and not plan(129, 4096, 4096).startswith("xm")
     assert not plan(64, 4096, 4096, G=64).startswith("xm") and not plan(64, 4608, 4096, G=384).startswith("xm")               # G a power-of-two multiple of 128
     assert plan(40, 4096, 4096, kernel_id=kernels.KERNEL_XM | (3 << 4) | (2 << 8)).startswith("xm tokens=64 channels=96 waves=8 grid=43x1")   # forced: pairs, 64-token tiles; ragged last block
     # r04: the four-wave kernels with generated loops (w4a16_xw.hpp) from 160 tokens (96 on wide layers), picked by their own launch-time model
@@ -250,7 +259,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(160, 4096, 6144).startswith("xw tokens=128 channels=128") and "slices=2" in plan(160, 4096, 6144)
     assert plan(1024, 4096, 4096).startswith("xw tokens=128 channels=128 waves=4 ring=4 queue=4 grid=256 slices=1")   # 256 tiles of 128 x 128: one round, nothing to exchange
     assert "slices=2" in plan(512, 11008, 4096) and "xw tokens=128 channels=128" in plan(512, 11008, 4096)            # 128 tiles x 2 slices of 43 stages
-    assert plan(96, 4096, 22016).startswith("xw tokens=128 channels=128") and plan(96, 4096, 4096).startswith("xw tokens=128 channels=128")   # from 96 tokens on every layer since r05
+    assert plan(96, 4096, 22016).startswith("xw tokens=128 channels=128") and plan(96, 11008, 4096).startswith("xw tokens=128 channels=128")   # from 96 tokens on every layer since r05
     assert plan(2048, 3584, 18944).startswith("xw tokens=256 channels=256")                            # several rounds: the 256 x 256 tile, since r04 with the generated loop
     assert plan(2048, 4096, 4096).startswith("xw tokens=128 channels=256") and "xw tokens=256 channels=256 waves=4 ring=2 queue=2 grid=2752 slices=1" in plan(8192, 4096, 22016)
     assert plan(1024, 28672, 8192).startswith("xw tokens=128 channels=256 waves=4 ring=4 queue=4 grid=256 slices=1")   # (r02: 128 tiles of 256 x 256 x 2 K slices; 256 one-slice tiles of 128 x 256 are 10 % ahead)

@@ -28,7 +28,16 @@ def one_round(pairs, mt):
 def rule(M, K, N):
     """-> (mb, pr) or None: the rule of make_plan (w4a16_gemm.hip), restated"""
     pairs, KT = N // 32, K // 128
-    if KT < 32 or M <= 16 or M > 64:
+    if KT < 32 or M <= 16 or M > 128:
+        return None
+    if M > 64:
+        p1, p2 = one_round(pairs, -(-M // 32)), one_round(pairs, 2)
+        if p1 and p1 <= 2 and (KT <= 64 or (KT <= 86 and M <= 80)):
+            return (1, p1)
+        if p1 == 3 and M <= 96 and KT <= 64:
+            return (1, 3)
+        if p2 and 10 * (-(-pairs // p2) * 2) >= 8 * CUS and ((p2 <= 2 and KT <= 32) or (M <= 95 and KT <= 64)):
+            return (2, p2)
         return None
     if M <= 32:
         pr = one_round(pairs, 1)
