@@ -54,7 +54,7 @@ extern "C" {
 #define QUICK_KERNEL_LEAN 6   /* [r05] 1..16 tokens: one workgroup per 16 tokens x 16 channels, its waves split K; x by LDS-DMA FIRST in the
                                  memory queue, every weight tile of a wave requested up front, unit sums computed under the weights'
                                  flight (G % 128 == 0, K / 128 between waves and 16 * waves; else QUICK_ERR_UNSUPPORTED when forced) */
-#define QUICK_KERNEL_XM 7     /* [r06] 17..64 tokens: one workgroup per 32 / 64 tokens x 32..96 channels for all of K, eight waves splitting K, each
+#define QUICK_KERNEL_XM 7     /* [r06] 17..128 tokens: one workgroup per 32 / 64 tokens x 32..96 channels for all of K, eight waves splitting K, each
                                  with its own x ring (LDS-DMA) and weight queue in a generated loop without barriers; every dequantised
                                  fragment feeds all token blocks (G a power-of-two multiple of 128, K / 128 >= 8) */
 

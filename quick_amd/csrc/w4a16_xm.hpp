@@ -1,4 +1,4 @@
-// Mid-token kernels (r06): 17..64 tokens (two token tiles: up to 128), the regime of the reference's _m32n128k32 / _m64n128k32 kernels and its
+// Mid-token kernels (r06): 17..128 tokens (AUTO: 17..64 on layers one round covers, 65..128 on narrow ones), the regime of the reference's _m32n128k32 / _m64n128k32 kernels and its
 // compute_gemm_x2 (csrc/gemm_cuda_quick.cu:1293-1397, :458-1196) -- a dequantised weight fragment feeds EVERY token block of the tile.
 //
 // One workgroup = MB x 32 tokens x PR x 32 channels for the whole K (or a K slice); its eight waves split the k tiles.  Each wave is a
