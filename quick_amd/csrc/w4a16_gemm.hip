@@ -1302,16 +1302,18 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         while (pr < 3 && (long)((pairs + pr - 1) / pr) * ((M + mb * 32 - 1) / (mb * 32)) > cus) ++pr;
     } else if (family == QUICK_KERNEL_AUTO && xm_on && !with_ln && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k <= 1 && envelope && M > 16 && M <= 128 && KT >= 32) {   // (K >= 4096: what the audit measured)
       if (M > 64) {
-        // [r06, profiles/r06_xm_audit_65_128.txt, three boxes] 65..128 tokens against the four-slice exchange launches that ran them:
-        //   * three or four 32-token tiles x the fewest pairs that make ONE round where that is <= 2 pairs (N <= 5120; K <= 8192: 0.70-0.88, 80 x 4096 x 4096
-        //     11.8 -> 8.9 us, 128 x: 10.7 -> 9.0-9.7; K = 11008 up to 80 tokens: 0.85-0.90) or, up to 96 tokens, 3 pairs (4096 x 6144: 0.86-0.97);
-        //   * else two 64-token tiles x <= 2 pairs on K = 4096 layers that this fills to >= 80 % (4096 x 8192: 0.67-0.91), and up to 95 tokens x <= 3 pairs
-        //     with K <= 8192 (80 x 4096 x 12288 19.5-20.9 -> 16.2-17.2 us, 80 x 8192 x 10240 31.7-32.6 -> 28.4-29.1: the exchange-K 64-token tiles those counts fall to);
-        //   * wider layers, longer K, more tokens: level or behind the four-wave / exchange-K picks -- they stay.
+        // [r06, profiles/r06_xm_audit_65_128.txt (three boxes) and r06_planner_audit.txt, third section (two more, every family forced)] 65..128 tokens against the
+        // four-slice 128 x 128 four-wave tile:
+        //   * three or four 32-token tiles x the fewest pairs that make ONE round where that is <= 2 pairs (N <= 5120; K <= 8192: 80 x 4096 x 4096 10.7-11.8 -> 8.4-8.9 us,
+        //     128 x: 11.0 -> 9.0-10.6, 96 x 5120 x 5120 12.7 -> 11.0; K = 11008 up to 80 tokens: 19.4 -> 18.6-19.3) or, up to 96 tokens, 3 pairs (4096 x 6144: 0.92-1.0);
+        //   * else two 64-token tiles x <= 2 pairs that fill >= 80 % of the CUs: K = 4096 up to 128 tokens (4096 x 8192: 20.5 -> 13.6-15.0), K <= 8192 up to 95
+        //     (8192 x 8192: 24.4 -> 21.9 on three boxes of four; the four-wave tile follows the box there, 18.8-25.4 us);
+        //   * three pairs of 64-token tiles (4096 x 12288, 8192 x 10240) were ahead of the 64-token exchange tiles those counts ran until this audit, but are level with / 12 %
+        //     behind the 128 x 128 four-wave tile, which the planner runs from 65 tokens since (below): not taken.  Wider layers, longer K: behind -- they stay.
         const int p1 = one_round((M + 31) / 32), p2 = one_round(2);
         if (p1 && p1 <= 2 && (KT <= 64 || (KT <= 86 && M <= 80))) mb = 1, pr = p1;
         else if (p1 == 3 && M <= 96 && KT <= 64) mb = 1, pr = 3;
-        else if (p2 && 10 * ((pairs + p2 - 1) / p2 * 2) >= 8 * cus && ((p2 <= 2 && KT <= 32) || (M <= 95 && KT <= 64))) mb = 2, pr = p2;
+        else if (p2 && 10 * ((pairs + p2 - 1) / p2 * 2) >= 8 * cus && p2 <= 2 && (KT <= 32 || (M <= 95 && KT <= 64))) mb = 2, pr = p2;
       } else if (M <= 32) {
         if (KT <= 64 && (pr = one_round(1))) mb = 1;
       } else if (2 * pairs <= cus) {
@@ -1501,7 +1503,8 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
     // (where the 256 x 256 tile is the pick they compete only if it runs with a K split: 1024 x 28672 x 8192, 128 tiles x 2 slices, 419 us
     // against 379 on 256 tiles of 128 x 256 -- profiles/r04_xw256.txt)
     if (best > 0 && allow_xk && (wide_mb != 8 || (N % 256 == 0 && wide_split((long)((M + 255) / 256) * (N / 256)) > 1)) && (G / 128 & (G / 128 - 1)) == 0 &&
-        M >= 96 &&   // [r05 sweep, profiles/r05_mid_sweep.txt: from 96 tokens on the narrow layers as well -- 96 / 128 x 4096 x 4096 12.4 / 12.6 -> 11.4 / 11.6 us, x 5120 x 5120 14.8 / 16.9 -> 13.6 / 13.9, x 8192 x 8192 27.9 / 29.1 -> 25.0 / 26.0, x 13824 x 5120 29.5 -> 25.4; at 33..64 tokens no four-wave tile beats the r03 picks by more than the session noise]
+        M >= 65 &&   // [r06 audit at 80 tokens, profiles/r06_planner_audit.txt: from 65 tokens -- the 128 x 128 tile with its upper rows empty is 10-32 % ahead of the 64-token
+                     // exchange tiles these counts fell to: 80 x 4096 x 22016 29.8 -> 25.4 us, x 13824 x 5120 31.6 -> 23.4, x 28672 x 8192 66.0 -> 55.8]   [r05 sweep, profiles/r05_mid_sweep.txt: from 96 tokens on the narrow layers as well -- 96 / 128 x 4096 x 4096 12.4 / 12.6 -> 11.4 / 11.6 us, x 5120 x 5120 14.8 / 16.9 -> 13.6 / 13.9, x 8192 x 8192 27.9 / 29.1 -> 25.0 / 26.0, x 13824 x 5120 29.5 -> 25.4; at 33..64 tokens no four-wave tile beats the r03 picks by more than the session noise]
 
         (size_t)M * (size_t)K * 2 < ((size_t)1 << 32) && (size_t)M * (size_t)N * 2 < ((size_t)1 << 32)) {
       struct XwCand { int mb, pairs; double c, a, b_ceil, b_frac, s0, s1, d; };
@@ -1514,7 +1517,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         if (N % (pairs * 128) != 0) continue;
         const long T = (long)((M + mb * 32 - 1) / (mb * 32)) * (N / (pairs * 128));
         for (int sx = 1; sx <= mb && sx <= 4; sx *= 2) {
-          if (sx > 1 && (T * sx > 256 || KT / sx < 4 || (KT + (KT + sx - 1) / sx - 1) / ((KT + sx - 1) / sx) != sx)) continue;
+          if (sx > 1 && (T * sx > std::min(256, exchange_cus()) || KT / sx < 4 || (KT + (KT + sx - 1) / sx - 1) / ((KT + sx - 1) / sx) != sx)) continue;
           const double f = (double)(T * sx) / 256.0, n = (double)((T * sx + 255) / 256), stages = (double)((KT + sx - 1) / sx);
           // (- 0.5 us with slices: the exchange lost its atomics after the fit -- 512 x 4096 x 4096 22.0 -> 21.5 / 24.2 -> 23.3 us on two / four
           // slices, profiles/r04_ab_exchange.txt)
@@ -1584,12 +1587,13 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
       (size_t)M * (size_t)K * 2 < ((size_t)1 << 32) && (size_t)M * (size_t)N * 2 < ((size_t)1 << 32)) {
     const long t64 = (long)((M + 63) / 64) * (N / 128), t128 = (long)(N / 128);
     const auto splits_evenly = [KT](int sx) { return KT / sx >= 4 && (KT + (KT + sx - 1) / sx - 1) / ((KT + sx - 1) / sx) == sx; };
-    if (M >= 33 && M <= 95 && t64 * 2 >= 160 && t64 * 2 <= 256 && splits_evenly(2)) {
+    const long xcus = std::min(256, exchange_cus());   // (QUICK_AMD_EXCHANGE_CUS: how many CUs the K slices of a tile may count on)
+    if (M >= 33 && M <= 64 && t64 * 2 >= 160 && t64 * 2 <= xcus && splits_evenly(2)) {   // (r06: up to 64 tokens; above, the 128 x 128 tile -- see the four-wave rule)
       p.kernel = QUICK_KERNEL_XW;
       xw_auto_mb = 2;
       xw_auto_pairs = 1;
       xw_auto_s = 2;
-    } else if (M >= 96 && M <= 128 && t128 * 4 <= 256 && t128 * 4 >= 96 && splits_evenly(4)) {
+    } else if (M >= 65 && M <= 128 && t128 * 4 <= xcus && t128 * 4 >= 96 && splits_evenly(4)) {
       p.kernel = QUICK_KERNEL_XW;
       xw_auto_mb = 4;
       xw_auto_pairs = 1;

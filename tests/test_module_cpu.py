@@ -175,11 +175,13 @@ def test_exchange_cus_override_keeps_k_slices_on_one_cu():
         return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=e).stdout.strip().splitlines()[-2:]
     auto, forced = run({})
     assert "slices=4" in auto and "slices=2" in forced
-    for cus in ("0", "100"):          # 64 tiles of 64 tokens / 128 tiles of 128 tokens: two slices each do not fit 100 CUs
+    for cus in ("0", "60"):           # 32 tiles of 128 x 128 (65 tokens) / 128 tiles (512 tokens): two slices each do not fit 60 CUs
         auto, forced = run({"QUICK_AMD_EXCHANGE_CUS": cus})
         assert "slices=4" not in auto and "slices=2" not in auto and "slices=1" in forced, (cus, auto, forced)
-    auto, forced = run({"QUICK_AMD_EXCHANGE_CUS": "128"})      # 64 tiles x 2 slices fit, 128 tiles x 2 do not
-    assert auto.startswith("xk") and "slices=2" in auto and "slices=1" in forced
+    auto, forced = run({"QUICK_AMD_EXCHANGE_CUS": "100"})      # 32 tiles x 2 slices fit, x 4 do not; 128 tiles x 2 do not
+    assert auto.startswith("xw") and "slices=2" in auto and "slices=1" in forced
+    auto, forced = run({"QUICK_AMD_EXCHANGE_CUS": "128"})      # [r06: the four-wave rules honour the override as the exchange-K ones always did]
+    assert auto.startswith("xw") and "slices=4" in auto and "slices=1" in forced
 
 
 def test_plan_describe_pins_the_shape_heuristics():
@@ -194,7 +196,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "grid=464x1x1" in plan(1, 4096, 22016, kernel_id=kernels.KERNEL_SKINNY)          # 1376 blocks in 3 rounds of <= 464
     assert "dequant=exact" in plan(8, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)            # one block per workgroup: the table does not pay
     assert plan(64, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4") and "deferred-zero-fragment" in plan(64, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)   # (r01-r05's pick; AUTO: the r06 mid-token kernels, below)
-    assert plan(65, 14336, 4096).startswith("xk tokens=64") and "slices=4" in plan(65, 14336, 4096)   # r03: 64 exchange-K tiles x 4 K slices = one round (K = 4096 there until r06 gave 65..128 tokens x K <= 8192 to the mid-token kernels)
+    assert plan(64, 14336, 4096).startswith("xk tokens=64") and "slices=8" in plan(64, 14336, 4096)   # r03: 32 exchange-K tiles x 8 K slices = one round (x 4 at 65 x 4096 x 4096 there until r06: the mid-token kernels, and from 65 tokens the 128 x 128 four-wave tile)
     assert plan(32, 4096, 8192, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4")   # 256 workgroups of 64 channels x 16 tokens: one round, 32 stages each
     assert plan(32, 4096, 28672).startswith("tiled")         # (r01: where the skinny workgroups would be two rounds, the tiled kernel, no K split needed)
     # K split until the 256 CUs are covered; the workspace is what workspace_bytes_ex says
@@ -226,7 +228,7 @@ def test_plan_describe_pins_the_shape_heuristics():
         "xk tokens=64 channels=128 waves=8 ring=5 queue=4 grid=256 slices=1")                            # r03's bench line: one 64 x 128 tile per CU
     assert plan(64, 4096, 22016, kernel_id=X).startswith("xk tokens=64") and "slices=2" in plan(64, 4096, 12288, kernel_id=X)   # 172 / 96 tiles of 64 x 128 (r03's picks there; AUTO up to 64 tokens: r06's mid-token kernels, below)
     assert plan(128, 11008, 4096).startswith("xw tokens=128 channels=128") and "grid=128 slices=4" in plan(128, 11008, 4096)   # r05 audit: one row of 128 x 128 tiles x four slices (r03-r04: xk 64-token tiles; K = 4096: r06's mid-token kernels, below)
-    assert plan(80, 13824, 5120).startswith("xw tokens=64 channels=128") and plan(48, 5120, 5120).startswith("skinny ntw=4")        # 33..64 tokens where the mid-token kernels are not ahead: the r03-r05 picks
+    assert plan(64, 13824, 5120).startswith("xk tokens=64 channels=128") and plan(80, 13824, 5120).startswith("xw tokens=128 channels=128") and plan(48, 5120, 5120).startswith("skinny ntw=4")        # 33..64 tokens where the mid-token kernels are not ahead: the r03-r05 picks
     # [r06] the mid-token kernels (w4a16_xm.hpp), where the audit has them ahead (profiles/r06_xm_audit.txt): 17..32 tokens -- the fewest channel pairs
     # per workgroup that cover the layer in one round; 33..64 tokens -- two 32-token tiles on layers of <= 8192 channels; K <= 8192
     assert plan(64, 4096, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x2") and plan(33, 4096, 4096).startswith("xm tokens=32 channels=32 waves=8 grid=128x2")
@@ -243,13 +245,16 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert not plan(64, 4096, 28672).startswith("xm") and not plan(24, 8192, 57344).startswith("xm") and not plan(64, 28672, 8192).startswith("xm")
     assert not plan(48, 5120, 5120).startswith("xm") and plan(56, 5120, 5120).startswith("xm tokens=32 channels=64 waves=8 grid=80x2")
     # 65..128 tokens (profiles/r06_xm_audit_65_128.txt, three boxes): 32-token tiles x the fewest pairs that make one round on narrow layers with K <= 8192
-    # (K = 11008 up to 80 tokens), 64-token tiles on wide ones up to 95 tokens (two pairs and K = 4096: up to 128); the four-slice exchange launches elsewhere
+    # (K = 11008 up to 80 tokens), 64-token tiles x <= 2 pairs up to 95 tokens (K = 4096: up to 128); the 128 x 128 four-wave tile elsewhere
     assert plan(65, 4096, 4096).startswith("xm tokens=32 channels=64 waves=8 grid=64x3") and plan(128, 4096, 4096).startswith("xm tokens=32 channels=64 waves=8 grid=64x4")
     assert plan(80, 11008, 4096).startswith("xm tokens=32 channels=64") and not plan(96, 11008, 4096).startswith("xm") and not plan(65, 14336, 4096).startswith("xm")
     assert plan(96, 5120, 5120).startswith("xm tokens=32 channels=64 waves=8 grid=80x3") and not plan(112, 5120, 5120).startswith("xm")
     assert plan(96, 4096, 6144).startswith("xm tokens=32 channels=96 waves=8 grid=64x3") and not plan(128, 4096, 6144).startswith("xm")
     assert plan(128, 4096, 8192).startswith("xm tokens=64 channels=64 waves=8 grid=128x2") and plan(80, 8192, 8192).startswith("xm tokens=64 channels=64") and not plan(96, 8192, 8192).startswith("xm")
-    assert plan(95, 4096, 12288).startswith("xm tokens=64 channels=96 waves=8 grid=128x2") and not plan(96, 4096, 12288).startswith("xm") and plan(95, 8192, 10240).startswith("xm tokens=64 channels=96")
+    assert plan(95, 4096, 8192).startswith("xm tokens=64 channels=64 waves=8 grid=128x2") and plan(95, 8192, 8192).startswith("xm tokens=64 channels=64")
+    # ... and where the mid-token kernels are not taken, 65..95 tokens run the 128 x 128 four-wave tile as 96..128 do (r06 audit: the 64-token exchange tiles r03-r05 ran there were 10-32 % behind)
+    assert plan(80, 4096, 12288).startswith("xw tokens=128 channels=128") and "slices=2" in plan(80, 4096, 12288) and plan(65, 4096, 22016).startswith("xw tokens=128 channels=128")
+    assert plan(65, 14336, 4096).startswith("xw tokens=128 channels=128") and "slices=4" in plan(65, 14336, 4096) and plan(80, 8192, 10240).startswith("xw tokens=128 channels=128")
     assert not plan(65, 4096, 22016).startswith("xm") and not plan(65, 4096, 28672).startswith("xm") and not plan(129, 4096, 4096).startswith("xm")
     assert not plan(64, 4096, 4096, G=64).startswith("xm") and not plan(64, 4608, 4096, G=384).startswith("xm")               # G a power-of-two multiple of 128
     assert plan(40, 4096, 4096, kernel_id=kernels.KERNEL_XM | (3 << 4) | (2 << 8)).startswith("xm tokens=64 channels=96 waves=8 grid=43x1")   # forced: pairs, 64-token tiles; ragged last block
