@@ -59,6 +59,9 @@ BARRIER = os.environ.get("XM_BARRIER", "0") != "0"   # prologue barrier between 
 WFIRST = os.environ.get("XM_WFIRST", "1") != "0"     # W(0) in front of x(0) in the prologue (A/B switch)
 DQ = os.environ.get("XM_D", "")                      # queue depths of the six configurations, e.g. 2,2,2,2,2,2 (A/B switch)
 W_NT = " nt" if os.environ.get("XM_W_NT", "1") != "0" else ""   # the weights are read once: streaming cache policy (as the lean kernels)
+if os.environ.get("XM_W_POLICY") is not None:                    # A/B switch: any combination of sc0 / sc1 / nt on the weight loads, e.g. XM_W_POLICY="sc1 nt"
+    W_NT = (" " + os.environ["XM_W_POLICY"].strip()) if os.environ["XM_W_POLICY"].strip() else ""
+X_POLICY = (" " + os.environ["XM_X_POLICY"].strip()) if os.environ.get("XM_X_POLICY", "").strip() else ""   # A/B switch: cache policy bits on the x pieces (LDS-DMA)
 JITQ_ENV = os.environ.get("XM_JITQ", "")                # "q": every configuration requests W(s + 1) in quarter q of stage s; "-1": none does (A/B switch; default: Cfg.jitq)
 SBAR = os.environ.get("XM_SBAR", "")                   # quarters at whose head every stage has a workgroup barrier (e.g. "0" or "1,3"): phase-locks the waves' requests (A/B switch;
                                                        # only for shapes whose waves own equally many k tiles)
@@ -169,7 +172,7 @@ class Cfg:
         pairs; the caller puts at least one instruction between the two"""
         out = []
         for i in range(self.NX):
-            ld = I(f"buffer_load_dwordx4 {v(self.VX + i)}, {sr(S_DX, 4)}, {s(S_XQ[h])} offen lds", "vmem", [], ["m0"])
+            ld = I(f"buffer_load_dwordx4 {v(self.VX + i)}, {sr(S_DX, 4)}, {s(S_XQ[h])} offen{X_POLICY} lds", "vmem", [], ["m0"])
             ld.tag = tag
             out.append((I(f"s_add_u32 m0, {XDST}, {rs * 2 * self.HB + h * self.HB + i * 1024}", "salu", ["m0"], []), ld))
         return out
