@@ -130,8 +130,8 @@ template <int MB, int PR, int ABL = 0>
 __global__ __launch_bounds__(512) void w4a16_xm_kernel(const half_t* __restrict__ aX, const u32x4* __restrict__ aQW, const half_t* __restrict__ aS, int aM, int aK,
                                                        int aN, int tpg_log2, int gx, const XmRest rest) {
   if constexpr (ABL & 32) span_stamp(rest.span, 0);
-  [[maybe_unused]] unsigned long long t_entry = 0;
-  if constexpr (ABL & 64) t_entry = __builtin_amdgcn_s_memrealtime();
+  [[maybe_unused]] unsigned long long t_entry = 0, c_entry = 0, c_loop = 0;   // (c_: the shader clock counter, s_memtime -- core clocks against the 100 MHz stamps)
+  if constexpr (ABL & 64) { t_entry = __builtin_amdgcn_s_memrealtime(); c_entry = __builtin_amdgcn_s_memtime(); }
   extern __shared__ __attribute__((aligned(256))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = uniform(threadIdx.x >> 6);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512) void w4a16_xm_kernel(const half_t* __restrict_
     xm_run<MB, PR, (ABL & 64) != 0>(accr, rsx_lo, rsx_hi, rsw_lo, rsw_hi, rss_lo, rss_hi, x_row, x_chunk, m_last, k2, w_voff, s_voff, xrd, xdst, kb_tpg, ke, w_pstride, s_pstride, t_voff, xm_t);
   }
   [[maybe_unused]] unsigned long long t_loop = 0;
-  if constexpr (ABL & 64) t_loop = __builtin_amdgcn_s_memrealtime();
+  if constexpr (ABL & 64) { t_loop = __builtin_amdgcn_s_memrealtime(); c_loop = __builtin_amdgcn_s_memtime(); }
   if (rest.silu_mul) xm_finish<MB, PR, true>(accr, smem, lane, wave, m0, nb, pv, aM, aN, rest);
   else xm_finish<MB, PR, false>(accr, smem, lane, wave, m0, nb, pv, aM, aN, rest);
   if constexpr (ABL & 32) span_stamp(rest.span, 1);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512) void w4a16_xm_kernel(const half_t* __restrict_
     const unsigned long long t_exit = __builtin_amdgcn_s_memrealtime();
     if (rest.dbg != nullptr && lane == 0) {
       unsigned long long* o = rest.dbg + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 511u) * 8 + wave) * 8;
-      o[0] = t_entry; o[1] = xm_t[0]; o[2] = xm_t[1]; o[3] = xm_t[2]; o[4] = t_loop; o[5] = t_exit;
+      o[0] = t_entry; o[1] = xm_t[0]; o[2] = xm_t[1]; o[3] = xm_t[2]; o[4] = t_loop; o[5] = t_exit; o[6] = c_entry; o[7] = c_loop;
     }
   }
 }

@@ -31,7 +31,7 @@ for spec in (args or ["64x4096x4096", "64x4096x22016"]):
         ws = torch.zeros((DBG + (1 << 20)) // 8, dtype=torch.int64, device=dev)
         k16 = kid + (16 << 16)
         REP = 8
-        acc = []
+        acc, clk = [], []
         for i in range(nsets + REP):
             qw, sc, qz = sets[i % nsets]
             ws.zero_()
@@ -52,8 +52,12 @@ for spec in (args or ["64x4096x4096", "64x4096x22016"]):
                         cols.append(full)
                 cols += [raw[:, 4], raw[:, 5]]
                 acc.append(np.stack(cols, 1).astype(np.float64) / 100.0)
+                # core clock of the wave between entry and the end of its loop: s_memtime ticks over the 100 MHz stamps
+                dt = (raw[:, 4] - raw[:, 0]).astype(np.float64) / 100.0
+                dc = (raw[:, 7] - raw[:, 6]).astype(np.float64)
+                clk.append(float(np.median(dc[dt > 0] / dt[dt > 0]) / 1e3))
         tot = np.mean([d[:, 8].max() - d[:, 0].min() for d in acc])
-        print(f"{spec} pr={pr}: {plan}\n   {len(acc[0])} waves stamped, {REP} launches; first entry -> last exit {tot:.2f} us")
+        print(f"{spec} pr={pr}: {plan}\n   {len(acc[0])} waves stamped, {REP} launches; first entry -> last exit {tot:.2f} us; core clock entry -> loop left (median over waves) {np.mean(clk):.2f} GHz")
         print(f"   {'phase (us since the first wave entered)':42s} {'first':>7s} {'mean':>7s} {'last':>7s}    own: min  mean  max (since the wave's previous stamp)")
         for i, n in enumerate(NAMES):
             rel = [d[:, i] - d[:, 0].min() for d in acc]
