@@ -125,7 +125,8 @@ int quick_w4a16_workspace_check(const void* workspace, size_t workspace_bytes, v
  * bit field -- every field 0 = "planner's choice within the family":
  *   bits 0-3    family, QUICK_KERNEL_*
  *   bits 4-7    SKINNY: channel tiles of 16 per workgroup (1, 2, 4; 8 = [r05] the straight-line eight-tile fragment kernel where it is built --
- *               9..16 tokens, G = 128, K / 128 = 8 waves x slices x {2, 4, 7, 8} k tiles, no RMSNorm prologue -- else 4); TILED: token tiles of 16 per workgroup (2, 4, 8);
+ *               9..16 tokens, G = 128, K / 128 = 8 waves x slices x {2, 4, 7, 8} k tiles, no RMSNorm prologue -- else 4; 7 = [r06] the same kernel with seven tiles per
+ *               workgroup: K = 8192, one slice, N % 112 == 0 -- else 4); TILED: token tiles of 16 per workgroup (2, 4, 8);
  *               WIDE / XK / XW: token tiles of 32 per workgroup (WIDE 2, 4, 8; XK 2, 4; XW 2, 4, 8 -- 0 = 4; 8 = the 256 x 256 tile; [r06] WIDE 8 x 2 pairs runs
  *               128 x 256 tiles: r02's hipcc-scheduled 256 x 256 tile spilled registers and lives on in tools builds only);
  *               XM: 32-channel pairs per workgroup (1..3; 0 = the fewest that cover the layer in one round)

@@ -1091,10 +1091,12 @@ static thread_local bool g_span_unsupported = false;  // set by a launcher asked
 // results that -amdgpu-waitcnt-forcezero cured (hipcc's wait counts around guarded / replayed requests in a loop).  Here
 // every wave owns EXACTLY T k tiles (the planner only picks the kernel when K / 128 == 8 waves x ksplit x T), every request is unconditional,
 // nothing is replayed and no request's result dies unread: the form in which hipcc's counts are exact (as in the lean kernels).
-template <int T, bool NT, bool SPAN = false>
+// [r06, late] NTW = 7: the same kernel with SEVEN channel tiles per workgroup, for layers whose block count makes whole rounds that way -- 16 x 8192 x 57344 (Llama-2-70B
+// gate_up: 57344 = 7 x 8192) is 448 blocks of 128 channels = 1.75 rounds of one workgroup per CU (212 registers), but 512 blocks of 112 = two whole rounds.
+template <int T, bool NT, bool SPAN = false, int NTW_ = 8>
 __global__ __launch_bounds__(512) void w4a16_frag8_kernel(const GemmArgs a) {
   if constexpr (SPAN) span_stamp(a.span, 0);
-  constexpr int NTW = 8, WAVES = 8;
+  constexpr int NTW = NTW_, WAVES = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   floatx4* red = (floatx4*)smem;  // [WAVES][NTW][64]
   const int lane = threadIdx.x & 63;
@@ -1934,13 +1936,15 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         const char* e = getenv("QUICK_AMD_FRAG8");
         return e ? atoi(e) : 1;
       }();
-      const bool asked = family == QUICK_KERNEL_SKINNY && mt_req == 8;
+      const bool asked7 = family == QUICK_KERNEL_SKINNY && mt_req == 7;   // (forced: seven tiles per workgroup, T = 8, one slice)
+      const bool asked = (family == QUICK_KERNEL_SKINNY && mt_req == 8) || asked7;
       const bool auto_ok = frag8_env != 0 && !with_ln && family == QUICK_KERNEL_AUTO && !mt_req && !waves_req && !(kernel >> 12) && grid_split_k == 0 && p.mt == 4 && p.dz &&
                            !p.xlds && (long)K * N >= 60L * 1000 * 1000;
       if ((asked || auto_ok) && G == 128 && M >= 9 && M <= 16 && N % 128 == 0 && KT % 8 == 0 && (long)M * K * 2 < (1L << 31)) {
         int best_ks = 0, best_t = 0;
         for (int s2 = 1; s2 <= 4; s2 *= 2) {   // the forced slice count, else the first that gives >= 256 workgroups, else the last one that fits
           if (grid_split_k > 0 && s2 != grid_split_k) continue;
+          if (asked7 && s2 != 1) continue;
           if ((KT / 8) % s2 != 0) continue;
           const int t = KT / 8 / s2;
           if (t != 2 && t != 4 && t != 7 && t != 8) continue;
@@ -1953,6 +1957,7 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         // ... and 8192 x 28672 -- 224 blocks, one slice -- 28.7 -> 23.5: one slice from 192 blocks, K slices only on whole multiples of 64 blocks)
         // (128 blocks x two slices, 8192 x 16384: 16.4 -> 18.5 us, behind: K slices only where measured ahead, 64 blocks x four)
         if (best_ks && !asked && !((best_ks == 1 && N / 128 >= 192) || (N / 128 == 64 && best_ks == 4))) best_ks = 0;
+        if (asked7 && !(best_ks == 1 && best_t == 8 && N % 112 == 0)) best_ks = 0;
         if (best_ks) {
           p.mt = 8;
           p.waves = 8;
@@ -1964,6 +1969,23 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
           p.grid_x = N / 128;
           p.ntiles = (N / 128) * ((M + 15) / 16);
           p.slab_floats = (size_t)8 * 256;
+          // [r06, late] seven tiles per workgroup where that makes fewer or fuller rounds of one workgroup per CU (one slice, T = 8 only -- K = 8192): a round costs
+          // its weights + its x fragments (x: as many bytes as four tiles' weights), so 7 + 4 against 8 + 4 per round.  16 x 8192 x 57344: 448 blocks = 2 rounds (the
+          // second three quarters full) -> 512 blocks = 2 full rounds of less: QUICK_AMD_FRAG7=0 keeps eight.
+          static const int frag7_env = [] {
+            const char* e = getenv("QUICK_AMD_FRAG7");
+            return e ? atoi(e) : 1;
+          }();
+          if (best_ks == 1 && best_t == 8 && N % 112 == 0 && (asked7 || (!asked && frag7_env != 0))) {
+            const int cus = cu_count();
+            const long cost8 = (long)((N / 128 + cus - 1) / cus) * 12, cost7 = (long)((N / 112 + cus - 1) / cus) * 11;
+            if (asked7 || cost7 < cost8) {
+              p.mt = 7;
+              p.grid_x = N / 112;
+              p.ntiles = (N / 112) * ((M + 15) / 16);
+              p.slab_floats = (size_t)7 * 256;
+            }
+          }
         }
       }
     }
@@ -2358,6 +2380,23 @@ static int run_gemm(const void* x, const void* qweight, const void* scales, cons
     switch (p.mt) {
       case 1: launch_skinny<1>(p, a, L); break;
       case 2: launch_skinny<2>(p, a, L); break;
+      case 7: {   // seven tiles per workgroup: the straight-line fragment kernel with T = 8, one slice
+        if (p.frag8_t != 8 || p.ksplit != 1 || f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "skinny: seven channel tiles per workgroup only in the straight-line fragment kernel (K = 8192, one slice), no RMSNorm prologue");
+        dim3 grid(p.grid_x, (M + 15) / 16, 1), block(512);
+        const unsigned lds = 8 * 7 * 1024;
+        if (a.span) {
+          auto kfn = w4a16_frag8_kernel<8, true, true, 7>;
+          static std::atomic<unsigned long long> attr_set_s{0};
+          (void)lds_limit_once(attr_set_s, (const void*)kfn, (int)kLdsPerCu);
+          hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
+        } else {
+          auto kfn = w4a16_frag8_kernel<8, true, false, 7>;
+          static std::atomic<unsigned long long> attr_set{0};
+          (void)lds_limit_once(attr_set, (const void*)kfn, (int)kLdsPerCu);
+          hipExtLaunchKernelGGL(kfn, grid, block, lds, L.st, L.start, L.stop, 0, a);
+        }
+        break;
+      }
       case 8: {
         if (!p.frag8_t || f.ln_w) return fail(QUICK_ERR_UNSUPPORTED, "skinny: eight channel tiles per workgroup only in the straight-line fragment kernel, no RMSNorm prologue");
         dim3 grid(p.grid_x, (M + 15) / 16, p.ksplit), block(512);

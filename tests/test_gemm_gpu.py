@@ -1300,6 +1300,59 @@ def test_eight_tile_fragment_kernel_against_oracle(qa, device, M, K, N, ks):
         qa.gemm_forward(xd, *packed, kernel_id=kid, grid_split_k=ks, rmsnorm_weight=torch.ones(K, dtype=torch.float16, device=device))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [9, 13, 16])
+@pytest.mark.parametrize("N", [896, 1792, 2688])
+def test_seven_tile_fragment_kernel_against_oracle(qa, device, M, N):
+    """[r06, late] the straight-line fragment kernel with SEVEN channel tiles per workgroup (T = 8: K = 8192, one slice) -- the launch AUTO runs on layers whose block
+    count makes whole rounds that way (16 x 8192 x 57344: 448 blocks of 128 channels -> 512 of 112).  Forced by kernel id (SKINNY, 7 tiles) on widths of 8, 16 and 24
+    blocks: against the oracle into a NaN-poisoned output, three times bit-equal, against the four-tile kernel, with bias + residual, SiLU * mul, and no RMSNorm prologue."""
+    from quick_amd import kernels as K_
+    K = 8192
+    kid = K_.KERNEL_SKINNY | (7 << 4)
+    plan = K_.plan_describe(M, K, N, 128, kid)
+    assert plan.startswith("skinny ntw=7 ") and "ksplit=1" in plan and f"grid={N // 112}x" in plan, plan
+    x, iw, s, z = oracle.make_synthetic(M, K, N, 128, seed=M + N)
+    want = oracle.w4a16_forward(x, iw, s, z, 128).astype(np.float32)
+    packed = _pack_dev(iw, s, z, device)
+    xd = _dev(x, device)
+    ys = []
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device=device)
+        ys.append(qa.gemm_forward(xd, *packed, kernel_id=kid, out=out))
+        assert rel_err(ys[-1].cpu().numpy(), want) <= TOL, plan
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2]), plan
+    y4 = qa.gemm_forward(xd, *packed, kernel_id=K_.KERNEL_SKINNY | (1 << 4))
+    assert rel_err(ys[0].cpu().numpy(), y4.float().cpu().numpy()) <= 1e-3
+    bias = torch.linspace(-1, 1, N, device=device).half()
+    res = torch.randn(M, N, device=device).half()
+    yb = qa.gemm_forward(xd, *packed, bias=bias, residual=res, kernel_id=kid)
+    assert rel_err(yb.cpu().numpy(), want + bias.float().cpu().numpy() + res.float().cpu().numpy()) <= TOL, plan
+    ysm = qa.gemm_forward(xd, *packed, silu_mul=True, kernel_id=kid)
+    yf = ys[0].float().view(M, N // 16, 2, 8)
+    ref = (torch.nn.functional.silu(yf[:, :, 0].half().float()).half().float() * yf[:, :, 1]).half().view(M, N // 2)
+    assert (ysm.float() - ref.float()).abs().max() <= 2e-3 * ref.float().abs().max() + 1e-3, plan
+    with pytest.raises(NotImplementedError):
+        qa.gemm_forward(xd, *packed, kernel_id=kid, rmsnorm_weight=torch.ones(K, dtype=torch.float16, device=device))
+
+
+@pytest.mark.gpu
+def test_llama2_70b_gate_up_shape_runs_seven_tiles_and_equals_eight(qa, device):
+    """AUTO at 16 x 8192 x 57344 (Llama-2-70B gate_up at bs = 16) takes the seven-tile launch (two whole rounds of workgroups); the whole output against the forced
+    eight-tile launch -- the same sums in the same order per output: bit-equal (sampled channels against the oracle: test_e2e_layer_shapes_sampled_channels_against_oracle)."""
+    from quick_amd import kernels as K_, packing
+    M, K, N = 16, 8192, 57344
+    assert K_.plan_describe(M, K, N, 128).startswith("skinny ntw=7 "), K_.plan_describe(M, K, N, 128)
+    gen = torch.Generator(device=device).manual_seed(7)
+    qw, sc, qz = packing.random_mi355x(K, N, 128, device, gen)
+    x = (torch.randn(M, K, device=device, generator=gen) * 0.5).half()
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=device)
+    y7 = qa.gemm_forward(x, qw, sc, qz, out=out)
+    y8 = qa.gemm_forward(x, qw, sc, qz, kernel_id=K_.KERNEL_SKINNY | (8 << 4))
+    assert not torch.isnan(y7).any()
+    assert torch.equal(y7, y8)
+
+
 XW_TILES = [(4, 2), (4, 1), (2, 1), (8, 2)]
 XW_IDS = ["128x256", "128x128", "64x128", "256x256"]
 

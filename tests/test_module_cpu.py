@@ -290,11 +290,14 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert "deferred-zero-table" in plan(12, 4096, 22016, kernel_id=kernels.KERNEL_SKINNY) and plan(16, 4096, 22016, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=4")
     # [r05] 9..16 tokens on the Llama-2-70B layers: the straight-line eight-tile fragment kernel where K / 128 = 8 waves x slices x {2, 4, 7, 8} and the
     # blocks come in multiples of 64 (measured ahead there); 80 blocks (the fused qkv) stay with four tiles
-    assert plan(16, 8192, 57344).startswith("skinny ntw=8") and "grid=448x1x1 ksplit=1" in plan(16, 8192, 57344)
+    # [r06, late] ... with SEVEN tiles per workgroup where that makes fuller rounds of one workgroup per CU: 57344 = 448 blocks of 128 (1.75 rounds) = 512 of 112 (two),
+    # 28672 = 224 of 128 = 256 of 112 (every CU busy); QUICK_AMD_FRAG7=0 / the forced eight-tile id keep eight
+    assert plan(16, 8192, 57344).startswith("skinny ntw=7") and "grid=512x1x1 ksplit=1" in plan(16, 8192, 57344)
+    assert "grid=448x1x1 ksplit=1" in plan(16, 8192, 57344, kernel_id=kernels.KERNEL_SKINNY | (8 << 4)) and plan(16, 8192, 1792, kernel_id=kernels.KERNEL_SKINNY | (7 << 4)).startswith("skinny ntw=7")
     assert plan(16, 28672, 8192).startswith("skinny ntw=8") and "grid=64x1x4 ksplit=4" in plan(16, 28672, 8192)
-    assert plan(16, 8192, 8192).startswith("skinny ntw=8") and "ksplit=4" in plan(16, 8192, 8192) and plan(9, 8192, 57344).startswith("skinny ntw=8")
+    assert plan(16, 8192, 8192).startswith("skinny ntw=8") and "ksplit=4" in plan(16, 8192, 8192) and plan(9, 8192, 57344).startswith("skinny ntw=7")
     assert plan(16, 8192, 10240).startswith("skinny ntw=4") and plan(8, 8192, 57344).startswith("skinny ntw=1") and not plan(17, 8192, 57344).startswith("skinny ntw=8")
-    assert plan(16, 8192, 28672).startswith("skinny ntw=8") and "grid=224x1x1 ksplit=1" in plan(16, 8192, 28672) and plan(16, 8192, 16384).startswith("skinny ntw=4")   # (one slice from 192 blocks; 128 blocks x 2 slices measured behind)
+    assert plan(16, 8192, 28672).startswith("skinny ntw=7") and "grid=256x1x1 ksplit=1" in plan(16, 8192, 28672) and plan(16, 8192, 16384).startswith("skinny ntw=4")   # (one slice from 192 blocks; 128 blocks x 2 slices measured behind)
     # r03 audit: from five tokens no LDS copy of x outside the table flavour; one-tile launches with K = 4096 run sixteen waves
     assert plan(6, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY).startswith("skinny ntw=1 waves=16 x=l2 dequant=exact") and "waves=8 x=lds" in plan(4, 4096, 4096, kernel_id=kernels.KERNEL_SKINNY)
     assert plan(7, 4096, 12288).startswith("skinny ntw=4 waves=8 x=l2") and plan(10, 11008, 4096).startswith("skinny ntw=4 waves=8 x=l2")
