@@ -1533,6 +1533,17 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
           }
         }
       }
+      // [r06, three-box audit of the final tree, profiles/r06_planner_audit.txt] 129..256 tokens on layers where FOUR slices of the 128 x 128 tile are exactly one round
+      // (N = 4096: 2 x 32 tiles x 4): the fit prefers two slices of the 64 x 128 tile there, and every box measured the 128 x 128 tile ahead -- 160 / 192 / 256 x 4096 x 4096
+      // 13.5-15.2 -> 12.6-14.0 us (4-7 %), 160 / 192 x 11008 x 4096 27.2-28.5 -> 24.1-26.7 (7-10 %).  (N = 5120: 320 workgroups, the 64-token tile stays ahead.)
+      if (xw_auto_mb == 2 && xw_auto_pairs == 1 && xw_auto_s == 2 && M > 128 && M <= 256 && N % 128 == 0) {
+        const long T41 = (long)((M + 127) / 128) * (N / 128);
+        if (T41 * 4 <= std::min(256, exchange_cus()) && KT / 4 >= 4 && (KT + (KT + 3) / 4 - 1) / ((KT + 3) / 4) == 4) {
+          xw_auto_mb = 4;
+          xw_auto_pairs = 1;
+          xw_auto_s = 4;
+        }
+      }
     }
     // [r04] where the r02 model's pick is the 256 x 256 tile with ONE K slice, the four-wave kernel with the generated 256 x 256 loop runs it
     // instead: 0.935-0.965 of the hipcc-scheduled kernel's time on 28 prefill shapes of 1024..8192 tokens in one session, bit-identical

@@ -260,7 +260,9 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(40, 4096, 4096, kernel_id=kernels.KERNEL_XM | (3 << 4) | (2 << 8)).startswith("xm tokens=64 channels=96 waves=8 grid=43x1")   # forced: pairs, 64-token tiles; ragged last block
     # r04: the four-wave kernels with generated loops (w4a16_xw.hpp) from 160 tokens (96 on wide layers), picked by their own launch-time model
     assert plan(512, 4096, 4096).startswith("xw tokens=128 channels=128 waves=4 ring=4 queue=4 grid=256 slices=2")    # the bench line: 128 x 128 tiles, two K slices
-    assert plan(256, 4096, 4096).startswith("xw tokens=64 channels=128 waves=4 ring=8 queue=8 grid=256 slices=2")
+    # [r06, three-box audit] 129..256 tokens where four slices of the 128 x 128 tile are exactly one round (N = 4096): that tile, not two slices of 64 x 128 (the fit's pick, 4-10 % behind on every box)
+    assert plan(256, 4096, 4096).startswith("xw tokens=128 channels=128 waves=4 ring=4 queue=4 grid=256 slices=4") and "tokens=128 channels=128" in plan(160, 11008, 4096) and "slices=4" in plan(192, 11008, 4096)
+    assert plan(160, 5120, 5120).startswith("xw tokens=64 channels=128") and "slices=2" in plan(160, 5120, 5120)      # (320 workgroups with four slices: the 64-token tile stays)
     assert plan(160, 4096, 6144).startswith("xw tokens=128 channels=128") and "slices=2" in plan(160, 4096, 6144)
     assert plan(1024, 4096, 4096).startswith("xw tokens=128 channels=128 waves=4 ring=4 queue=4 grid=256 slices=1")   # 256 tiles of 128 x 128: one round, nothing to exchange
     assert "slices=2" in plan(512, 11008, 4096) and "xw tokens=128 channels=128" in plan(512, 11008, 4096)            # 128 tiles x 2 slices of 43 stages
