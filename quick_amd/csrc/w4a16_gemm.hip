@@ -1315,7 +1315,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
         const int p1 = one_round((M + 31) / 32), p2 = one_round(2);
         if (p1 && p1 <= 2 && (KT <= 64 || (KT <= 86 && M <= 80))) mb = 1, pr = p1;
         else if (p1 == 3 && M <= 96 && KT <= 64) mb = 1, pr = 3;
-        else if (p2 && 10 * ((pairs + p2 - 1) / p2 * 2) >= 8 * cus && p2 <= 2 && (KT <= 32 || (M <= 95 && KT <= 64))) mb = 2, pr = p2;
+        // [r06, end of round: 96 / 128 x 8192 x 8192 on three more boxes (profiles/r06_planner_audit.txt)] ... and up to 128 tokens with K <= 8192 as well: the four-slice 128 x 128 launch these
+        // counts ran reads 19.6-32.8 us by box there (all 256 CUs in a four-way exchange), the two 64-token tiles 21.2-23.4: ahead by 9-11 % on three boxes of five, level on one, 2-4 % behind on one.
+        else if (p2 && 10 * ((pairs + p2 - 1) / p2 * 2) >= 8 * cus && p2 <= 2 && KT <= 64) mb = 2, pr = p2;
       } else if (M <= 32) {
         if (KT <= 64 && (pr = one_round(1))) mb = 1;
       } else if (2 * pairs <= cus) {

@@ -250,7 +250,7 @@ def test_plan_describe_pins_the_shape_heuristics():
     assert plan(80, 11008, 4096).startswith("xm tokens=32 channels=64") and not plan(96, 11008, 4096).startswith("xm") and not plan(65, 14336, 4096).startswith("xm")
     assert plan(96, 5120, 5120).startswith("xm tokens=32 channels=64 waves=8 grid=80x3") and not plan(112, 5120, 5120).startswith("xm")
     assert plan(96, 4096, 6144).startswith("xm tokens=32 channels=96 waves=8 grid=64x3") and not plan(128, 4096, 6144).startswith("xm")
-    assert plan(128, 4096, 8192).startswith("xm tokens=64 channels=64 waves=8 grid=128x2") and plan(80, 8192, 8192).startswith("xm tokens=64 channels=64") and not plan(96, 8192, 8192).startswith("xm")
+    assert plan(128, 4096, 8192).startswith("xm tokens=64 channels=64 waves=8 grid=128x2") and plan(80, 8192, 8192).startswith("xm tokens=64 channels=64") and plan(128, 8192, 8192).startswith("xm tokens=64 channels=64 waves=8 grid=128x2") and not plan(129, 8192, 8192).startswith("xm")   # (K <= 8192 up to 128 tokens since the end of r06: the four-slice exchange launch there follows the box, 19.6-32.8 us)
     assert plan(95, 4096, 8192).startswith("xm tokens=64 channels=64 waves=8 grid=128x2") and plan(95, 8192, 8192).startswith("xm tokens=64 channels=64")
     # ... and where the mid-token kernels are not taken, 65..95 tokens run the 128 x 128 four-wave tile as 96..128 do (r06 audit: the 64-token exchange tiles r03-r05 ran there were 10-32 % behind)
     assert plan(80, 4096, 12288).startswith("xw tokens=128 channels=128") and "slices=2" in plan(80, 4096, 12288) and plan(65, 4096, 22016).startswith("xw tokens=128 channels=128")

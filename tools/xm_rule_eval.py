@@ -36,7 +36,7 @@ def rule(M, K, N):
             return (1, p1)
         if p1 == 3 and M <= 96 and KT <= 64:
             return (1, 3)
-        if p2 and 10 * (-(-pairs // p2) * 2) >= 8 * CUS and p2 <= 2 and (KT <= 32 or (M <= 95 and KT <= 64)):
+        if p2 and 10 * (-(-pairs // p2) * 2) >= 8 * CUS and p2 <= 2 and KT <= 64:
             return (2, p2)
         return None
     if M <= 32:
