@@ -1328,7 +1328,9 @@ static Plan make_plan(int M, int K, int N, int G, int kernel, int grid_split_k, 
           const int wgs = (pairs + p1 - 1) / p1 * 2;
           if (10 * wgs >= 7 * cus || M >= 56) mb = 1, pr = p1;
         } else if (p2) {
-          mb = 2, pr = p2;
+          // [r06, three boxes, profiles/r06_xm_audit.txt] ... except 57..64 tokens on a long K (> 4096) where the 64-token tiles leave > 30 % of the CUs idle: 64 x 8192 x 10240
+          // (160 workgroups) 21.6-22.0 us against 20.3-21.2 for the 64 x 128 four-wave tile on every box (level at 56 tokens, 3-8 % ahead up to 48)
+          if (!(KT > 32 && M > 56 && 10 * ((pairs + p2 - 1) / p2) < 7 * cus)) mb = 2, pr = p2;
         }
       }
       if (!mb) pr = 0;

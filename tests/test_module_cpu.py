@@ -206,7 +206,8 @@ def test_plan_describe_pins_the_shape_heuristics():
     p = plan(128, 11008, 4096)
     # (what workspace_bytes_ex asks for also covers the launch a SiLU * mul epilogue falls back to where the exchange-K plan cannot carry it)
     assert "slices=4" in p and int(p.rsplit("workspace=", 1)[1]) == 65536 + (16 << 20) <= _lib.load().quick_w4a16_workspace_bytes_ex(128, 11008, 4096, 128, 0, 0)
-    assert plan(64, 8192, 10240).startswith("xm tokens=64 channels=64 waves=8 grid=160x1")   # r06's mid-token kernels (r05 audit: 80 tiles of 64 x 128 x two exchange slices, level with it; r02-r04: wide tiles, three K slices)
+    # r06's mid-token kernels up to 56 tokens; 57..64 on this long-K layer that leaves 38 % of the CUs idle: the 64 x 128 four-wave tile with two exchange slices (3.5-6 % ahead on three boxes; r02-r04: wide tiles, three K slices)
+    assert plan(56, 8192, 10240).startswith("xm tokens=64 channels=64 waves=8 grid=160x1") and plan(64, 8192, 10240).startswith("xw tokens=64 channels=128 waves=4 ring=8 queue=8 grid=160 slices=2")
     assert "grid=80x3 ksplit=3" in plan(64, 8192, 10240, kernel_id=kernels.KERNEL_TILED)
     # r01's tiled kernel (kernel_id TILED; the planner's own choice for G < 128): 256-channel tiles by how they quantise onto 256 CUs
     T = kernels.KERNEL_TILED

@@ -56,6 +56,8 @@ def rule(M, K, N):
     wgs = -(-pairs // pick[1]) * (2 if pick[0] == 1 else 1)
     if pick[0] == 1 and 10 * wgs < 7 * CUS and M < 56:   # (two 32-token tiles on a layer that leaves CUs idle: the fragment kernels stay ahead up to 55 tokens)
         return None
+    if pick[0] == 2 and KT > 32 and M > 56 and 10 * wgs < 7 * CUS:   # (64-token tiles, long K, > 30 % of the CUs idle: behind the 64 x 128 four-wave tile from 57 tokens -- 64 x 8192 x 10240 on three boxes)
+        return None
     return pick
 
 
